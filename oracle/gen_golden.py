@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own compiled code (TEST INFRASTRUCTURE).
+
+Runs only where /root/reference exists: `make -C oracle ref` compiles the reference's
+src/pixel.cpp + src/table.cpp into oracle/_ref/libx265ref_pixel.so, and this script calls the
+reference functions through ctypes on seeded inputs and stores {inputs, expected outputs}.
+The fixtures are data only; no reference source text is stored.
+
+Functions called (mangled C++ names; signatures from inc/x265.h:650-670 and src/pixel.cpp):
+  xSadN[0..4]                    src/pixel.cpp:711
+  xCalcHADs4x4/8x8/16x16/32x32/64x64, xCalcHADs32x32_test   src/pixel.cpp:63-527
+  xSubDct / xQuant / xDeQuant / xIDctAdd                      src/pixel.cpp:3446, 1054, 1244, 5938
+  xPredInterLumaBlk                                           src/pixel.cpp:8745
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+LIB = os.path.join(HERE, "_ref", "libx265ref_pixel.so")
+
+SLICE_P, SLICE_I, MODE_INVALID = 1, 2, 255
+
+
+def aligned(shape, dtype, align=64):
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape)) * dtype.itemsize
+    raw = np.zeros(n + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+def ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+class XMV(C.Structure):
+    _fields_ = [("x", C.c_int16), ("y", C.c_int16)]
+
+
+def edge_blocks(n):
+    """(src, ref) pairs that hit the extremes: all-equal, max difference, checkerboards, DC-max."""
+    z = np.zeros((n, n), np.uint8)
+    f = np.full((n, n), 255, np.uint8)
+    yy, xx = np.mgrid[0:n, 0:n]
+    chk = (((yy + xx) & 1) * 255).astype(np.uint8)
+    ramp = ((xx * 255) // max(n - 1, 1)).astype(np.uint8)
+    return [(z, z), (f, f), (f, z), (z, f), (chk, 255 - chk), (chk, z), (ramp, ramp.T.copy()), (f, chk)]
+
+
+def main():
+    if not os.path.exists(LIB):
+        sys.exit("build oracle/_ref first: make -C oracle ref")
+    lib = C.CDLL(LIB)
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20251111)
+
+    def block_cases(n, n_random):
+        cases = edge_blocks(n)
+        for i in range(n_random):
+            a = rng.integers(0, 256, (n, n), dtype=np.uint8)
+            if i % 3 == 0:      # small residual, like a good prediction
+                b = np.clip(a.astype(int) + rng.integers(-6, 7, (n, n)), 0, 255).astype(np.uint8)
+            elif i % 3 == 1:    # smooth content
+                b = np.clip(128 + 60 * np.sin(np.arange(n)[None, :] / 3.0 + i) + rng.integers(-9, 10, (n, n)), 0, 255).astype(np.uint8)
+            else:
+                b = rng.integers(0, 256, (n, n), dtype=np.uint8)
+            cases.append((a, b))
+        return cases
+
+    # ---------------- SAD (xSadN) and HM SATD ----------------
+    sad_tab = (C.c_void_p * 5).in_dll(lib, "xSadN")
+    sad_proto = C.CFUNCTYPE(C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
+    had = {4: "_Z12xCalcHADs4x4PKhjS0_j", 8: "_Z12xCalcHADs8x8PKhjS0_j", 16: "_Z14xCalcHADs16x16PKhjS0_j",
+           32: "_Z14xCalcHADs32x32PKhjS0_j", 64: "_Z14xCalcHADs64x64PKhjS0_j"}
+    out = {}
+    for idx, n in enumerate((4, 8, 16, 32, 64)):
+        cases = block_cases(n, 24)
+        src = aligned((64, 64), np.uint8)
+        ref = aligned((80, 96), np.uint8)
+        fsad = sad_proto(sad_tab[idx])
+        fhad = getattr(lib, had[n])
+        fhad.restype = C.c_uint32
+        fhad.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        A = np.stack([c[0] for c in cases])
+        B = np.stack([c[1] for c in cases])
+        sads, satds = [], []
+        for a, b in cases:
+            src[:n, :n] = a
+            ref[:n, :n] = b
+            sads.append(fsad(ptr(src), 64, ptr(ref), 96))
+            satds.append(fhad(ptr(src), 64, ptr(ref), 96))
+        out[f"a{n}"], out[f"b{n}"] = A, B
+        out[f"sad{n}"] = np.array(sads, np.uint32)
+        out[f"satd_hm{n}"] = np.array(satds, np.uint32)
+        if n == 32:  # the entry actually bound as xSatdN[3]
+            f32 = lib._Z19xCalcHADs32x32_testPhlS_l
+            f32.restype = C.c_int
+            f32.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+            t = []
+            for a, b in cases:
+                src[:n, :n] = a
+                ref[:n, :n] = b
+                t.append(f32(ptr(src), 64, ptr(ref), 96))
+            out["satd_tab3_32"] = np.array(t, np.uint32)
+    np.savez_compressed(os.path.join(OUT, "sad_satd.npz"), **out)
+
+    # ---------------- transform chain ----------------
+    fsub = lib._Z7xSubDctPsPhjS0_jS_S_ij
+    fsub.restype = None
+    fsub.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
+    fq = lib._Z6xQuantPsS_jjii10xSliceType
+    fq.restype = C.c_uint32
+    fq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]
+    fdq = lib._Z8xDeQuantPsS_jjii
+    fdq.restype = None
+    fdq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int]
+    fidct = lib._Z8xIDctAddPhjPsjS_S0_S0_ij
+    fidct.restype = None
+    fidct.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint]
+
+    S = 64
+    pix = aligned((S, S), np.uint8)
+    pred = aligned((S, S), np.uint8)
+    rec = aligned((S, 80), np.uint8)
+    t0 = aligned(((64 + 16) * 64,), np.int16)
+    t1 = aligned(((64 + 16) * 64,), np.int16)
+    coef = aligned((S, S), np.int16)
+    deq = aligned((S, S), np.int16)
+    out = {}
+    qps = (0, 22, 27, 32, 37, 51)
+    for n, mode, tag in ((4, MODE_INVALID, "dct4"), (4, 1, "dst4"), (8, MODE_INVALID, "dct8"),
+                         (16, MODE_INVALID, "dct16"), (32, MODE_INVALID, "dct32")):
+        cases = block_cases(n, 10)
+        A = np.stack([c[0] for c in cases])
+        B = np.stack([c[1] for c in cases])
+        tr = np.zeros((len(cases), n, n), np.int16)
+        lv = np.zeros((len(cases), len(qps), 2, n, n), np.int16)
+        sm = np.zeros((len(cases), len(qps), 2), np.uint32)
+        dq = np.zeros((len(cases), len(qps), 2, n, n), np.int16)
+        rc = np.zeros((len(cases), len(qps), 2, n, n), np.uint8)
+        for ci, (a, b) in enumerate(cases):
+            pix[:n, :n] = a
+            pred[:n, :n] = b
+            t0[:] = 0
+            fsub(ptr(t0), ptr(pix), S, ptr(pred), S, ptr(t0), ptr(t1), n, mode)
+            tcoef = t0[:S * S].reshape(S, S)[:n, :n].copy()
+            tr[ci] = tcoef
+            for qi, qp in enumerate(qps):
+                for si, st in enumerate((SLICE_P, SLICE_I)):
+                    t0[:] = 0
+                    t0[:S * S].reshape(S, S)[:n, :n] = tcoef
+                    coef[:] = 0
+                    sm[ci, qi, si] = fq(ptr(coef), ptr(t0), S, qp, n, n, st)
+                    lv[ci, qi, si] = coef[:n, :n]
+                    deq[:] = 0
+                    fdq(ptr(deq), ptr(coef), S, qp, n, n)
+                    dq[ci, qi, si] = deq[:n, :n]
+                    rec[:] = 0
+                    # same argument pattern as src/encode.cpp:3012 (tmp0 = psTmp[1], tmp1 = psTmp[0] = src)
+                    t0[:] = 0
+                    t0[:S * S].reshape(S, S)[:n, :n] = deq[:n, :n]
+                    fidct(ptr(rec), 80, ptr(t0), S, ptr(pred), ptr(t1), ptr(t0), n, mode)
+                    rc[ci, qi, si] = rec[:n, :n]
+        out[f"{tag}_pix"], out[f"{tag}_pred"] = A, B
+        out[f"{tag}_coef"], out[f"{tag}_level"], out[f"{tag}_sum"] = tr, lv, sm
+        out[f"{tag}_deq"], out[f"{tag}_rec"] = dq, rc
+    out["qps"] = np.array(qps, np.int32)
+    np.savez_compressed(os.path.join(OUT, "transform.npz"), **out)
+
+    # ---------------- quant / dequant / idct on raw coefficient inputs (incl. saturation) ----------------
+    out = {}
+    for n in (4, 8, 16, 32):
+        cs = []
+        for i in range(6):
+            amp = (40, 400, 4000, 20000, 32640, 32767)[i]
+            cs.append(rng.integers(-amp, amp + 1, (n, n)).astype(np.int16))
+        cs.append(np.full((n, n), 32767, np.int16))
+        cs.append(np.full((n, n), -32767, np.int16))
+        Cs = np.stack(cs)
+        lv = np.zeros((len(cs), len(qps), 2, n, n), np.int16)
+        sm = np.zeros((len(cs), len(qps), 2), np.uint32)
+        dq = np.zeros((len(cs), len(qps), n, n), np.int16)
+        for ci, c in enumerate(cs):
+            for qi, qp in enumerate(qps):
+                for si, st in enumerate((SLICE_P, SLICE_I)):
+                    t0[:] = 0
+                    t0[:S * S].reshape(S, S)[:n, :n] = c
+                    coef[:] = 0
+                    sm[ci, qi, si] = fq(ptr(coef), ptr(t0), S, qp, n, n, st)
+                    lv[ci, qi, si] = coef[:n, :n]
+                # dequant of the raw values treated as levels (exercises the int16 saturation)
+                coef[:] = 0
+                coef[:n, :n] = c
+                deq[:] = 0
+                fdq(ptr(deq), ptr(coef), S, qp, n, n)
+                dq[ci, qi] = deq[:n, :n]
+        out[f"q{n}_in"], out[f"q{n}_level"], out[f"q{n}_sum"], out[f"q{n}_deq"] = Cs, lv, sm, dq
+        # inverse transform of raw coefficient blocks (exercises the inter-stage clipping)
+        for mode, tag in (((MODE_INVALID, "idct"),) if n != 4 else ((MODE_INVALID, "idct"), (1, "idst"))):
+            pr = rng.integers(0, 256, (len(cs), n, n), dtype=np.uint8)
+            rc = np.zeros((len(cs), n, n), np.uint8)
+            for ci, c in enumerate(cs):
+                pred[:] = 0
+                pred[:n, :n] = pr[ci]
+                rec[:] = 0
+                t0[:] = 0
+                t0[:S * S].reshape(S, S)[:n, :n] = c
+                fidct(ptr(rec), 80, ptr(t0), S, ptr(pred), ptr(t1), ptr(t0), n, mode)
+                rc[ci] = rec[:n, :n]
+            out[f"{tag}{n}_pred"], out[f"{tag}{n}_rec"] = pr, rc
+    out["qps"] = np.array(qps, np.int32)
+    np.savez_compressed(os.path.join(OUT, "quant_raw.npz"), **out)
+
+    # ---------------- luma interpolation ----------------
+    fint = lib._Z17xPredInterLumaBlkPKhPhjjj3xMVPs
+    fint.restype = None
+    fint.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, XMV, C.c_void_p]
+    out = {}
+    RS = 112
+    refbuf = aligned((96, RS), np.uint8)
+    dst = aligned((64, 64), np.uint8)
+    tmp = aligned(((64 + 16) * 64,), np.int16)
+    for n in (8, 16, 32, 64):
+        frames = rng.integers(0, 256, (2, 96, RS), dtype=np.uint8)
+        frames[1] = np.where(rng.random((96, RS)) < 0.5, 0, 255).astype(np.uint8)  # extreme ringing
+        res = np.zeros((2, 16, n, n), np.uint8)
+        mvs = np.zeros((16, 2), np.int16)
+        for fi in range(2):
+            refbuf[:] = frames[fi]
+            for fr in range(16):
+                mv = XMV(int(4 * (fr % 3 - 1) + (fr & 3)), int(4 * ((fr // 5) - 1) + (fr >> 2)))
+                mvs[fr] = (mv.x, mv.y)
+                dst[:] = 0
+                origin = C.c_void_p(refbuf.ctypes.data + 16 * RS + 16)
+                fint(origin, ptr(dst), RS, n, n, mv, ptr(tmp))
+                res[fi, fr] = dst[:n, :n]
+        out[f"ref{n}"], out[f"mv{n}"], out[f"pred{n}"] = frames, mvs, res
+    out["origin"] = np.array([16, 16], np.int32)
+    np.savez_compressed(os.path.join(OUT, "interp.npz"), **out)
+    print("golden vectors written to", os.path.normpath(OUT))
+
+
+if __name__ == "__main__":
+    main()

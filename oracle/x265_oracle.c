@@ -1,0 +1,464 @@
+/*
+ * x265_oracle.c - CPU restatement of the x265-Milestone pixel primitives (TEST INFRASTRUCTURE).
+ * See x265_oracle.h for scope, citations and parity status. Nothing here is shipped or measured as
+ * the product; it is the checker for the HIP kernels and the "port" CPU baseline.
+ */
+#include "x265_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* floor(log2(x))+1, inc/utils.h:34-47; sizes are passed as xLog2(size-1): 4->2 ... 64->6 */
+static int xlog2(unsigned x)
+{
+    int n = 0;
+    while (x) { n++; x >>= 1; }
+    return n;
+}
+
+/* ------------------------------------------------------------------ SAD / SSD ---- */
+
+uint32_t orc_sad_wh(int w, int h, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            s += (uint32_t)abs((int)src[y * ss + x] - (int)ref[y * rs + x]);
+    return s;
+}
+
+uint32_t orc_sad(int n, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    return orc_sad_wh(n, n, src, ss, ref, rs);
+}
+
+uint32_t orc_ssd(int n, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int d = (int)src[y * ss + x] - (int)ref[y * rs + x];
+            s += (uint32_t)(d * d);
+        }
+    return s;
+}
+
+/* ------------------------------------------------------------------ SATD ---- */
+
+/* sum |H_n * D * H_n| for one n x n tile (n = 4 or 8), natural-order Hadamard. The sum of absolute
+ * values does not depend on the row/column order of H, so the reference's H4/H8 orderings
+ * (src/pixel.cpp:50-61) and a butterfly give the same number. */
+static uint32_t hadamard_abs_sum(int n, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    int m[8][8];
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            m[y][x] = (int)src[y * ss + x] - (int)ref[y * rs + x];
+    for (int y = 0; y < n; y++)
+        for (int len = 1; len < n; len <<= 1)
+            for (int i = 0; i < n; i += 2 * len)
+                for (int j = i; j < i + len; j++) {
+                    int a = m[y][j], b = m[y][j + len];
+                    m[y][j] = a + b;
+                    m[y][j + len] = a - b;
+                }
+    for (int x = 0; x < n; x++)
+        for (int len = 1; len < n; len <<= 1)
+            for (int i = 0; i < n; i += 2 * len)
+                for (int j = i; j < i + len; j++) {
+                    int a = m[j][x], b = m[j + len][x];
+                    m[j][x] = a + b;
+                    m[j + len][x] = a - b;
+                }
+    uint32_t s = 0;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++)
+            s += (uint32_t)abs(m[y][x]);
+    return s;
+}
+
+uint32_t orc_satd_hm(int n, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    if (n == 4)
+        return (hadamard_abs_sum(4, src, ss, ref, rs) + 1) >> 1;
+    uint32_t s = 0;
+    for (int y = 0; y < n; y += 8)
+        for (int x = 0; x < n; x += 8)
+            s += (hadamard_abs_sum(8, src + y * ss + x, ss, ref + y * rs + x, rs) + 2) >> 2;
+    return s;
+}
+
+uint32_t orc_satd_x264(int n, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    uint32_t s = 0;
+    for (int y = 0; y < n; y += 4)
+        for (int x = 0; x < n; x += 4)
+            s += hadamard_abs_sum(4, src + y * ss + x, ss, ref + y * rs + x, rs);
+    return s >> 1;
+}
+
+uint32_t orc_satd_table(int idx, const uint8_t *src, int ss, const uint8_t *ref, int rs)
+{
+    switch (idx) {
+    case 0: return orc_satd_x264(4, src, ss, ref, rs);
+    case 1: return orc_satd_x264(8, src, ss, ref, rs);
+    case 2: return orc_satd_x264(16, src, ss, ref, rs);
+    default: return orc_satd_hm(32, src, ss, ref, rs);
+    }
+}
+
+/* ------------------------------------------------------------------ transforms ---- */
+
+/* HEVC core transform basis. a[m] is the integer the standard assigns to 64*sqrt(2)*cos(m*pi/64);
+ * row k of the N-point matrix is T[k][n] = sign * a[.] of the angle k*(2n+1)*(32/N) (mod 128).
+ * Values equal xg_aiT4/8/16/32 in src/table.cpp. */
+static const int16_t k_cos64[33] = {
+    64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0
+};
+
+static int dct_coef(int n_pt, int k, int n)
+{
+    if (k == 0)
+        return 64;
+    int m = (k * (32 / n_pt) * (2 * n + 1)) & 127;
+    if (m <= 32) return k_cos64[m];
+    if (m <= 64) return -k_cos64[64 - m];
+    if (m <= 96) return -k_cos64[m - 64];
+    return k_cos64[128 - m];
+}
+
+static const int16_t k_dst4[4][4] = {
+    { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 }
+};
+
+static void build_matrix(int n, int use_dst, int m[32][32])
+{
+    for (int k = 0; k < n; k++)
+        for (int j = 0; j < n; j++)
+            m[k][j] = use_dst ? k_dst4[k][j] : dct_coef(n, k, j);
+}
+
+void orc_sub_dct(int16_t *dst, const uint8_t *src, int stride, const uint8_t *pred, int stride_pred,
+                 int width, unsigned mode)
+{
+    const int n = width;
+    const int lg = xlog2((unsigned)n - 1);
+    const int use_dst = (n == 4) && (mode != ORC_MODE_INVALID);
+    int m[32][32];
+    static int16_t resid[32 * 32], tmp[32 * 32]; /* not re-entrant: test infrastructure only */
+    build_matrix(n, use_dst, m);
+
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            resid[i * n + j] = (int16_t)((int)src[i * stride + j] - (int)pred[i * stride_pred + j]);
+
+    int shift = lg - 1, rnd = 1 << (shift - 1);
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < n; k++) {
+            int acc = 0;
+            for (int j = 0; j < n; j++)
+                acc += m[k][j] * resid[i * n + j];
+            tmp[k * n + i] = (int16_t)((acc + rnd) >> shift);
+        }
+    shift = lg + 6;
+    rnd = 1 << (shift - 1);
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < n; k++) {
+            int acc = 0;
+            for (int j = 0; j < n; j++)
+                acc += m[k][j] * tmp[i * n + j];
+            dst[k * stride + i] = (int16_t)((acc + rnd) >> shift);
+        }
+}
+
+static const int k_quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 }; /* src/table.cpp:150 */
+static const int k_inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };               /* src/table.cpp:155 */
+
+uint32_t orc_quant(int16_t *dst, const int16_t *src, int stride, unsigned qp, int width, int height,
+                   int slice_type)
+{
+    const int lg = xlog2((unsigned)width - 1);
+    const int q = k_quant_scales[qp % 6];
+    const int qbits = 14 + (int)(qp / 6) + (15 - 8 - lg);
+    const int rnd = (slice_type == ORC_SLICE_I ? 171 : 85) << (qbits - 9);
+    uint32_t sum = 0;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int c = src[y * stride + x];
+            int level = (abs(c) * q + rnd) >> qbits;
+            sum += (uint32_t)level;
+            if (c < 0) level = -level;
+            dst[y * stride + x] = (int16_t)clip3(-32768, 32767, level);
+        }
+    return sum;
+}
+
+void orc_dequant(int16_t *dst, const int16_t *src, int stride, unsigned qp, int width, int height)
+{
+    const int lg = xlog2((unsigned)width - 1);
+    const int shift = 20 - 14 - (15 - 8 - lg);
+    const int rnd = 1 << (shift - 1);
+    const int scale = k_inv_quant_scales[qp % 6] << (qp / 6);
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            int v = (src[y * stride + x] * scale + rnd) >> shift;
+            dst[y * stride + x] = (int16_t)clip3(-32768, 32767, v);
+        }
+}
+
+void orc_idct_add(uint8_t *dst, int stride_dst, const int16_t *src, int stride, const uint8_t *pred,
+                  int width, unsigned mode)
+{
+    const int n = width;
+    const int use_dst = (n == 4) && (mode != ORC_MODE_INVALID);
+    int m[32][32];
+    static int16_t t0[32 * 32], t1[32 * 32];
+    build_matrix(n, use_dst, m);
+
+    /* stage 1 over columns of the coefficient block: t0[i][j] = sum_k M[k][j] * src[k][i] */
+    int shift = 7, rnd = 1 << (shift - 1);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            int acc = 0;
+            for (int k = 0; k < n; k++)
+                acc += m[k][j] * src[k * stride + i];
+            t0[i * n + j] = (int16_t)clip3(-32768, 32767, (acc + rnd) >> shift);
+        }
+    shift = 12;
+    rnd = 1 << (shift - 1);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            int acc = 0;
+            for (int k = 0; k < n; k++)
+                acc += m[k][j] * t0[k * n + i];
+            t1[i * n + j] = (int16_t)clip3(-32768, 32767, (acc + rnd) >> shift);
+        }
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            dst[i * stride_dst + j] = (uint8_t)clip3(0, 255, t1[i * n + j] + pred[i * stride + j]);
+}
+
+uint32_t orc_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef,
+                      int size, int stride, int stride_rec, unsigned qp, unsigned mode, int slice_type)
+{
+    static int16_t work[64 * 64];
+    orc_sub_dct(work, pix, stride, pred, stride, size, mode);
+    uint32_t sum = orc_quant(coef, work, stride, qp, size, size, slice_type);
+    if (sum) {
+        orc_dequant(work, coef, stride, qp, size, size);
+        orc_idct_add(rec, stride_rec, work, stride, pred, size, mode);
+    } else {
+        for (int i = 0; i < size; i++)
+            memcpy(rec + i * stride_rec, pred + i * stride, (size_t)size);
+    }
+    return sum;
+}
+
+/* ------------------------------------------------------------------ SAD surface ---- */
+
+void orc_sad_surface(const uint8_t *cur, int cur_stride, const uint8_t *ref, int ref_stride,
+                     int width, int height, int range, int pitch,
+                     uint16_t *sad8, uint16_t *sad16, uint32_t *sad32, uint32_t *sad64,
+                     int ctu_begin, int ctu_end)
+{
+    const int wc = width / 64;
+    const int nmv = 2 * range + 1;
+    const size_t plane = (size_t)nmv * (size_t)pitch;
+    (void)height;
+    for (int ctu = ctu_begin; ctu < ctu_end; ctu++) {
+        const int cx = (ctu % wc) * 64, cy = (ctu / wc) * 64;
+        for (int dy = -range; dy <= range; dy++)
+            for (int dx = -range; dx <= range; dx++) {
+                uint32_t s8[64];
+                const size_t at = (size_t)(dy + range) * (size_t)pitch + (size_t)(dx + range);
+                for (int b = 0; b < 64; b++) {
+                    int bx = (b & 7) * 8, by = (b >> 3) * 8;
+                    s8[b] = orc_sad(8, cur + (size_t)(cy + by) * cur_stride + cx + bx, cur_stride,
+                                    ref + (ptrdiff_t)(cy + by + dy) * ref_stride + cx + bx + dx, ref_stride);
+                    sad8[((size_t)ctu * 64 + b) * plane + at] = (uint16_t)s8[b];
+                }
+                uint32_t s16[16], s32[4] = { 0, 0, 0, 0 }, s64 = 0;
+                for (int b = 0; b < 16; b++) {
+                    int bx = (b & 3) * 2, by = (b >> 2) * 2;
+                    s16[b] = s8[by * 8 + bx] + s8[by * 8 + bx + 1] + s8[(by + 1) * 8 + bx] + s8[(by + 1) * 8 + bx + 1];
+                    sad16[((size_t)ctu * 16 + b) * plane + at] = (uint16_t)s16[b];
+                    s32[(b >> 3) * 2 + ((b & 3) >> 1)] += s16[b];
+                }
+                for (int b = 0; b < 4; b++) {
+                    sad32[((size_t)ctu * 4 + b) * plane + at] = s32[b];
+                    s64 += s32[b];
+                }
+                sad64[(size_t)ctu * plane + at] = s64;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ ME driver ---- */
+
+unsigned orc_mv_component_bits(int val)
+{
+    unsigned length = 1;
+    unsigned t = (val <= 0) ? ((unsigned)(-val) << 1) + 1 : ((unsigned)val << 1);
+    while (t != 1) {
+        t >>= 1;
+        length += 2;
+    }
+    return length;
+}
+
+static const int k_luma_filter[4][8] = { /* src/table.cpp:525-530 */
+    { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+    { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 }
+};
+
+void orc_pred_inter_luma(const uint8_t *ref, uint8_t *dst, int rs, int w, int h, int mvx, int mvy)
+{
+    const int dx = mvx >> 2, dy = mvy >> 2, xf = mvx & 3, yf = mvy & 3;
+    ref += (ptrdiff_t)dy * rs + dx;
+    if (!xf && !yf) {
+        for (int i = 0; i < h; i++)
+            memcpy(dst + i * 64, ref + (ptrdiff_t)i * rs, (size_t)w);
+    } else if (!yf) { /* src/pixel.cpp:7705-7734 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 8; t++)
+                    s += ref[(ptrdiff_t)i * rs + j + t - 3] * k_luma_filter[xf][t];
+                dst[i * 64 + j] = (uint8_t)clip3(0, 255, (s + 32) >> 6);
+            }
+    } else if (!xf) { /* src/pixel.cpp:8137-8166 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 8; t++)
+                    s += ref[(ptrdiff_t)(i + t - 3) * rs + j] * k_luma_filter[yf][t];
+                dst[i * 64 + j] = (uint8_t)clip3(0, 255, (s + 32) >> 6);
+            }
+    } else { /* src/pixel.cpp:8690-8741 */
+        static int16_t tmp[(64 + 7) * 64];
+        for (int i = 0; i < h + 7; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 8; t++)
+                    s += ref[(ptrdiff_t)(i - 3) * rs + j + t - 3] * k_luma_filter[xf][t];
+                tmp[i * 64 + j] = (int16_t)(s - 8192);
+            }
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 8; t++)
+                    s += tmp[(i + t) * 64 + j] * k_luma_filter[yf][t];
+                dst[i * 64 + j] = (uint8_t)clip3(0, 255, (s + 8192 * 64 + 2048) >> 12);
+            }
+    }
+}
+
+void orc_motion_search(const uint8_t *cur, const uint8_t *ref, int rs, int size,
+                       const orc_mv mvp[2], int zero_mv_tested, orc_mv mv_min_ipel, orc_mv mv_max_ipel,
+                       double lambda, int me_range, orc_me_result *out)
+{
+    static const int dia4[4][2] = { { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 } };
+    static const int dia9[9][2] = { { 0, 0 }, { 0, -1 }, { 0, 1 }, { -1, 0 }, { 1, 0 },
+                                    { -1, -1 }, { -1, 1 }, { 1, -1 }, { 1, 1 } };
+    const uint32_t ulambda = (uint32_t)sqrt(lambda);
+    uint8_t tmp[64 * 64];
+    int mvp_idx = -1, bmx = 0, bmy = 0, best_k = -1;
+    uint32_t bsad = INT_MAX, bcost = INT_MAX;
+    int passes = 1;
+    out->n_int_sads = 0;
+    out->n_sub_sads = 0;
+
+    if ((abs(mvp[0].x - mvp[1].x) >> 2) + (abs(mvp[0].y - mvp[1].y) >> 2) > 4)
+        passes = 2;
+    for (int i = 0; i < passes; i++) {
+        orc_pred_inter_luma(ref, tmp, rs, size, size, mvp[i].x, mvp[i].y);
+        uint32_t s = orc_sad(size, cur, 64, tmp, 64);
+        out->n_sub_sads++;
+        if (s < bsad) {
+            bsad = s;
+            mvp_idx = i;
+        }
+    }
+    const int px = mvp[mvp_idx].x, py = mvp[mvp_idx].y;
+#define MVCOST(X, Y) (ulambda * (orc_mv_component_bits(px - (X)) + orc_mv_component_bits(py - (Y))))
+    if (!zero_mv_tested) {
+        uint32_t c = orc_sad(size, cur, 64, ref, rs) + MVCOST(0, 0);
+        out->n_int_sads++;
+        if (c < bcost) {
+            bcost = c;
+            bmx = bmy = 0;
+        }
+    }
+    int omx = px >> 2, omy = py >> 2;
+    {
+        uint32_t c = orc_sad(size, cur, 64, ref + (ptrdiff_t)omy * rs + omx, rs) + MVCOST(omx * 4, omy * 4);
+        out->n_int_sads++;
+        if (c < bcost) {
+            bcost = c;
+            bmx = omx * 4;
+            bmy = omy * 4;
+        }
+    }
+    for (int i = 0; i < me_range; i++) {
+        int changed = 0;
+        for (int k = 0; k < 4; k++) {
+            int tx = clip3(mv_min_ipel.x, mv_max_ipel.x, omx + dia4[k][0]);
+            int ty = clip3(mv_min_ipel.y, mv_max_ipel.y, omy + dia4[k][1]);
+            uint32_t c = orc_sad(size, cur, 64, ref + (ptrdiff_t)ty * rs + tx, rs) + MVCOST(tx * 4, ty * 4);
+            out->n_int_sads++;
+            if (c < bcost) {
+                changed = 1;
+                bcost = c;
+                best_k = k;
+                bmx = tx * 4;
+                bmy = ty * 4;
+            }
+        }
+        if (!changed)
+            break;
+        omx += dia4[best_k][0];
+        omy += dia4[best_k][1];
+        if (bcost < 800)
+            break;
+    }
+    {   /* src/encode.cpp:2950-2953: x is clipped against the y maximum (reference quirk, kept) */
+        int mnx = 4 * (mv_min_ipel.x - 4), mny = 4 * (mv_min_ipel.y - 4);
+        int mxy = 4 * (mv_max_ipel.y - 4);
+        bmx = clip3(mnx, mxy, bmx);
+        bmy = clip3(mny, mxy, bmy);
+    }
+    bcost = INT_MAX;
+    int step = 2;
+    for (int i = 0; i < 2; i++) {
+        int changed = 0;
+        for (int k = 0; k < 9; k++) {
+            int tx = bmx + dia9[k][0] * step, ty = bmy + dia9[k][1] * step;
+            tx = (int16_t)tx; /* tmv is an xMV of Int16 */
+            ty = (int16_t)ty;
+            orc_pred_inter_luma(ref, tmp, rs, size, size, tx, ty);
+            uint32_t c = orc_sad(size, cur, 64, tmp, 64) + MVCOST(tx, ty);
+            out->n_sub_sads++;
+            if (c < bcost) {
+                changed = 1;
+                bcost = c;
+                best_k = k;
+            }
+        }
+        if (changed) {
+            bmx += dia9[best_k][0] * step;
+            bmy += dia9[best_k][1] * step;
+        }
+        step >>= 1;
+    }
+#undef MVCOST
+    out->mv.x = (int16_t)bmx;
+    out->mv.y = (int16_t)bmy;
+    out->best_cost = bcost;
+    out->best_sad = bsad;
+    out->mvp_idx = mvp_idx;
+}

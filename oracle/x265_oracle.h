@@ -1,0 +1,121 @@
+/*
+ * x265_oracle.h - CPU restatement of the x265-Milestone pixel primitives (TEST INFRASTRUCTURE).
+ *
+ * This is the checker the HIP kernels are held against. It is NOT part of the product:
+ * only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load it.
+ * Every function cites the reference file:line it restates (paths relative to the
+ * reference tree). Plain C, scalar, no intrinsics: readable first, fast second.
+ *
+ * Parity status: pinned against the reference's own C++/SSE4 code compiled from
+ * src/pixel.cpp + src/table.cpp (oracle/Makefile -> oracle/_ref/libx265ref_pixel.so) through the
+ * golden vectors in tests/golden/ (generator: oracle/gen_golden.py). The reference ships no
+ * test vectors of its own. Two groups are NOT pinned by reference-compiled code because the
+ * reference implements them only in NASM, which cannot be assembled in this image:
+ *   - orc_satd_x264 (x265_pixel_satd_{4x4,8x8,16x16}_sse4)   -> "parity unpinned" except for
+ *     the 4x4 case, which must equal the reference's own xCalcHADs4x4 (checked).
+ *   - orc_ssd       (x265_pixel_ssd_*)                        -> exact sum of squares.
+ */
+#ifndef X265_ORACLE_H
+#define X265_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_SLICE_P 1      /* inc/x265.h:79 */
+#define ORC_SLICE_I 2      /* inc/x265.h:80 */
+#define ORC_MODE_INVALID 255 /* inc/x265.h:163 */
+
+/* A1: src/pixel.cpp:546-696 (xSad4x4..xSad64x64).  n in {4,8,16,32,64}. */
+uint32_t orc_sad(int n, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+/* rectangular entries of xSad_AMP, src/pixel.cpp:719-791 */
+uint32_t orc_sad_wh(int w, int h, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+
+/* A11: src/pixel.cpp:793-816 binds NASM x265_pixel_ssd_*; exact sum of squared differences. */
+uint32_t orc_ssd(int n, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+
+/* A3: HM-style SATD. src/pixel.cpp:63-158 (4x4, (sum+1)>>1), :160-330 (8x8, (sum+2)>>2),
+ * :332-458 (16/32/64 = sum of independently rounded 8x8 tiles). n in {4,8,16,32,64}. */
+uint32_t orc_satd_hm(int n, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+
+/* A4: x264-style SATD bound at src/pixel.cpp:531-533; defined by src/x86/pixel-a.asm:1645 (4x4),
+ * :3455 (8x8), :1787/:3282 (16x16): sum over 4x4 tiles of sum|H4*D*H4|, halved. n in {4,8,16}.
+ * 32-bit accumulation (the asm's 16-bit lane overflow for adversarial 16x16 input is not
+ * reproduced). */
+uint32_t orc_satd_x264(int n, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+
+/* The table the encoder actually calls, src/pixel.cpp:529-542 with SATD_USE_TRUE_ASM=1:
+ * idx 0..2 -> x264 4x4/8x8/16x16, idx 3 -> xCalcHADs32x32_test (HM 8x8 tiles). */
+uint32_t orc_satd_table(int idx, const uint8_t *src, int stride_src, const uint8_t *ref, int stride_ref);
+
+/* A5: xSubDct, src/pixel.cpp:3446-3458 (C spec :1415 DCT4, :1567 DST4, :1826 DCT8, :2300 DCT16,
+ * :3149 DCT32). dst rows use the SAME stride as src (pDst[k*nStride+i]). DST when width==4 and
+ * mode != MODE_INVALID. */
+void orc_sub_dct(int16_t *dst, const uint8_t *src, int stride, const uint8_t *pred, int stride_pred,
+                 int width, unsigned mode);
+
+/* A6: xQuant, src/pixel.cpp:1060-1089 (C spec). Returns sum of |level| (before sign, before clip). */
+uint32_t orc_quant(int16_t *dst, const int16_t *src, int stride, unsigned qp, int width, int height,
+                   int slice_type);
+
+/* A7: xDeQuant, src/pixel.cpp:1249-1267 (C spec). */
+void orc_dequant(int16_t *dst, const int16_t *src, int stride, unsigned qp, int width, int height);
+
+/* A8: xIDctAdd, src/pixel.cpp:5938-5950 (C spec :3584 IDST4, :3725 IDCT4, :4071 IDCT8, :4629 IDCT16,
+ * :5573 IDCT32). pred is read with `stride` (the coefficient stride), dst with stride_dst. */
+void orc_idct_add(uint8_t *dst, int stride_dst, const int16_t *src, int stride, const uint8_t *pred,
+                  int width, unsigned mode);
+
+/* A10: xSubDctQuantRec, src/encode.cpp:3005-3021. One TU: sub+DCT -> quant -> (dequant -> IDCT+add |
+ * copy pred). pix/pred/coef share `stride`, rec uses stride_rec. Returns sum|level|. */
+uint32_t orc_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef,
+                      int size, int stride, int stride_rec, unsigned qp, unsigned mode, int slice_type);
+
+/*
+ * Frame-wide SAD surface: for every 64x64 CTU, every integer MV (dx,dy) in [-range,range]^2 and
+ * every square PU of the quad-tree (64 8x8, 16 16x16, 4 32x32, 1 64x64) the value the
+ * reference's xSad_AMP[idx](cur,64,ref+dy*stride+dx,stride) would return (src/encode.cpp:2885-2931).
+ * A superset of the candidates xMotionSearch visits; each value is exact.
+ *
+ * cur:  width x height luma (multiples of 64), stride cur_stride.
+ * ref:  pointer to pixel (0,0) of a frame padded by at least `range` on every side, stride ref_stride.
+ * Output planes, all indexed [ctu][blk][dy+range][dx+range] with row pitch `pitch` elements
+ * (pitch >= 2*range+1) and (2*range+1) rows per block; blk is raster order inside the CTU
+ * (8x8: by*8+bx, 16x16: by*4+bx, 32x32: by*2+bx); ctu is raster order in the frame.
+ * Only CTUs [ctu_begin, ctu_end) are written (at their absolute index).
+ */
+void orc_sad_surface(const uint8_t *cur, int cur_stride, const uint8_t *ref, int ref_stride,
+                     int width, int height, int range, int pitch,
+                     uint16_t *sad8, uint16_t *sad16, uint32_t *sad32, uint32_t *sad64,
+                     int ctu_begin, int ctu_end);
+
+/* xGetComponentBits, src/encode.cpp:194-205. */
+unsigned orc_mv_component_bits(int val);
+
+/* N1: xPredInterLumaBlk, src/pixel.cpp:8745-8795: HEVC 8-tap luma interpolation of a w x h block
+ * at quarter-pel MV (mvx,mvy) from ref (pointer at the block's integer origin). dst stride 64. */
+void orc_pred_inter_luma(const uint8_t *ref, uint8_t *dst, int ref_stride, int w, int h, int mvx, int mvy);
+
+/* A2: xMotionSearch, src/encode.cpp:2815-3003 (MV_CLIP=1, MVD_COST_BY_TABLE=0, SATD_FOR_FRAC_ME=0).
+ * cur: stride 64. ref: pointer at the PU origin in the padded reference. mvp[2]: quarter-pel
+ * predictors {x,y}. Outputs mirror the reference's out-parameters. Returns packed mv: x | y<<16. */
+typedef struct { int16_t x, y; } orc_mv;
+typedef struct {
+    orc_mv mv;           /* returned quarter-pel MV */
+    uint32_t best_cost;  /* *uiBestRDCostY */
+    uint32_t best_sad;   /* *pSad_best (SAD of the chosen MVP) */
+    int mvp_idx;         /* *pMVPIdx */
+    int n_int_sads;      /* integer-pel SAD evaluations performed */
+    int n_sub_sads;      /* sub-pel SAD evaluations performed */
+} orc_me_result;
+void orc_motion_search(const uint8_t *cur, const uint8_t *ref, int ref_stride, int size,
+                       const orc_mv mvp[2], int zero_mv_tested, orc_mv mv_min_ipel, orc_mv mv_max_ipel,
+                       double lambda, int me_range, orc_me_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+"""CPU: the oracle (oracle/x265_oracle.c) against golden vectors produced by the reference's own
+compiled pixel.cpp (oracle/gen_golden.py). Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return O.load()
+
+
+def _blk(a, stride=None):
+    n = a.shape[0]
+    stride = stride or n
+    buf = np.zeros((n, stride), a.dtype)
+    buf[:, :n] = a
+    return buf
+
+
+def test_sad_and_hm_satd(lib, golden_dir):
+    g = np.load(os.path.join(golden_dir, "sad_satd.npz"))
+    for n in (4, 8, 16, 32, 64):
+        A, B = g[f"a{n}"], g[f"b{n}"]
+        for i in range(len(A)):
+            a, b = _blk(A[i], 64), _blk(B[i], 96)
+            assert lib.orc_sad(n, O.p(a), 64, O.p(b), 96) == g[f"sad{n}"][i]
+            assert lib.orc_satd_hm(n, O.p(a), 64, O.p(b), 96) == g[f"satd_hm{n}"][i]
+            if n == 32:
+                assert lib.orc_satd_table(3, O.p(a), 64, O.p(b), 96) == g["satd_tab3_32"][i]
+            if n == 4:
+                # the NASM 4x4 SATD has no compiled reference here; its definition (sum|H4 D H4| / 2)
+                # must coincide with the reference's own xCalcHADs4x4 ((sum+1)>>1, sum always even)
+                assert lib.orc_satd_x264(4, O.p(a), 64, O.p(b), 96) == g["satd_hm4"][i]
+            # exact SSD needs no reference run: cross-check against numpy
+            d = A[i].astype(np.int64) - B[i].astype(np.int64)
+            assert lib.orc_ssd(n, O.p(a), 64, O.p(b), 96) == int((d * d).sum())
+
+
+@pytest.mark.parametrize("tag,n,mode", [("dct4", 4, O.MODE_INVALID), ("dst4", 4, 1), ("dct8", 8, O.MODE_INVALID),
+                                        ("dct16", 16, O.MODE_INVALID), ("dct32", 32, O.MODE_INVALID)])
+def test_transform_chain(lib, golden_dir, tag, n, mode):
+    g = np.load(os.path.join(golden_dir, "transform.npz"))
+    qps = g["qps"]
+    S = 64
+    for ci in range(len(g[f"{tag}_pix"])):
+        pix, pred = _blk(g[f"{tag}_pix"][ci], S), _blk(g[f"{tag}_pred"][ci], S)
+        coef = np.zeros((n, S), np.int16)
+        lib.orc_sub_dct(O.p(coef), O.p(pix), S, O.p(pred), S, n, mode)
+        np.testing.assert_array_equal(coef[:, :n], g[f"{tag}_coef"][ci])
+        for qi, qp in enumerate(qps):
+            for si, st in enumerate((O.SLICE_P, O.SLICE_I)):
+                lev = np.zeros((n, S), np.int16)
+                s = lib.orc_quant(O.p(lev), O.p(coef), S, int(qp), n, n, st)
+                assert s == g[f"{tag}_sum"][ci, qi, si]
+                np.testing.assert_array_equal(lev[:, :n], g[f"{tag}_level"][ci, qi, si])
+                deq = np.zeros((n, S), np.int16)
+                lib.orc_dequant(O.p(deq), O.p(lev), S, int(qp), n, n)
+                np.testing.assert_array_equal(deq[:, :n], g[f"{tag}_deq"][ci, qi, si])
+                rec = np.zeros((n, 80), np.uint8)
+                lib.orc_idct_add(O.p(rec), 80, O.p(deq), S, O.p(pred), n, mode)
+                np.testing.assert_array_equal(rec[:, :n], g[f"{tag}_rec"][ci, qi, si])
+                # fused driver (xSubDctQuantRec): same levels; recon = idct result or pred copy
+                rec2 = np.zeros((n, 80), np.uint8)
+                lev2 = np.zeros((n, S), np.int16)
+                s2 = lib.orc_tu_chain(O.p(pix), O.p(pred), O.p(rec2), O.p(lev2), n, S, 80, int(qp), mode, st)
+                assert s2 == s
+                np.testing.assert_array_equal(lev2[:, :n], lev[:, :n])
+                want = g[f"{tag}_rec"][ci, qi, si] if s else g[f"{tag}_pred"][ci]
+                np.testing.assert_array_equal(rec2[:, :n], want)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_quant_dequant_idct_raw(lib, golden_dir, n):
+    g = np.load(os.path.join(golden_dir, "quant_raw.npz"))
+    qps = g["qps"]
+    S = 64
+    Cs = g[f"q{n}_in"]
+    for ci in range(len(Cs)):
+        c = _blk(Cs[ci], S)
+        for qi, qp in enumerate(qps):
+            for si, st in enumerate((O.SLICE_P, O.SLICE_I)):
+                lev = np.zeros((n, S), np.int16)
+                s = lib.orc_quant(O.p(lev), O.p(c), S, int(qp), n, n, st)
+                assert s == g[f"q{n}_sum"][ci, qi, si]
+                np.testing.assert_array_equal(lev[:, :n], g[f"q{n}_level"][ci, qi, si])
+            deq = np.zeros((n, S), np.int16)
+            lib.orc_dequant(O.p(deq), O.p(c), S, int(qp), n, n)
+            np.testing.assert_array_equal(deq[:, :n], g[f"q{n}_deq"][ci, qi])
+        for mode, tag in (((O.MODE_INVALID, "idct"),) if n != 4 else ((O.MODE_INVALID, "idct"), (1, "idst"))):
+            pred = _blk(g[f"{tag}{n}_pred"][ci], S)
+            rec = np.zeros((n, 80), np.uint8)
+            lib.orc_idct_add(O.p(rec), 80, O.p(c), S, O.p(pred), n, mode)
+            np.testing.assert_array_equal(rec[:, :n], g[f"{tag}{n}_rec"][ci])
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64])
+def test_luma_interpolation(lib, golden_dir, n):
+    g = np.load(os.path.join(golden_dir, "interp.npz"))
+    oy, ox = g["origin"]
+    frames, mvs, want = g[f"ref{n}"], g[f"mv{n}"], g[f"pred{n}"]
+    for fi in range(frames.shape[0]):
+        ref = np.ascontiguousarray(frames[fi])
+        for k in range(len(mvs)):
+            dst = np.zeros((64, 64), np.uint8)
+            lib.orc_pred_inter_luma(O.at(ref, oy, ox), O.p(dst), ref.strides[0], n, n, int(mvs[k, 0]), int(mvs[k, 1]))
+            np.testing.assert_array_equal(dst[:n, :n], want[fi, k])
+
+
+def test_satd_x264_properties(lib):
+    """No compiled reference exists for the NASM SATD (parity unpinned): check its definition only."""
+    rng = np.random.default_rng(5)
+    for n in (8, 16):
+        a = rng.integers(0, 256, (n, n), dtype=np.uint8)
+        b = rng.integers(0, 256, (n, n), dtype=np.uint8)
+        tot = 0
+        for y in range(0, n, 4):
+            for x in range(0, n, 4):
+                tot += lib.orc_satd_hm(4, O.at(a, y, x), n, O.at(b, y, x), n)
+        # sum of the 4x4 SATDs ((s+1)>>1 each, s even) equals the tile definition
+        assert lib.orc_satd_x264(n, O.p(a), n, O.p(b), n) == tot
+        assert lib.orc_satd_x264(n, O.p(a), n, O.p(a), n) == 0
+
+
+def test_mv_bits(lib):
+    assert [lib.orc_mv_component_bits(v) for v in (0, 1, -1, 2, -2, 3, 4, -4, 255)] == [1, 3, 3, 5, 5, 5, 7, 7, 17]
