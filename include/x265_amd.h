@@ -1,0 +1,141 @@
+/*
+ * x265_amd.h - C ABI of libx265_amd.so: the MI355X (gfx950) implementation of the x265-Milestone
+ * pixel-primitive hot path (integer-ME SAD, SATD, SSD, forward/inverse transform + quantisation).
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; every buffer is caller-owned.
+ *   - *_dev entry points take DEVICE pointers and a hipStream_t passed as void* (NULL = default
+ *     stream); they enqueue work and return without synchronising.
+ *   - entry points without the _dev suffix take HOST pointers, run on the GPU and return when the
+ *     result is in host memory. They are drop-ins for the reference's per-call primitives.
+ *   - return value: >= 0 success (or the primitive's value), XMI_ERR_* (< 0) on failure;
+ *     xmi_last_error() gives the message for the calling thread. There is NO CPU fallback: without a
+ *     usable GPU every compute entry point fails with XMI_ERR_NO_DEVICE.
+ *
+ * Citations name the reference interface each entry point replaces (paths relative to the
+ * reference tree).
+ */
+#ifndef X265_AMD_H
+#define X265_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XMI_OK             0
+#define XMI_ERR_ARG       -1   /* bad argument (size, alignment, range, null pointer) */
+#define XMI_ERR_HIP       -2   /* a HIP runtime call failed */
+#define XMI_ERR_NO_DEVICE -3   /* no usable gfx950 device */
+
+#define XMI_SLICE_P 1          /* xSliceType, inc/x265.h:79-80 */
+#define XMI_SLICE_I 2
+#define XMI_MODE_INVALID 255   /* inc/x265.h:163: "not an intra luma mode" -> DCT, not DST, for 4x4 */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int         xmi_init(int device);      /* bind the calling process to `device`; idempotent */
+void        xmi_shutdown(void);        /* free library-owned device memory */
+const char *xmi_last_error(void);
+int         xmi_device_count(void);
+const char *xmi_version(void);
+
+/* ---- frame-wide integer-ME SAD surface ------------------------------------------------------
+ * Replaces the xSad_AMP[nSadIdx](cur, 64, ref + tY*stride + tX, stride) evaluations of
+ * xMotionSearch (src/encode.cpp:2885, 2907, 2931; table src/pixel.cpp:833-844; xSad8x8..64x64
+ * src/pixel.cpp:578-696): for every 64x64 CTU, every integer MV (dx,dy) in [-range,range]^2 (the
+ * box xCuMvClip allows, src/encode.cpp:3794-3812) and every square PU of the quad-tree
+ * (64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 = 85 per MV) the exact SAD.
+ *
+ * Output planes (element index, row-major):
+ *   sadN[ctu][blk][dy + range][dx + range], row pitch `pitch` elements, 2*range+1 rows per block,
+ *   blk in raster order inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx), ctu in
+ *   raster order. sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32.
+ * Requirements: width,height multiples of 64; range in {16,32,64,128}; pitch a multiple of 4 and
+ * >= 2*range+1; the reference frame must be readable range+4 pixels beyond every edge (the
+ * reference encoder pads by 80, inc/config.h:52); d_cur, d_ref_origin and both strides 4-byte
+ * aligned; output planes 16-byte aligned. */
+typedef struct xmi_sad_geom {
+    int width, height;   /* coded luma size */
+    int cur_stride;      /* bytes between rows of the current frame */
+    int ref_stride;      /* bytes between rows of the padded reference frame */
+    int range;           /* R */
+    int pitch;           /* elements between surface rows */
+} xmi_sad_geom;
+
+/* elements in one surface plane set: level 0 = 8x8, 1 = 16x16, 2 = 32x32, 3 = 64x64 */
+size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level);
+
+int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8_t *d_ref_origin,
+                        uint16_t *d_sad8, uint16_t *d_sad16, uint32_t *d_sad32, uint32_t *d_sad64,
+                        int ctu_begin, int ctu_end, void *stream);
+
+/* host-pointer convenience form: uploads both frames, runs, downloads the four planes.
+ * ref_origin points at pixel (0,0) of the padded reference; `pad` is its border in pixels. */
+int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *ref_origin, int pad,
+                    uint16_t *sad8, uint16_t *sad16, uint32_t *sad32, uint32_t *sad64);
+
+/* ---- batched block metrics -------------------------------------------------------------------
+ * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
+ *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717
+ *   XMI_METRIC_SSD       xSsdN[log2(n)-2]                        src/pixel.cpp:793-816
+ *   XMI_METRIC_SATD_HM   xCalcHADs4x4/8x8/16x16/32x32/64x64      src/pixel.cpp:63-458
+ *   XMI_METRIC_SATD_X264 x265_pixel_satd_{4x4,8x8,16x16}_sse4    src/x86/pixel-a.asm:1645,3455,1787
+ *   XMI_METRIC_SATD_TAB  the table the encoder calls, xSatdN[]   src/pixel.cpp:529-542
+ *                        (n=4,8,16 -> x264 form, n=32 -> xCalcHADs32x32_test) */
+#define XMI_METRIC_SAD       0
+#define XMI_METRIC_SSD       1
+#define XMI_METRIC_SATD_HM   2
+#define XMI_METRIC_SATD_X264 3
+#define XMI_METRIC_SATD_TAB  4
+
+int xmi_block_metric_batch_dev(int metric, int n, int count, const uint8_t *d_a, const uint8_t *d_b,
+                               uint32_t *d_out, void *stream);
+
+/* ---- batched transform-unit chain ------------------------------------------------------------
+ * Replaces xSubDctQuantRec (src/encode.cpp:3005-3021) = xSubDct -> xQuant -> (xDeQuant -> xIDctAdd |
+ * copy pred) for `count` independent n x n TUs, n in {4,8,16,32}. Blocks are packed back to back.
+ * Per TU i: qp[i] in 0..51, flags[i] bit0 = slice is I (rounding 171/512, else 85/512),
+ * bit1 = use the 4x4 DST (reference: width==4 && mode != MODE_INVALID).
+ * Outputs: level (int16 n*n), rec (uint8 n*n), sum[i] = sum |level| (the reference's return value). */
+int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t *d_pred,
+                           const uint8_t *d_qp, const uint8_t *d_flags,
+                           int16_t *d_level, uint8_t *d_rec, uint32_t *d_sum, void *stream);
+
+/* the four stages on their own, same packing (for callers that interleave host logic) */
+int xmi_sub_dct_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t *d_pred,
+                          const uint8_t *d_flags, int16_t *d_coef, void *stream);
+int xmi_quant_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_qp,
+                        const uint8_t *d_flags, int16_t *d_level, uint32_t *d_sum, void *stream);
+int xmi_dequant_batch_dev(int n, int count, const int16_t *d_level, const uint8_t *d_qp,
+                          int16_t *d_coef, void *stream);
+int xmi_idct_add_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_pred,
+                           const uint8_t *d_flags, uint8_t *d_rec, void *stream);
+
+/* ---- per-call drop-ins (HOST pointers, strided, synchronous) ---------------------------------
+ * Same argument meaning as the reference primitives; each call stages its operands to the GPU,
+ * runs the batch kernel with count = 1 and copies the result back. Correct and slow: they exist so
+ * an unmodified caller can be re-pointed at the GPU library; throughput comes from the batch forms. */
+int64_t xmi_sad(int n, const uint8_t *src, uint32_t stride_src, const uint8_t *ref, uint32_t stride_ref);  /* xSadN / xSad_AMP */
+int64_t xmi_ssd(int n, const uint8_t *src, intptr_t stride_src, const uint8_t *ref, intptr_t stride_ref);  /* xSsdN */
+int64_t xmi_satd(int n, const uint8_t *src, intptr_t stride_src, const uint8_t *ref, intptr_t stride_ref); /* xSatdN */
+int64_t xmi_satd_hm(int n, const uint8_t *src, uint32_t stride_src, const uint8_t *ref, uint32_t stride_ref); /* xCalcHADs* / xSatd_AMP */
+/* xSubDct, src/pixel.cpp:3446 (dst uses `stride`, like the reference) */
+int xmi_sub_dct(int16_t *dst, const uint8_t *src, uint32_t stride, const uint8_t *pred, uint32_t stride_pred,
+                int width, uint32_t mode);
+/* xQuant, src/pixel.cpp:1054; returns sum|level| */
+int64_t xmi_quant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, int width, int height, int slice_type);
+/* xDeQuant, src/pixel.cpp:1244 */
+int xmi_dequant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, int width, int height);
+/* xIDctAdd, src/pixel.cpp:5938 (pred is read with `stride`, like the reference) */
+int xmi_idct_add(uint8_t *dst, uint32_t stride_dst, const int16_t *src, uint32_t stride, const uint8_t *pred,
+                 int width, uint32_t mode);
+/* xSubDctQuantRec, src/encode.cpp:3005 */
+int64_t xmi_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef, int size,
+                     int stride, int stride_rec, uint32_t qp, uint32_t mode, int slice_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_AMD_H */

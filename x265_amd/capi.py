@@ -1,0 +1,96 @@
+"""ctypes binding of libx265_amd.so (include/x265_amd.h). No computation happens in Python."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libx265_amd.so")
+
+XMI_OK = 0
+SLICE_P, SLICE_I, MODE_INVALID = 1, 2, 255
+METRIC_SAD, METRIC_SSD, METRIC_SATD_HM, METRIC_SATD_X264, METRIC_SATD_TAB = range(5)
+
+
+class XmiError(RuntimeError):
+    pass
+
+
+class SadGeom(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("cur_stride", C.c_int), ("ref_stride", C.c_int),
+                ("range", C.c_int), ("pitch", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """Load the native library. Raises XmiError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XmiError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C x265_amd/csrc` (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i = C.c_void_p, C.c_int
+    L.xmi_init.restype = i
+    L.xmi_init.argtypes = [i]
+    L.xmi_shutdown.restype = None
+    L.xmi_last_error.restype = C.c_char_p
+    L.xmi_device_count.restype = i
+    L.xmi_version.restype = C.c_char_p
+    L.xmi_sad_surface_elems.restype = C.c_size_t
+    L.xmi_sad_surface_elems.argtypes = [C.POINTER(SadGeom), i]
+    L.xmi_sad_surface_dev.restype = i
+    L.xmi_sad_surface_dev.argtypes = [C.POINTER(SadGeom), vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.xmi_sad_surface.restype = i
+    L.xmi_sad_surface.argtypes = [C.POINTER(SadGeom), vp, vp, i, vp, vp, vp, vp]
+    if hasattr(L, "xmi_block_metric_batch_dev"):
+        L.xmi_block_metric_batch_dev.restype = i
+        L.xmi_block_metric_batch_dev.argtypes = [i, i, i, vp, vp, vp, vp]
+        L.xmi_tu_chain_batch_dev.restype = i
+        L.xmi_tu_chain_batch_dev.argtypes = [i, i, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.xmi_sub_dct_batch_dev.restype = i
+        L.xmi_sub_dct_batch_dev.argtypes = [i, i, vp, vp, vp, vp, vp]
+        L.xmi_quant_batch_dev.restype = i
+        L.xmi_quant_batch_dev.argtypes = [i, i, vp, vp, vp, vp, vp, vp]
+        L.xmi_dequant_batch_dev.restype = i
+        L.xmi_dequant_batch_dev.argtypes = [i, i, vp, vp, vp, vp]
+        L.xmi_idct_add_batch_dev.restype = i
+        L.xmi_idct_add_batch_dev.argtypes = [i, i, vp, vp, vp, vp, vp]
+        u32, ip = C.c_uint32, C.c_ssize_t
+        L.xmi_sad.restype = C.c_int64
+        L.xmi_sad.argtypes = [i, vp, u32, vp, u32]
+        L.xmi_satd_hm.restype = C.c_int64
+        L.xmi_satd_hm.argtypes = [i, vp, u32, vp, u32]
+        L.xmi_ssd.restype = C.c_int64
+        L.xmi_ssd.argtypes = [i, vp, ip, vp, ip]
+        L.xmi_satd.restype = C.c_int64
+        L.xmi_satd.argtypes = [i, vp, ip, vp, ip]
+        L.xmi_sub_dct.restype = i
+        L.xmi_sub_dct.argtypes = [vp, vp, u32, vp, u32, i, u32]
+        L.xmi_quant.restype = C.c_int64
+        L.xmi_quant.argtypes = [vp, vp, u32, u32, i, i, i]
+        L.xmi_dequant.restype = i
+        L.xmi_dequant.argtypes = [vp, vp, u32, u32, i, i]
+        L.xmi_idct_add.restype = i
+        L.xmi_idct_add.argtypes = [vp, u32, vp, u32, vp, i, u32]
+        L.xmi_tu_chain.restype = C.c_int64
+        L.xmi_tu_chain.argtypes = [vp, vp, vp, vp, i, i, i, u32, u32, i]
+    _lib = L
+    return L
+
+
+def lib():
+    return load()
+
+
+def check(rc):
+    """Raise XmiError with the library's message when an entry point reports failure."""
+    if rc < 0:
+        raise XmiError(f"libx265_amd error {rc}: {load().xmi_last_error().decode()}")
+    return rc
+
+
+def surface_pitch(rng):
+    """Smallest legal row pitch (elements) for a [-rng, rng] surface: multiple of 4, >= 2*rng+1."""
+    return (2 * rng + 1 + 3) & ~3
