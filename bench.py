@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the ME SAD-surface hot path on MI355X.
+
+A step = one P-frame: the full 85-PU SAD pyramid of every CTU over the [-R,R]^2 integer search window
+(current frame vs. the padded previous frame), computed by libx265_amd.so from frames that are
+already resident in HBM. Workload at N=1: 1920x1080 (coded 1920x1088, 510 CTUs), R=64, synthetic
+IPPP video - BASELINE.json configs[1]. With --gpus N every rank runs the same number of steps on its
+own GOP segment (weak scaling, no data-path collective); the only exchange is the final gather of
+per-rank statistics.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak; measured copy ceiling is ~6.3 TB/s
+PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/config.h:52)
+
+
+def synth_frame(w, h, t, seed):
+    """Synthetic 8-bit luma: moving sinusoid texture (3,2) px/frame + uniform noise in [-6,6]."""
+    rng = np.random.default_rng(seed * 1000 + t)
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = 128 + 60 * np.sin((xx + 3 * t) / 17.0) + 40 * np.cos((yy + 2 * t) / 11.0) + rng.integers(-6, 7, (h, w))
+    return np.clip(y, 0, 255).astype(np.uint8)
+
+
+def pad_frame(f, pad):
+    return np.pad(f, pad, mode="edge")  # edge replication, as xFramePadding does (src/encode.cpp:2043)
+
+
+def algorithmic_bytes(w, h, rng, pad):
+    nctu = (w // 64) * (h // 64)
+    nmv = (2 * rng + 1) ** 2
+    return w * h + (w + 2 * pad) * (h + 2 * pad) + nctu * nmv * 180, nctu * nmv * 85
+
+
+def cpu_baseline(cur, refp, rng, budget_s=12.0):
+    """Time the CPU SAD path on a bounded sample of CTUs (rank 0 only). Returns a dict or None."""
+    exe = os.path.join(ROOT, "oracle", "cpu_baseline")
+    if not os.path.exists(exe):
+        return None
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libx265ref_pixel.so")
+    h, w = cur.shape
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(cur.tobytes())
+        f.write(refp.tobytes())
+        path = f.name
+    try:
+        def run(nctu):
+            args = [exe, path, str(w), str(h), str(PAD), str(rng), str(nctu)]
+            if os.path.exists(ref_lib):
+                args.append(ref_lib)
+            out = subprocess.run(args, capture_output=True, text=True, timeout=300).stdout.strip()
+            kv = dict(x.split("=") for x in out.split())
+            return kv["kind"], int(kv["cands"]), float(kv["seconds"])
+        kind, cands, sec = run(2)                      # calibrate
+        n = max(2, min((w // 64) * (h // 64), int(2 * budget_s / max(sec, 1e-6))))
+        kind, cands, sec = run(n)
+        return {"value": round(cands / sec / 1e9, 5), "unit": "Gcand/s", "cores": 1, "kind": kind,
+                "sample": f"{n} of {(w // 64) * (h // 64)} CTUs x {(2 * rng + 1) ** 2} MVs x 85 PUs, one xSad call per "
+                          f"candidate, {sec:.1f} s single thread"}
+    finally:
+        os.unlink(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--range", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from x265_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    L = capi.load()
+    capi.check(L.xmi_init(local))
+
+    w = args.width
+    h = (args.height + 63) // 64 * 64          # frames are padded to CTU multiples (src/x265.cpp:157-168)
+    w = (w + 63) // 64 * 64
+    R = args.range
+    pitch = capi.surface_pitch(R)
+    nctu = (w // 64) * (h // 64)
+    nmv1 = 2 * R + 1
+
+    # each rank owns its own GOP segment of synthetic video (seed per rank)
+    frames = [synth_frame(w, h, t, seed=7 + rank) for t in range(args.frames)]
+    d_cur = [torch.from_numpy(f).to(dev) for f in frames]
+    d_ref = [torch.from_numpy(pad_frame(f, PAD)).to(dev) for f in frames]
+    ref_stride = w + 2 * PAD
+
+    s8 = torch.empty((nctu, 64, nmv1, pitch), dtype=torch.int16, device=dev)
+    s16 = torch.empty((nctu, 16, nmv1, pitch), dtype=torch.int16, device=dev)
+    s32 = torch.empty((nctu, 4, nmv1, pitch), dtype=torch.int32, device=dev)
+    s64 = torch.empty((nctu, 1, nmv1, pitch), dtype=torch.int32, device=dev)
+    geom = capi.SadGeom(w, h, w, ref_stride, R, pitch)
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        t = 1 + i % (args.frames - 1)          # P-frame t is searched in frame t-1
+        ref0 = d_ref[t - 1].data_ptr() + PAD * ref_stride + PAD
+        capi.check(L.xmi_sad_surface_dev(C.byref(geom), d_cur[t].data_ptr(), ref0, s8.data_ptr(), s16.data_ptr(),
+                                         s32.data_ptr(), s64.data_ptr(), 0, nctu, stream.cuda_stream))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for i in range(args.steps):
+        step(i)
+        ev[i + 1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # average duration of the dominant kernel pair (main + edge column), HIP events on the launch stream
+    kern_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    kern_avg_ms = sum(kern_ms) / len(kern_ms)
+
+    # a light end-of-segment exchange: per-rank statistics record (what a rate-control gather would carry)
+    rec = torch.tensor([rank, args.steps, float(s64[0, 0, R, R].item()), kern_avg_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        recs = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(recs, rec)
+
+    if rank == 0:
+        abytes, cands = algorithmic_bytes(w, h, R, PAD)
+        value = cands * args.steps * world / elapsed / 1e9
+        achieved = abytes / (kern_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ME SAD candidate evaluations per second (85-PU pyramid over the full integer window)",
+            "value": round(value, 3), "unit": "Gcand/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.width}x{args.height} 8-bit luma (coded {w}x{h}, {nctu} CTUs), IPPP P-frame SAD pyramid, "
+                                   f"search range {R} ({nmv1}x{nmv1} integer MVs), {args.frames} resident frames per GPU",
+                       "cands_per_step": cands, "frames_per_s": round(args.steps * world / elapsed, 2),
+                       "parallelism": f"gop-segments x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),
+                         "kernel_ms_min": round(kern_ms[0], 4)},
+        }
+        if not args.no_cpu_baseline:
+            t = 1
+            out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
