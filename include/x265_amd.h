@@ -48,24 +48,26 @@ const char *xmi_version(void);
  * box xCuMvClip allows, src/encode.cpp:3794-3812) and every square PU of the quad-tree
  * (64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 = 85 per MV) the exact SAD.
  *
- * Output planes (element index, row-major):
- *   sadN[ctu][blk][dy + range][dx + range], row pitch `pitch` elements, 2*range+1 rows per block,
- *   blk in raster order inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx), ctu in
- *   raster order. sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32.
- * Requirements: width,height multiples of 64; range in {16,32,64,128}; pitch a multiple of 4 and
- * >= 2*range+1; the reference frame must be readable range+4 pixels beyond every edge (the
- * reference encoder pads by 80, inc/config.h:52); d_cur, d_ref_origin and both strides 4-byte
- * aligned; output planes 16-byte aligned. */
+ * Output planes: sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32. The layout is tiled so that the
+ * GPU writes whole cache lines: per (ctu, dy) one row = R/8 tiles of 16 consecutive dx, each tile
+ * holding all blocks of the level ([block slot][dx % 16]), then one short tile with dx = +R alone
+ * ([block slot]); sad64 rows are padded to a multiple of 4 elements. ctu is raster order in the
+ * frame. Use xmi_sad_surface_index() for the element index of (level, ctu, blk, dy, dx) with blk in
+ * raster order inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx; 64x64: 0).
+ * Requirements: width,height multiples of 64; range in {16,32,64,128}; the reference frame must be
+ * readable range+4 pixels beyond every edge (the reference encoder pads by 80, inc/config.h:52);
+ * d_cur, d_ref_origin and both strides 4-byte aligned; output planes 16-byte aligned. */
 typedef struct xmi_sad_geom {
     int width, height;   /* coded luma size */
     int cur_stride;      /* bytes between rows of the current frame */
     int ref_stride;      /* bytes between rows of the padded reference frame */
     int range;           /* R */
-    int pitch;           /* elements between surface rows */
 } xmi_sad_geom;
 
 /* elements in one surface plane set: level 0 = 8x8, 1 = 16x16, 2 = 32x32, 3 = 64x64 */
 size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level);
+/* element index inside the level's plane; dy,dx in [-range, range] */
+size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk, int dy, int dx);
 
 int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8_t *d_ref_origin,
                         uint16_t *d_sad8, uint16_t *d_sad16, uint32_t *d_sad32, uint32_t *d_sad64,

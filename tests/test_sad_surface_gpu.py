@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_lib as O
-from x265_amd import capi
+from x265_amd import capi, layout
 
 pytestmark = pytest.mark.gpu
 
@@ -38,19 +38,30 @@ def make_frames(w, h, pad, seed, kind="noise"):
     return np.ascontiguousarray(cur), np.ascontiguousarray(ref)
 
 
-def gpu_surface(L, cur, ref, pad, rng, pitch):
+def gpu_surface(L, cur, ref, pad, rng):
+    """run the host-pointer entry point and return the four levels in natural [ctu][blk][dy][dx] order"""
     h, w = cur.shape
-    g = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng, pitch)
+    g = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng)
     nctu = (h // 64) * (w // 64)
-    nmv = 2 * rng + 1
-    s8 = np.full((nctu, 64, nmv, pitch), 0xAAAA, np.uint16)
-    s16 = np.full((nctu, 16, nmv, pitch), 0xAAAA, np.uint16)
-    s32 = np.full((nctu, 4, nmv, pitch), 0xAAAAAAAA, np.uint32)
-    s64 = np.full((nctu, 1, nmv, pitch), 0xAAAAAAAA, np.uint32)
-    assert L.xmi_sad_surface_elems(C.byref(g), 0) == s8.size
-    assert L.xmi_sad_surface_elems(C.byref(g), 3) == s64.size
-    capi.check(L.xmi_sad_surface(C.byref(g), O.p(cur), O.at(ref, pad, pad), pad, O.p(s8), O.p(s16), O.p(s32), O.p(s64)))
-    return s8, s16, s32, s64
+    dts = (np.uint16, np.uint16, np.uint32, np.uint32)
+    planes = []
+    for lvl in range(4):
+        n = L.xmi_sad_surface_elems(C.byref(g), lvl)
+        assert n == nctu * (2 * rng + 1) * layout.row_elems(rng, lvl)
+        planes.append(np.full(n, 0xAAAA, dts[lvl]))
+    capi.check(L.xmi_sad_surface(C.byref(g), O.p(cur), O.at(ref, pad, pad), pad, *[O.p(x) for x in planes]))
+    nat = [layout.untile(planes[lvl], nctu, rng, lvl) for lvl in range(4)]
+    # the C-side index helper agrees with the host-side untiling
+    r = np.random.default_rng(1)
+    for lvl in range(4):
+        for _ in range(20):
+            ctu, blk = int(r.integers(nctu)), int(r.integers(layout.NBLK[lvl]))
+            dy, dx = int(r.integers(-rng, rng + 1)), int(r.integers(-rng, rng + 1))
+            idx = L.xmi_sad_surface_index(C.byref(g), lvl, ctu, blk, dy, dx)
+            assert planes[lvl][idx] == nat[lvl][ctu, blk, dy + rng, dx + rng]
+        idx = L.xmi_sad_surface_index(C.byref(g), lvl, nctu - 1, layout.NBLK[lvl] - 1, rng, rng)
+        assert planes[lvl][idx] == nat[lvl][nctu - 1, -1, 2 * rng, 2 * rng]
+    return nat
 
 
 @pytest.mark.parametrize("w,h,rng,kind", [(64, 64, 16, "noise"), (128, 64, 32, "noise"), (64, 128, 64, "smooth"),
@@ -58,21 +69,17 @@ def gpu_surface(L, cur, ref, pad, rng, pitch):
 def test_surface_matches_oracle(L, orc, w, h, rng, kind):
     pad = ((rng + 4 + 15) // 16) * 16
     cur, ref = make_frames(w, h, pad, seed=w * 7 + h + rng, kind=kind)
-    pitch = capi.surface_pitch(rng)
-    got = gpu_surface(L, cur, ref, pad, rng, pitch)
-    want = O.sad_surface(orc, cur, ref, pad, rng, pitch)
-    nmv = 2 * rng + 1
+    got = gpu_surface(L, cur, ref, pad, rng)
+    want = O.sad_surface(orc, cur, ref, pad, rng)
     for name, a, b in zip(("sad8", "sad16", "sad32", "sad64"), got, want):
-        np.testing.assert_array_equal(a[..., :nmv], b[..., :nmv], err_msg=f"{name} {w}x{h} R={rng} {kind}")
-        # columns beyond 2R+1 are padding the kernels never touch (the host form zeroes them)
-        assert not a[..., nmv:].any()
+        np.testing.assert_array_equal(a, b, err_msg=f"{name} {w}x{h} R={rng} {kind}")
 
 
 def test_surface_pyramid_property_416x240(L):
     """config 0 geometry (416x240 coded as 448x256, R=64): levels must sum exactly (no oracle needed)."""
     rng, pad = 64, 80
     cur, ref = make_frames(448, 256, pad, seed=1234, kind="smooth")
-    s8, s16, s32, s64 = gpu_surface(L, cur, ref, pad, rng, capi.surface_pitch(rng))
+    s8, s16, s32, s64 = gpu_surface(L, cur, ref, pad, rng)
     nctu = s8.shape[0]
     a8 = s8.reshape(nctu, 8, 8, *s8.shape[2:]).astype(np.uint32)
     a16 = a8.reshape(nctu, 4, 2, 4, 2, *s8.shape[2:]).sum(axis=(2, 4))
@@ -89,19 +96,18 @@ def test_surface_pyramid_property_416x240(L):
         assert s64[ctu, 0, 0, 2 * rng] == d
 
 
-def test_surface_ctu_subrange_and_errors(L, orc):
+def test_surface_rejects_bad_arguments(L):
     rng, pad = 16, 32
     cur, ref = make_frames(192, 64, pad, seed=3)
     h, w = cur.shape
-    pitch = capi.surface_pitch(rng)
-    g = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng, pitch)
-    # bad arguments are rejected with a message, not executed
-    bad = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], 20, pitch)
     s = np.zeros(16, np.uint8)
+    # bad arguments are rejected with a message, not executed
+    bad = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], 20)
     assert L.xmi_sad_surface(C.byref(bad), O.p(cur), O.at(ref, pad, pad), pad, O.p(s), O.p(s), O.p(s), O.p(s)) == -1
     assert b"range" in L.xmi_last_error()
-    bad = capi.SadGeom(w - 2, h, cur.strides[0], ref.strides[0], rng, pitch)
+    bad = capi.SadGeom(w - 2, h, cur.strides[0], ref.strides[0], rng)
     assert L.xmi_sad_surface(C.byref(bad), O.p(cur), O.at(ref, pad, pad), pad, O.p(s), O.p(s), O.p(s), O.p(s)) == -1
-    bad = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng, 2 * rng + 1)
-    assert L.xmi_sad_surface(C.byref(bad), O.p(cur), O.at(ref, pad, pad), pad, O.p(s), O.p(s), O.p(s), O.p(s)) == -1
-    assert g.width == 192
+    assert b"multiples of 64" in L.xmi_last_error()
+    good = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng)
+    assert L.xmi_sad_surface(C.byref(good), O.p(cur), O.at(ref, pad, pad), 8, O.p(s), O.p(s), O.p(s), O.p(s)) == -1
+    assert b"pad" in L.xmi_last_error()

@@ -16,7 +16,7 @@ class XmiError(RuntimeError):
 
 class SadGeom(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("cur_stride", C.c_int), ("ref_stride", C.c_int),
-                ("range", C.c_int), ("pitch", C.c_int)]
+                ("range", C.c_int)]
 
 
 _lib = None
@@ -40,6 +40,8 @@ def load():
     L.xmi_version.restype = C.c_char_p
     L.xmi_sad_surface_elems.restype = C.c_size_t
     L.xmi_sad_surface_elems.argtypes = [C.POINTER(SadGeom), i]
+    L.xmi_sad_surface_index.restype = C.c_size_t
+    L.xmi_sad_surface_index.argtypes = [C.POINTER(SadGeom), i, i, i, i, i]
     L.xmi_sad_surface_dev.restype = i
     L.xmi_sad_surface_dev.argtypes = [C.POINTER(SadGeom), vp, vp, vp, vp, vp, vp, i, i, vp]
     L.xmi_sad_surface.restype = i
@@ -89,8 +91,3 @@ def check(rc):
     if rc < 0:
         raise XmiError(f"libx265_amd error {rc}: {load().xmi_last_error().decode()}")
     return rc
-
-
-def surface_pitch(rng):
-    """Smallest legal row pitch (elements) for a [-rng, rng] surface: multiple of 4, >= 2*rng+1."""
-    return (2 * rng + 1 + 3) & ~3

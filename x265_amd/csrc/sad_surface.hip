@@ -16,6 +16,14 @@
 //   16x16 = sum of the lane's 4 children (still packed u16, max 65280); 32x32 = DPP row-rotate sum
 //   over the 4 lanes of a quadrant; 64x64 = cross-row shuffle sum over the 4 quadrants.
 //   The dx = +R column (one more than a multiple of 4) is produced by the EDGE instantiation.
+//
+// Output layout (chosen so that every store instruction of a wavefront writes one contiguous run):
+//   per (ctu, dy) a row of R/8 full tiles of 16 dx each, then one short tile holding dx = +R alone:
+//     sad8 : [ctu][dy][tile][c*16 + z][dx % 16]   c = (by8&1)*2 + (bx8&1), z = z-order of the parent 16x16
+//     sad16: [ctu][dy][tile][z][dx % 16]
+//     sad32: [ctu][dy][tile][q][dx % 16]          q = raster index of the 32x32 quadrant
+//     sad64: [ctu][dy][tile][dx % 16]             (row padded to a multiple of 4 elements)
+//   the short tile drops the [dx % 16] dimension. xmi_sad_surface_index() does this arithmetic.
 #include "xmi_common.h"
 
 namespace {
@@ -30,12 +38,17 @@ struct SadParams {
     u32 *sad32, *sad64;
     int cur_stride, ref_stride;
     int wc;         // CTUs per frame row
-    int pitch;      // elements per surface row
     int seg_len;    // dy rows per workgroup (main) or per lane group (edge)
     int ctu_begin;
 };
 
 constexpr int kCurLdsBytes = 16 * 16 * 16;  // [row in 16x16 block][z][16 bytes]
+
+// elements per (ctu, dy) row of each level's plane
+__host__ __device__ constexpr int row_elems(int R, int level)
+{
+    return level == 0 ? (R / 8) * 1024 + 64 : level == 1 ? (R / 8) * 256 + 16 : level == 2 ? (R / 8) * 64 + 4 : (R / 8) * 16 + 4;
+}
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
@@ -94,19 +107,18 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
 
     const unsigned char *ref_lane = ref_lds + (by16 * 16 + dy_lane0) * rls + (bx16 * 4 + g) * 4;
 
-    // output offsets (elements) inside this CTU's block of planes
-    const size_t plane = (size_t)nmv * p.pitch;
-    const int dx_off = EDGE ? 2 * R : 4 * g;
-    uint16_t *o8 = p.sad8 + (size_t)ctu * 64 * plane;
-    uint16_t *o16 = p.sad16 + (size_t)ctu * 16 * plane;
-    u32 *o32 = p.sad32 + (size_t)ctu * 4 * plane;
-    u32 *o64 = p.sad64 + (size_t)ctu * plane;
-    const u32 blk8_00 = (u32)((by16 * 2) * 8 + bx16 * 2);
-    const u32 off8_c0 = (u32)(blk8_00 * plane) + dx_off;            // child (cy,cx) adds (cy*8+cx)*plane
-    const u32 off16 = (u32)((by16 * 4 + bx16) * plane) + dx_off;
-    const u32 off32 = (u32)(((by16 >> 1) * 2 + (bx16 >> 1)) * plane) + dx_off;
-    const u32 off64 = (u32)dx_off;
-    const u32 planeu = (u32)plane;
+    // output offsets (elements) inside this CTU's rows; a full tile is [blk][16 dx], the short tile [blk]
+    constexpr int ROW8 = row_elems(R, 0), ROW16 = row_elems(R, 1), ROW32 = row_elems(R, 2), ROW64 = row_elems(R, 3);
+    uint16_t *o8 = p.sad8 + (size_t)ctu * nmv * ROW8;
+    uint16_t *o16 = p.sad16 + (size_t)ctu * nmv * ROW16;
+    u32 *o32 = p.sad32 + (size_t)ctu * nmv * ROW32;
+    u32 *o64 = p.sad64 + (size_t)ctu * nmv * ROW64;
+    const int q = (by16 >> 1) * 2 + (bx16 >> 1);
+    const u32 off8 = EDGE ? (R / 8) * 1024 + z : wave * 1024 + z * 16 + gl * 4;   // child c adds c*16 (*16 in a full tile)
+    const u32 off16 = EDGE ? (R / 8) * 256 + z : wave * 256 + z * 16 + gl * 4;
+    const u32 off32 = EDGE ? (R / 8) * 64 + q : wave * 64 + q * 16 + gl * 4;
+    const u32 off64 = EDGE ? (R / 8) * 16 : wave * 16 + gl * 4;
+    constexpr u32 CH = EDGE ? 16 : 256;                                           // element step between children
 
     u64 acc[4][8];
 #pragma unroll
@@ -173,23 +185,24 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
             t3 += (u32)__shfl_xor((int)t3, 32);
 
             if (dyl >= 0 && dyl < ndy_lane && dyi < nmv) {
-                const u32 row = (u32)dyi * (u32)p.pitch;
                 if (!EDGE) {
-                    *reinterpret_cast<u64 *>(o8 + off8_c0 + row) = v0;
-                    *reinterpret_cast<u64 *>(o8 + off8_c0 + planeu + row) = v1;
-                    *reinterpret_cast<u64 *>(o8 + off8_c0 + 8 * planeu + row) = v2;
-                    *reinterpret_cast<u64 *>(o8 + off8_c0 + 9 * planeu + row) = v3;
-                    *reinterpret_cast<u64 *>(o16 + off16 + row) = v16;
-                    if ((z & 3) == 0) *reinterpret_cast<uint4 *>(o32 + off32 + row) = make_uint4(x0, x1, x2, x3);
-                    if (z == 0) *reinterpret_cast<uint4 *>(o64 + off64 + row) = make_uint4(t0, t1, t2, t3);
+                    u64 *r8 = reinterpret_cast<u64 *>(o8 + (u32)dyi * ROW8 + off8);
+                    r8[0] = v0;
+                    r8[CH / 4] = v1;
+                    r8[2 * CH / 4] = v2;
+                    r8[3 * CH / 4] = v3;
+                    *reinterpret_cast<u64 *>(o16 + (u32)dyi * ROW16 + off16) = v16;
+                    if ((z & 3) == 0) *reinterpret_cast<uint4 *>(o32 + (u32)dyi * ROW32 + off32) = make_uint4(x0, x1, x2, x3);
+                    if (z == 0) *reinterpret_cast<uint4 *>(o64 + (u32)dyi * ROW64 + off64) = make_uint4(t0, t1, t2, t3);
                 } else {
-                    o8[off8_c0 + row] = (uint16_t)v0;
-                    o8[off8_c0 + planeu + row] = (uint16_t)v1;
-                    o8[off8_c0 + 8 * planeu + row] = (uint16_t)v2;
-                    o8[off8_c0 + 9 * planeu + row] = (uint16_t)v3;
-                    o16[off16 + row] = (uint16_t)v16;
-                    if ((z & 3) == 0) o32[off32 + row] = x0;
-                    if (z == 0) o64[off64 + row] = t0;
+                    uint16_t *r8 = o8 + (u32)dyi * ROW8 + off8;
+                    r8[0] = (uint16_t)v0;
+                    r8[CH] = (uint16_t)v1;
+                    r8[2 * CH] = (uint16_t)v2;
+                    r8[3 * CH] = (uint16_t)v3;
+                    o16[(u32)dyi * ROW16 + off16] = (uint16_t)v16;
+                    if ((z & 3) == 0) o32[(u32)dyi * ROW32 + off32] = x0;
+                    if (z == 0) o64[(u32)dyi * ROW64 + off64] = t0;
                 }
             }
         }
@@ -236,12 +249,34 @@ int launch_pair(const SadParams &p, const SadParams &pe, int n, int nseg, size_t
 
 extern "C" {
 
+static bool range_ok(int R) { return R == 16 || R == 32 || R == 64 || R == 128; }
+
 size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level)
 {
-    if (!g || level < 0 || level > 3) return 0;
-    static const int blks[4] = { 64, 16, 4, 1 };
+    if (!g || level < 0 || level > 3 || !range_ok(g->range)) return 0;
     const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
-    return nctu * blks[level] * (size_t)(2 * g->range + 1) * (size_t)g->pitch;
+    return nctu * (size_t)(2 * g->range + 1) * (size_t)row_elems(g->range, level);
+}
+
+size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk, int dy, int dx)
+{
+    const int R = g->range;
+    const int dxi = dx + R, dyi = dy + R;
+    int slot;  // position of the block inside a tile
+    if (level == 0) {
+        const int by = blk >> 3, bx = blk & 7, by16 = by >> 1, bx16 = bx >> 1;
+        const int z = (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
+        slot = ((by & 1) * 2 + (bx & 1)) * 16 + z;
+    } else if (level == 1) {
+        const int by16 = blk >> 2, bx16 = blk & 3;
+        slot = (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
+    } else {
+        slot = level == 2 ? blk : 0;
+    }
+    static const int nblk[4] = { 64, 16, 4, 1 };
+    const size_t row = ((size_t)ctu * (2 * R + 1) + dyi) * (size_t)row_elems(R, level);
+    if (dxi == 2 * R) return row + (size_t)(R / 8) * nblk[level] * 16 + slot;
+    return row + ((size_t)(dxi >> 4) * nblk[level] + slot) * 16 + (dxi & 15);
 }
 
 int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8_t *d_ref_origin,
@@ -254,9 +289,8 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     XMI_ARG(g->width > 0 && g->height > 0 && g->width % 64 == 0 && g->height % 64 == 0,
             "xmi_sad_surface_dev: width/height (%d x %d) must be positive multiples of 64", g->width, g->height);
     const int R = g->range;
-    XMI_ARG(R == 16 || R == 32 || R == 64 || R == 128, "xmi_sad_surface_dev: range %d not in {16,32,64,128}", R);
+    XMI_ARG(range_ok(R), "xmi_sad_surface_dev: range %d not in {16,32,64,128}", R);
     const int nmv = 2 * R + 1;
-    XMI_ARG(g->pitch >= nmv && g->pitch % 4 == 0, "xmi_sad_surface_dev: pitch %d must be a multiple of 4 and >= %d", g->pitch, nmv);
     XMI_ARG(g->cur_stride >= g->width && g->cur_stride % 4 == 0 && g->ref_stride >= g->width + 2 * (R + 4) && g->ref_stride % 4 == 0,
             "xmi_sad_surface_dev: strides (cur %d, ref %d) must be multiples of 4 and cover width (+2*(range+4) for ref)",
             g->cur_stride, g->ref_stride);
@@ -266,8 +300,6 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     const int nctu = (g->width / 64) * (g->height / 64);
     XMI_ARG(ctu_begin >= 0 && ctu_begin <= ctu_end && ctu_end <= nctu, "xmi_sad_surface_dev: CTU range [%d,%d) outside [0,%d)", ctu_begin, ctu_end, nctu);
     if (ctu_begin == ctu_end) return XMI_OK;
-    const size_t plane_bytes_max = (size_t)64 * nmv * g->pitch * 2;
-    XMI_ARG(plane_bytes_max < (1ull << 31), "xmi_sad_surface_dev: pitch too large");
 
     SadParams p;
     p.cur = d_cur;
@@ -279,7 +311,6 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     p.cur_stride = g->cur_stride;
     p.ref_stride = g->ref_stride;
     p.wc = g->width / 64;
-    p.pitch = g->pitch;
     p.ctu_begin = ctu_begin;
 
     hipStream_t st = xmi::as_stream(stream);
@@ -312,6 +343,7 @@ int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *re
     int rc = xmi::require_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(g && cur && ref_origin && sad8 && sad16 && sad32 && sad64, "xmi_sad_surface: null argument");
+    XMI_ARG(range_ok(g->range), "xmi_sad_surface: range %d not in {16,32,64,128}", g->range);
     XMI_ARG(pad >= g->range + 4 && pad % 4 == 0, "xmi_sad_surface: pad %d must be a multiple of 4 and >= range+4", pad);
     XMI_ARG(g->width > 0 && g->height > 0 && g->cur_stride >= g->width && g->ref_stride >= g->width + 2 * pad,
             "xmi_sad_surface: bad geometry");
@@ -330,11 +362,7 @@ int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *re
     const uint8_t *ref_base = ref_origin - (ptrdiff_t)pad * g->ref_stride - pad;
     XMI_HIP(hipMemcpy(d_cur, cur, cur_bytes, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy(d_ref, ref_base, ref_bytes, hipMemcpyHostToDevice));
-    // columns [2R+1, pitch) are never written by the kernels: define them
-    XMI_HIP(hipMemset(d8, 0, e8 * 2));
-    XMI_HIP(hipMemset(d16, 0, e16 * 2));
-    XMI_HIP(hipMemset(d32, 0, e32 * 4));
-    XMI_HIP(hipMemset(d64, 0, e64 * 4));
+    XMI_HIP(hipMemset(d64, 0, e64 * 4));  // the 3 padding elements per sad64 row are never written: define them
     rc = xmi_sad_surface_dev(g, d_cur, d_ref + (size_t)pad * g->ref_stride + pad, d8, d16, d32, d64, 0,
                              (g->width / 64) * (g->height / 64), nullptr);
     if (rc != XMI_OK) return rc;

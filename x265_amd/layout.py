@@ -1,0 +1,32 @@
+"""Host-side description of the tiled SAD-surface layout written by xmi_sad_surface* (pure indexing)."""
+import numpy as np
+
+NBLK = (64, 16, 4, 1)
+
+
+def row_elems(rng, level):
+    t = rng // 8
+    return (t * 1024 + 64, t * 256 + 16, t * 64 + 4, t * 16 + 4)[level]
+
+
+def _z16(by16, bx16):
+    return (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1))
+
+
+def slot_of_block(level):
+    """slot index inside a tile for each raster-order block of the level"""
+    if level == 0:
+        return np.array([((by & 1) * 2 + (bx & 1)) * 16 + _z16(by >> 1, bx >> 1) for by in range(8) for bx in range(8)])
+    if level == 1:
+        return np.array([_z16(by, bx) for by in range(4) for bx in range(4)])
+    return np.arange(NBLK[level])
+
+
+def untile(plane, nctu, rng, level):
+    """tiled plane (flat array) -> natural [ctu][blk (raster)][dy+R][dx+R] array"""
+    nmv, t, nb = 2 * rng + 1, rng // 8, NBLK[level]
+    rows = np.asarray(plane).reshape(nctu, nmv, row_elems(rng, level))
+    full = rows[:, :, :t * nb * 16].reshape(nctu, nmv, t, nb, 16).transpose(0, 3, 1, 2, 4).reshape(nctu, nb, nmv, 2 * rng)
+    last = rows[:, :, t * nb * 16:t * nb * 16 + nb].transpose(0, 2, 1)[..., None]
+    nat = np.concatenate([full, last], axis=3)
+    return np.ascontiguousarray(nat[:, slot_of_block(level)])
