@@ -117,10 +117,10 @@ def main():
     d_ref = [torch.from_numpy(pad_frame(f, PAD)).to(dev) for f in frames]
     ref_stride = w + 2 * PAD
 
-    s8 = torch.empty((nctu, nmv1, layout.row_elems(R, 0)), dtype=torch.int16, device=dev)
-    s16 = torch.empty((nctu, nmv1, layout.row_elems(R, 1)), dtype=torch.int16, device=dev)
-    s32 = torch.empty((nctu, nmv1, layout.row_elems(R, 2)), dtype=torch.int32, device=dev)
-    s64 = torch.empty((nctu, nmv1, layout.row_elems(R, 3)), dtype=torch.int32, device=dev)
+    s8 = torch.empty(layout.plane_elems(nctu, R, 0), dtype=torch.int16, device=dev)
+    s16 = torch.empty(layout.plane_elems(nctu, R, 1), dtype=torch.int16, device=dev)
+    s32 = torch.empty(layout.plane_elems(nctu, R, 2), dtype=torch.int32, device=dev)
+    s64 = torch.empty(layout.plane_elems(nctu, R, 3), dtype=torch.int32, device=dev)
     geom = capi.SadGeom(w, h, w, ref_stride, R)
     stream = torch.cuda.current_stream(dev)
 
@@ -156,7 +156,7 @@ def main():
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
     # a light end-of-segment exchange: per-rank statistics record (what a rate-control gather would carry)
-    rec = torch.tensor([rank, args.steps, float(s64[0, R, (R // 16) * 16 + (R % 16)].item()), kern_avg_ms], dtype=torch.float64, device=dev)
+    rec = torch.tensor([rank, args.steps, float(s64[R * layout.row_elems(R, 3) + R].item()), kern_avg_ms], dtype=torch.float64, device=dev)
     if world > 1:
         recs = [torch.empty_like(rec) for _ in range(world)]
         dist.all_gather(recs, rec)

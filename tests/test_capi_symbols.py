@@ -1,0 +1,67 @@
+"""CPU: the built libraries export every entry point the public header declares (no compute calls)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "x265_amd", "lib", "libx265_amd.so")
+DROPIN = os.path.join(ROOT, "x265_amd", "lib", "libx265_amd_dropin.so")
+
+
+def exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
+def declared():
+    text = open(os.path.join(ROOT, "include", "x265_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(xmi_[a-z0-9_]+)\s*\(", text))
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built (run __graft_entry__.build())")
+def test_every_declared_symbol_is_exported():
+    decl = declared()
+    assert len(decl) >= 20
+    missing = decl - exported(LIB)
+    assert not missing, f"declared in include/x265_amd.h but not exported: {sorted(missing)}"
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
+def test_library_loads_and_reports_without_gpu():
+    import ctypes as C
+    lib = C.CDLL(LIB)
+    lib.xmi_version.restype = C.c_char_p
+    assert b"gfx950" in lib.xmi_version()
+    lib.xmi_last_error.restype = C.c_char_p
+    assert isinstance(lib.xmi_last_error(), bytes)
+    lib.xmi_device_count.restype = C.c_int
+    assert lib.xmi_device_count() >= 0
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in library not built")
+def test_dropin_exports_the_reference_primitive_interface():
+    # mangled names are the ones an object compiled from the reference's encode.cpp imports
+    want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "xSatd_AMP", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType",
+            "_Z8xDeQuantPsS_jjii", "_Z8xIDctAddPhjPsjS_S0_S0_ij", "xmi_install_primitives"}
+    assert want <= exported(DROPIN)
+
+
+def test_no_cpu_fallback_when_no_gpu():
+    """Without a GPU the compute entry points must fail loudly, never compute on the host."""
+    import ctypes as C
+    if not os.path.exists(LIB):
+        pytest.skip("library not built")
+    lib = C.CDLL(LIB)
+    lib.xmi_device_count.restype = C.c_int
+    if lib.xmi_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    lib.xmi_last_error.restype = C.c_char_p
+    import numpy as np
+    a = np.zeros((8, 8), np.uint8)
+    lib.xmi_sad.restype = C.c_int64
+    lib.xmi_sad.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    assert lib.xmi_sad(8, a.ctypes.data, 8, a.ctypes.data, 8) == -3
+    assert b"no CPU fallback" in lib.xmi_last_error()

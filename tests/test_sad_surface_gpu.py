@@ -47,7 +47,7 @@ def gpu_surface(L, cur, ref, pad, rng):
     planes = []
     for lvl in range(4):
         n = L.xmi_sad_surface_elems(C.byref(g), lvl)
-        assert n == nctu * (2 * rng + 1) * layout.row_elems(rng, lvl)
+        assert n == layout.plane_elems(nctu, rng, lvl)
         planes.append(np.full(n, 0xAAAA, dts[lvl]))
     capi.check(L.xmi_sad_surface(C.byref(g), O.p(cur), O.at(ref, pad, pad), pad, *[O.p(x) for x in planes]))
     nat = [layout.untile(planes[lvl], nctu, rng, lvl) for lvl in range(4)]

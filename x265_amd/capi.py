@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libx265_amd.so")
+# X265_AMD_LIB lets a profiling run point at an experimental build of the same library
+LIB_PATH = os.environ.get("X265_AMD_LIB") or os.path.join(_HERE, "lib", "libx265_amd.so")
 
 XMI_OK = 0
 SLICE_P, SLICE_I, MODE_INVALID = 1, 2, 255

@@ -1,0 +1,133 @@
+// Batched block-distortion metrics for gfx950: SAD, SSD, HM-style SATD and x264-style SATD over packed
+// n x n block pairs.
+//
+//   SAD        xSad4x4..xSad64x64                       src/pixel.cpp:546-696
+//   SSD        x265_pixel_ssd_* (exact sum of squares)  src/pixel.cpp:793-816
+//   SATD (HM)  xCalcHADs4x4 ((s+1)>>1), xCalcHADs8x8 ((s+2)>>2), 16/32/64 = sum of rounded 8x8 tiles
+//                                                        src/pixel.cpp:63-458
+//   SATD (x264) x265_pixel_satd_{4x4,8x8,16x16}_sse4 = (sum over 4x4 tiles of sum|H4 D H4|) / 2
+//                                                        src/x86/pixel-a.asm:1645, 3455, 1787
+//
+// One lane owns one tile (4x4 or 8x8) of one block, keeps the whole residual tile in registers, runs the
+// 2-D Hadamard there, and the tiles of a block (consecutive lanes) are summed with a segmented
+// wavefront reduction. HBM traffic is the algorithmic 2*n*n + 4 bytes per pair.
+#include "xmi_common.h"
+
+namespace {
+
+typedef unsigned int u32;
+
+enum { M_SAD = XMI_METRIC_SAD, M_SSD = XMI_METRIC_SSD, M_SATD_HM = XMI_METRIC_SATD_HM, M_SATD_X264 = XMI_METRIC_SATD_X264 };
+
+template <int T>
+__device__ __forceinline__ void hadamard_1d(int *v)
+{
+#pragma unroll
+    for (int len = 1; len < T; len <<= 1)
+#pragma unroll
+        for (int i = 0; i < T; i += 2 * len)
+#pragma unroll
+            for (int j = i; j < i + len; j++) {
+                const int a = v[j], b = v[j + len];
+                v[j] = a + b;
+                v[j + len] = a - b;
+            }
+}
+
+// value of one T x T tile (T = 4 or 8) at a/b with row stride n
+template <int T, int METRIC>
+__device__ __forceinline__ u32 tile_value(const uint8_t *a, const uint8_t *b, int n)
+{
+    int d[T][T];
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+        if (T == 8) {
+            const uint2 va = *reinterpret_cast<const uint2 *>(a + r * n), vb = *reinterpret_cast<const uint2 *>(b + r * n);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                d[r][c] = (int)((va.x >> (8 * c)) & 255) - (int)((vb.x >> (8 * c)) & 255);
+                d[r][c + 4] = (int)((va.y >> (8 * c)) & 255) - (int)((vb.y >> (8 * c)) & 255);
+            }
+        } else {
+            const u32 va = *reinterpret_cast<const u32 *>(a + r * n), vb = *reinterpret_cast<const u32 *>(b + r * n);
+#pragma unroll
+            for (int c = 0; c < 4; c++) d[r][c] = (int)((va >> (8 * c)) & 255) - (int)((vb >> (8 * c)) & 255);
+        }
+    }
+    u32 s = 0;
+    if (METRIC == M_SAD || METRIC == M_SSD) {
+#pragma unroll
+        for (int r = 0; r < T; r++)
+#pragma unroll
+            for (int c = 0; c < T; c++) s += METRIC == M_SAD ? (u32)abs(d[r][c]) : (u32)(d[r][c] * d[r][c]);
+        return s;
+    }
+#pragma unroll
+    for (int r = 0; r < T; r++) hadamard_1d<T>(d[r]);
+#pragma unroll
+    for (int c = 0; c < T; c++) {
+        int col[T];
+#pragma unroll
+        for (int r = 0; r < T; r++) col[r] = d[r][c];
+        hadamard_1d<T>(col);
+#pragma unroll
+        for (int r = 0; r < T; r++) s += (u32)abs(col[r]);
+    }
+    if (METRIC == M_SATD_HM) return T == 4 ? (s + 1) >> 1 : (s + 2) >> 2;  // each tile rounded on its own
+    return s;                                                            // x264 form: halved after the block sum
+}
+
+template <int T, int METRIC>
+__global__ void __launch_bounds__(256) metric_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int n, int count)
+{
+    const int tiles_per_row = n / T, tiles = tiles_per_row * tiles_per_row;   // tiles is a power of two <= 64
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long blk = gid / tiles;
+    const int tile = (int)(gid % tiles);
+    u32 v = 0;
+    if (blk < count) {
+        const size_t off = (size_t)blk * n * n + (size_t)(tile / tiles_per_row) * T * n + (size_t)(tile % tiles_per_row) * T;
+        v = tile_value<T, METRIC>(a + off, b + off, n);
+    }
+    for (int sh = 1; sh < tiles; sh <<= 1) v += (u32)__shfl_xor((int)v, sh);  // tiles of a block sit in consecutive lanes
+    if (blk < count && tile == 0) out[blk] = METRIC == M_SATD_X264 ? v >> 1 : v;
+}
+
+template <int T, int METRIC>
+int launch(const uint8_t *a, const uint8_t *b, u32 *out, int n, int count, hipStream_t st)
+{
+    const long long lanes = (long long)count * (n / T) * (n / T);
+    const unsigned blocks = (unsigned)((lanes + 255) / 256);
+    hipLaunchKernelGGL((metric_kernel<T, METRIC>), dim3(blocks), dim3(256), 0, st, a, b, out, n, count);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+}  // namespace
+
+extern "C" int xmi_block_metric_batch_dev(int metric, int n, int count, const uint8_t *d_a, const uint8_t *d_b,
+                                          uint32_t *d_out, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count >= 0, "xmi_block_metric_batch_dev: negative count");
+    XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32 || n == 64, "xmi_block_metric_batch_dev: block size %d not in {4,8,16,32,64}", n);
+    if (count == 0) return XMI_OK;
+    XMI_ARG(d_a && d_b && d_out, "xmi_block_metric_batch_dev: null argument");
+    XMI_ARG((((uintptr_t)d_a | (uintptr_t)d_b) & (n == 4 ? 3 : 7)) == 0, "xmi_block_metric_batch_dev: block arrays must be %d-byte aligned", n == 4 ? 4 : 8);
+    hipStream_t st = xmi::as_stream(stream);
+    if (metric == XMI_METRIC_SATD_TAB) {
+        // the table the encoder calls (src/pixel.cpp:529-542): x264 form for 4/8/16, HM 8x8 tiles for 32
+        XMI_ARG(n <= 32, "xmi_block_metric_batch_dev: xSatdN has no %dx%d entry", n, n);
+        metric = n == 32 ? XMI_METRIC_SATD_HM : XMI_METRIC_SATD_X264;
+    }
+    switch (metric) {
+    case XMI_METRIC_SAD: return n == 4 ? launch<4, M_SAD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SAD>(d_a, d_b, d_out, n, count, st);
+    case XMI_METRIC_SSD: return n == 4 ? launch<4, M_SSD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SSD>(d_a, d_b, d_out, n, count, st);
+    case XMI_METRIC_SATD_HM: return n == 4 ? launch<4, M_SATD_HM>(d_a, d_b, d_out, n, count, st) : launch<8, M_SATD_HM>(d_a, d_b, d_out, n, count, st);
+    case XMI_METRIC_SATD_X264:
+        XMI_ARG(n <= 16, "xmi_block_metric_batch_dev: the x264 SATD exists for 4, 8 and 16 only");
+        return launch<4, M_SATD_X264>(d_a, d_b, d_out, n, count, st);
+    default: xmi::set_error("xmi_block_metric_batch_dev: unknown metric %d", metric); return XMI_ERR_ARG;
+    }
+}

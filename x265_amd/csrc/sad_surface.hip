@@ -18,12 +18,14 @@
 //   The dx = +R column (one more than a multiple of 4) is produced by the EDGE instantiation.
 //
 // Output layout (chosen so that every store instruction of a wavefront writes one contiguous run):
-//   per (ctu, dy) a row of R/8 full tiles of 16 dx each, then one short tile holding dx = +R alone:
+//   main part, dx in [-R, R-1]: per (ctu, dy) a row of R/8 tiles of 16 consecutive dx (rows are
+//   multiples of 128 bytes, so every row starts on a cache line):
 //     sad8 : [ctu][dy][tile][c*16 + z][dx % 16]   c = (by8&1)*2 + (bx8&1), z = z-order of the parent 16x16
 //     sad16: [ctu][dy][tile][z][dx % 16]
 //     sad32: [ctu][dy][tile][q][dx % 16]          q = raster index of the 32x32 quadrant
-//     sad64: [ctu][dy][tile][dx % 16]             (row padded to a multiple of 4 elements)
-//   the short tile drops the [dx % 16] dimension. xmi_sad_surface_index() does this arithmetic.
+//     sad64: [ctu][dy][tile][dx % 16]
+//   edge part, dx = +R: appended after the main part of the same plane: [ctu][dy][block slot].
+//   xmi_sad_surface_index() does this arithmetic.
 #include "xmi_common.h"
 
 namespace {
@@ -40,15 +42,14 @@ struct SadParams {
     int wc;         // CTUs per frame row
     int seg_len;    // dy rows per workgroup (main) or per lane group (edge)
     int ctu_begin;
+    int nctu_total;  // CTUs in the frame: the edge part of every plane starts after nctu_total main blocks
 };
 
 constexpr int kCurLdsBytes = 16 * 16 * 16;  // [row in 16x16 block][z][16 bytes]
 
-// elements per (ctu, dy) row of each level's plane
-__host__ __device__ constexpr int row_elems(int R, int level)
-{
-    return level == 0 ? (R / 8) * 1024 + 64 : level == 1 ? (R / 8) * 256 + 16 : level == 2 ? (R / 8) * 64 + 4 : (R / 8) * 16 + 4;
-}
+// blocks per level, and elements per (ctu, dy) row of the main part of each level's plane
+__host__ __device__ constexpr int level_blocks(int level) { return level == 0 ? 64 : level == 1 ? 16 : level == 2 ? 4 : 1; }
+__host__ __device__ constexpr int row_elems(int R, int level) { return (R / 8) * level_blocks(level) * 16; }
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
@@ -87,12 +88,24 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
         reinterpret_cast<u32 *>(cur_lds)[(r16 * 16 + z) * 4 + (cd & 3)] = v;
     }
     // ---- stage reference window rows [cy0 - R + seg_base, +valid_rows) x [cx0 + col_origin, +4*wb_dw) ----
+    // flat dword index so that all lanes carry loads; 8 independent loads are in flight per thread
     {
         const uint8_t *src0 = p.ref + (ptrdiff_t)(cy0 - R + seg_base) * p.ref_stride + cx0 + col_origin;
-        for (int row = wave; row < valid_rows; row += nwaves) {
-            const u32 *src = reinterpret_cast<const u32 *>(src0 + (ptrdiff_t)row * p.ref_stride);
-            u32 *dst = reinterpret_cast<u32 *>(ref_lds + row * rls);
-            for (int c = lane; c < wb_dw; c += 64) dst[c] = src[c];
+        const int total = valid_rows * wb_dw;
+        for (int base = tid; base < total; base += 8 * (int)blockDim.x) {
+            u32 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int idx = base + k * (int)blockDim.x;
+                const int row = idx / wb_dw, col = idx - row * wb_dw;
+                v[k] = idx < total ? *reinterpret_cast<const u32 *>(src0 + (ptrdiff_t)row * p.ref_stride + col * 4) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int idx = base + k * (int)blockDim.x;
+                const int row = idx / wb_dw, col = idx - row * wb_dw;
+                if (idx < total) *reinterpret_cast<u32 *>(ref_lds + row * rls + col * 4) = v[k];
+            }
         }
     }
     __syncthreads();
@@ -107,18 +120,22 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
 
     const unsigned char *ref_lane = ref_lds + (by16 * 16 + dy_lane0) * rls + (bx16 * 4 + g) * 4;
 
-    // output offsets (elements) inside this CTU's rows; a full tile is [blk][16 dx], the short tile [blk]
-    constexpr int ROW8 = row_elems(R, 0), ROW16 = row_elems(R, 1), ROW32 = row_elems(R, 2), ROW64 = row_elems(R, 3);
-    uint16_t *o8 = p.sad8 + (size_t)ctu * nmv * ROW8;
-    uint16_t *o16 = p.sad16 + (size_t)ctu * nmv * ROW16;
-    u32 *o32 = p.sad32 + (size_t)ctu * nmv * ROW32;
-    u32 *o64 = p.sad64 + (size_t)ctu * nmv * ROW64;
+    // output offsets (elements): main rows are [tile][slot][16 dx]; the edge rows [slot] follow all main rows
+    constexpr int ROW8 = EDGE ? 64 : row_elems(R, 0), ROW16 = EDGE ? 16 : row_elems(R, 1);
+    constexpr int ROW32 = EDGE ? 4 : row_elems(R, 2), ROW64 = EDGE ? 1 : row_elems(R, 3);
+    const size_t rows_before = (EDGE ? (size_t)p.nctu_total * nmv : 0);
+    uint16_t *o8 = p.sad8 + rows_before * row_elems(R, 0) + (size_t)ctu * nmv * ROW8;
+    uint16_t *o16 = p.sad16 + rows_before * row_elems(R, 1) + (size_t)ctu * nmv * ROW16;
+    u32 *o32 = p.sad32 + rows_before * row_elems(R, 2) + (size_t)ctu * nmv * ROW32;
+    u32 *o64 = p.sad64 + rows_before * row_elems(R, 3) + (size_t)ctu * nmv * ROW64;
     const int q = (by16 >> 1) * 2 + (bx16 >> 1);
-    const u32 off8 = EDGE ? (R / 8) * 1024 + z : wave * 1024 + z * 16 + gl * 4;   // child c adds c*16 (*16 in a full tile)
-    const u32 off16 = EDGE ? (R / 8) * 256 + z : wave * 256 + z * 16 + gl * 4;
-    const u32 off32 = EDGE ? (R / 8) * 64 + q : wave * 64 + q * 16 + gl * 4;
-    const u32 off64 = EDGE ? (R / 8) * 16 : wave * 16 + gl * 4;
-    constexpr u32 CH = EDGE ? 16 : 256;                                           // element step between children
+    const u32 off8 = EDGE ? z : wave * 1024 + z * 16 + gl * 4;       // child c adds c*16 slots
+    const u32 off16 = EDGE ? z : wave * 256 + z * 16 + gl * 4;
+    // 32x32 / 64x64: after the reductions every lane of a quadrant (of the wavefront) holds the same 4 sums;
+    // lane b = z&3 writes the b-th one, so all 64 (16) lanes store one dword each into one contiguous run
+    const u32 off32 = EDGE ? q : wave * 64 + q * 16 + gl * 4 + (z & 3);
+    const u32 off64 = EDGE ? 0 : wave * 16 + gl * 4 + (z & 3);
+    constexpr u32 CH = EDGE ? 16 : 256;                              // element step between children
 
     u64 acc[4][8];
 #pragma unroll
@@ -135,6 +152,7 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
             u32 cur_off = (u32)z * 16u;
             asm volatile("" : "+v"(cur_off));
             const unsigned char *cl = cur_lds + cur_off;
+#ifndef XMI_EXP_NOCOMPUTE
 #pragma unroll
             for (int cy = 0; cy < 2; cy++) {
                 const u32 *rr = reinterpret_cast<const u32 *>(ref_lane + (cy * 8 + s) * rls);
@@ -158,6 +176,7 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
                     }
                 }
             }
+#endif
             // Pin every accumulator here: without it the compiler sinks this step's SADs into later
             // steps (only one accumulator per child is consumed now) and keeps whole rows live.
 #pragma unroll
@@ -184,16 +203,26 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
             t2 += (u32)__shfl_xor((int)t2, 32);
             t3 += (u32)__shfl_xor((int)t3, 32);
 
+#ifdef XMI_EXP_NOSTORE
+            if (dyl >= 0 && dyl < ndy_lane && dyi < nmv && v16 == 0x1234567812345678ull && t0 == 77u) {
+#else
             if (dyl >= 0 && dyl < ndy_lane && dyi < nmv) {
+#endif
                 if (!EDGE) {
+#ifndef XMI_EXP_STORES
+#define XMI_EXP_STORES 15
+#endif
                     u64 *r8 = reinterpret_cast<u64 *>(o8 + (u32)dyi * ROW8 + off8);
-                    r8[0] = v0;
-                    r8[CH / 4] = v1;
-                    r8[2 * CH / 4] = v2;
-                    r8[3 * CH / 4] = v3;
-                    *reinterpret_cast<u64 *>(o16 + (u32)dyi * ROW16 + off16) = v16;
-                    if ((z & 3) == 0) *reinterpret_cast<uint4 *>(o32 + (u32)dyi * ROW32 + off32) = make_uint4(x0, x1, x2, x3);
-                    if (z == 0) *reinterpret_cast<uint4 *>(o64 + (u32)dyi * ROW64 + off64) = make_uint4(t0, t1, t2, t3);
+                    if (XMI_EXP_STORES & 1) {
+                        r8[0] = v0;
+                        r8[CH / 4] = v1;
+                        r8[2 * CH / 4] = v2;
+                        r8[3 * CH / 4] = v3;
+                    }
+                    if (XMI_EXP_STORES & 2) *reinterpret_cast<u64 *>(o16 + (u32)dyi * ROW16 + off16) = v16;
+                    const int b = z & 3;
+                    if (XMI_EXP_STORES & 4) o32[(u32)dyi * ROW32 + off32] = b == 0 ? x0 : b == 1 ? x1 : b == 2 ? x2 : x3;
+                    if ((XMI_EXP_STORES & 8) && z < 4) o64[(u32)dyi * ROW64 + off64] = b == 0 ? t0 : b == 1 ? t1 : b == 2 ? t2 : t3;
                 } else {
                     uint16_t *r8 = o8 + (u32)dyi * ROW8 + off8;
                     r8[0] = (uint16_t)v0;
@@ -255,7 +284,7 @@ size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level)
 {
     if (!g || level < 0 || level > 3 || !range_ok(g->range)) return 0;
     const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
-    return nctu * (size_t)(2 * g->range + 1) * (size_t)row_elems(g->range, level);
+    return nctu * (size_t)(2 * g->range + 1) * (size_t)(row_elems(g->range, level) + level_blocks(level));
 }
 
 size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk, int dy, int dx)
@@ -273,10 +302,11 @@ size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk,
     } else {
         slot = level == 2 ? blk : 0;
     }
-    static const int nblk[4] = { 64, 16, 4, 1 };
-    const size_t row = ((size_t)ctu * (2 * R + 1) + dyi) * (size_t)row_elems(R, level);
-    if (dxi == 2 * R) return row + (size_t)(R / 8) * nblk[level] * 16 + slot;
-    return row + ((size_t)(dxi >> 4) * nblk[level] + slot) * 16 + (dxi & 15);
+    const size_t nmv = (size_t)(2 * R + 1), nb = (size_t)level_blocks(level);
+    const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
+    const size_t row = (size_t)ctu * nmv + (size_t)dyi;
+    if (dxi == 2 * R) return nctu * nmv * (size_t)row_elems(R, level) + row * nb + (size_t)slot;
+    return row * (size_t)row_elems(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
 }
 
 int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8_t *d_ref_origin,
@@ -312,6 +342,7 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     p.ref_stride = g->ref_stride;
     p.wc = g->width / 64;
     p.ctu_begin = ctu_begin;
+    p.nctu_total = nctu;
 
     hipStream_t st = xmi::as_stream(stream);
     const int n = ctu_end - ctu_begin;
@@ -362,7 +393,6 @@ int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *re
     const uint8_t *ref_base = ref_origin - (ptrdiff_t)pad * g->ref_stride - pad;
     XMI_HIP(hipMemcpy(d_cur, cur, cur_bytes, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy(d_ref, ref_base, ref_bytes, hipMemcpyHostToDevice));
-    XMI_HIP(hipMemset(d64, 0, e64 * 4));  // the 3 padding elements per sad64 row are never written: define them
     rc = xmi_sad_surface_dev(g, d_cur, d_ref + (size_t)pad * g->ref_stride + pad, d8, d16, d32, d64, 0,
                              (g->width / 64) * (g->height / 64), nullptr);
     if (rc != XMI_OK) return rc;

@@ -1,0 +1,261 @@
+// Batched transform-unit chain for gfx950: residual -> forward DCT/DST -> quant -> dequant -> inverse -> recon.
+//
+// Restates, per TU, the reference's xSubDctQuantRec (src/encode.cpp:3005-3021) and its parts xSubDct
+// (src/pixel.cpp:3446, C spec :1415/:1567/:1826/:2300/:3149), xQuant (:1060), xDeQuant (:1249), xIDctAdd (:5938,
+// C spec :3584/:3725/:4071/:4629/:5573). All arithmetic is integer and bit-exact: 32-bit accumulation of
+// int16 x int16 products, the reference's shifts and rounding, int16 clipping after each inverse stage.
+//
+// Every 1-D stage has the same shape  out[a][b] = f((sum_c Mat[a][c] * in[b][c] + rnd) >> shift)  when
+// the forward stages use the core matrix M and the inverse stages its transpose (the buffers are kept
+// transposed between stages exactly like the reference's temporaries), so one routine serves all four.
+// The inner product runs on v_dot2c_i32_i16 over LDS-resident int16 rows with an odd dword pitch.
+#include "xmi_common.h"
+
+namespace {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// integers the HEVC core transform assigns to 64*sqrt(2)*cos(m*pi/64), m = 0..32 (m = 0 is the DC row value)
+__constant__ int8_t k_cos64[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                    61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0 };
+__constant__ int8_t k_dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+__constant__ int k_quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };  // src/table.cpp:150
+__constant__ int k_inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };                // src/table.cpp:155
+
+__device__ __forceinline__ int dct_coef(int n, int k, int j)
+{
+    if (k == 0) return 64;
+    const int m = (k * (32 / n) * (2 * j + 1)) & 127;
+    if (m <= 32) return k_cos64[m];
+    if (m <= 64) return -k_cos64[64 - m];
+    if (m <= 96) return -k_cos64[m - 64];
+    return k_cos64[128 - m];
+}
+
+__device__ __forceinline__ int clip16(int v) { return min(32767, max(-32768, v)); }
+
+enum { MODE_CHAIN = 0, MODE_SUBDCT = 1, MODE_QUANT = 2, MODE_DEQUANT = 3, MODE_IDCT = 4 };
+
+struct TuParams {
+    const uint8_t *pix, *pred, *qp, *flags;
+    const int16_t *coef_in;   // QUANT: coefficients, DEQUANT: levels, IDCT: coefficients
+    int16_t *out16;           // CHAIN/QUANT: levels, SUBDCT/DEQUANT: coefficients
+    uint8_t *rec;
+    uint32_t *sum;
+    int count;
+};
+
+template <int N>
+struct Cfg {
+    static constexpr int LD = N + 2;                                   // int16 elements per LDS row (odd dword pitch)
+    static constexpr int TPT = N * N < 256 ? N * N : 256;              // threads per TU
+    static constexpr int TUS = 256 / TPT;                              // TUs per 256-thread workgroup
+    static constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+};
+
+// out[a][b] = f((sum_c mat[a][c] * in[b][c] + rnd) >> shift); all buffers [N][LD] int16 in LDS
+template <int N, bool CLIP>
+__device__ __forceinline__ void stage(const int16_t *mat, const int16_t *in, int16_t *out, int shift, int t)
+{
+    constexpr int LD = Cfg<N>::LD, TPT = Cfg<N>::TPT;
+    const int rnd = 1 << (shift - 1);
+#pragma unroll
+    for (int e = t; e < N * N; e += TPT) {
+        const int a = e / N, b = e % N;
+        const s16x2 *mr = reinterpret_cast<const s16x2 *>(mat + a * LD);
+        const s16x2 *ir = reinterpret_cast<const s16x2 *>(in + b * LD);
+        int acc = 0;
+#pragma unroll
+        for (int c = 0; c < N / 2; c++) acc = __builtin_amdgcn_sdot2(mr[c], ir[c], acc, false);
+        const int v = (acc + rnd) >> shift;
+        out[a * LD + b] = (int16_t)(CLIP ? clip16(v) : v);
+    }
+}
+
+template <int N, int MODE>
+__global__ void __launch_bounds__(256) tu_kernel(const TuParams p)
+{
+    constexpr int LD = Cfg<N>::LD, TPT = Cfg<N>::TPT, TUS = Cfg<N>::TUS, LG = Cfg<N>::LOG2;
+    __shared__ __align__(16) int16_t s_mat[2][2][N * LD];   // [dct|dst][M|Mt]
+    __shared__ __align__(16) int16_t s_a[TUS][N * LD];
+    __shared__ __align__(16) int16_t s_b[TUS][N * LD];
+    __shared__ uint32_t s_sum[TUS];
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPT, t = tid % TPT;
+    const int tu = blockIdx.x * TUS + slot;
+    const bool live = tu < p.count;
+
+    // core matrices (and the 4x4 DST) and their transposes
+    for (int e = tid; e < N * N; e += 256) {
+        const int k = e / N, j = e % N;
+        const int16_t c = (int16_t)dct_coef(N, k, j);
+        s_mat[0][0][k * LD + j] = c;
+        s_mat[0][1][j * LD + k] = c;
+        if (N == 4) {
+            const int16_t d = k_dst4[k * 4 + j];
+            s_mat[1][0][k * LD + j] = d;
+            s_mat[1][1][j * LD + k] = d;
+        }
+    }
+    if (tid < TUS) s_sum[tid] = 0;
+
+    const int flags = live && p.flags ? p.flags[tu] : 0;
+    const int qp = live && p.qp ? p.qp[tu] : 0;
+    const int use_dst = (N == 4) && (flags & 2);
+    const int16_t *M = s_mat[use_dst][0], *Mt = s_mat[use_dst][1];
+    int16_t *A = s_a[slot], *B = s_b[slot];
+    const size_t base = (size_t)tu * N * N;
+
+    if (MODE == MODE_CHAIN || MODE == MODE_SUBDCT) {
+        if (live)
+            for (int e = t; e < N * N; e += TPT) A[(e / N) * LD + e % N] = (int16_t)((int)p.pix[base + e] - (int)p.pred[base + e]);
+        __syncthreads();
+        if (live) stage<N, false>(M, A, B, LG - 1, t);   // rows of the residual -> columns of the temporary
+        __syncthreads();
+        if (live) stage<N, false>(M, B, A, LG + 6, t);   // A[k][i] = coefficient (row k = vertical frequency)
+        __syncthreads();
+        if (MODE == MODE_SUBDCT) {
+            if (live)
+                for (int e = t; e < N * N; e += TPT) p.out16[base + e] = A[(e / N) * LD + e % N];
+            return;
+        }
+    }
+    if (MODE == MODE_QUANT || MODE == MODE_DEQUANT || MODE == MODE_IDCT) {
+        if (live)
+            for (int e = t; e < N * N; e += TPT) A[(e / N) * LD + e % N] = p.coef_in[base + e];
+        __syncthreads();
+    }
+    if (MODE == MODE_CHAIN || MODE == MODE_QUANT || MODE == MODE_DEQUANT) {
+        // xQuant: level = (|c| * Q + rnd) >> qbits, sign restored, clipped to int16; sum of levels before sign/clip.
+        // xDeQuant: (level * (IQ << qp/6) + (1 << (shift-1))) >> shift, clipped to int16.
+        const int qbits = 14 + qp / 6 + (15 - 8 - LG);
+        const int q = k_quant_scales[qp % 6];
+        const int qrnd = ((flags & 1) ? 171 : 85) << (qbits - 9);
+        const int dshift = 20 - 14 - (15 - 8 - LG);
+        const int dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
+        uint32_t local = 0;
+        if (live)
+            for (int e = t; e < N * N; e += TPT) {
+                const int k = e / N, i = e % N;
+                int level = A[k * LD + i];
+                if (MODE != MODE_DEQUANT) {
+                    const int c = level;
+                    const int mag = (abs(c) * q + qrnd) >> qbits;
+                    local += (uint32_t)mag;
+                    level = clip16(c < 0 ? -mag : mag);
+                    p.out16[base + e] = (int16_t)level;
+                }
+                if (MODE != MODE_QUANT) {
+                    const int d = clip16((level * dscale + (1 << (dshift - 1))) >> dshift);
+                    if (MODE == MODE_DEQUANT) p.out16[base + e] = (int16_t)d;
+                    else B[i * LD + k] = (int16_t)d;   // transposed for the inverse stages
+                }
+            }
+        if (MODE != MODE_DEQUANT) {
+            if (live && local) atomicAdd(&s_sum[slot], local);
+            __syncthreads();
+            if (live && t == 0) p.sum[tu] = s_sum[slot];
+            if (MODE == MODE_QUANT) return;
+        } else {
+            return;
+        }
+        __syncthreads();
+    }
+    if (MODE == MODE_IDCT) {
+        // transpose the coefficient block into B for the inverse stages
+        if (live)
+            for (int e = t; e < N * N; e += TPT) B[(e % N) * LD + e / N] = A[(e / N) * LD + e % N];
+        __syncthreads();
+    }
+    // inverse: A[j][i] = clip16(sum_k M[k][j] * coef[k][i]) ; B[j][i] = clip16(sum_k M[k][j] * A'[k][i]) = residual[i][j]
+    if (live) stage<N, true>(Mt, B, A, 7, t);
+    __syncthreads();
+    if (live) stage<N, true>(Mt, A, B, 12, t);
+    __syncthreads();
+    if (live)
+        for (int e = t; e < N * N; e += TPT) {
+            const int i = e / N, j = e % N;
+            const int v = (int)B[j * LD + i] + (int)p.pred[base + e];
+            p.rec[base + e] = (uint8_t)min(255, max(0, v));
+        }
+}
+
+template <int MODE>
+int launch(int n, const TuParams &p, hipStream_t st)
+{
+    if (p.count == 0) return XMI_OK;
+    switch (n) {
+    case 4: hipLaunchKernelGGL((tu_kernel<4, MODE>), dim3((p.count + Cfg<4>::TUS - 1) / Cfg<4>::TUS), dim3(256), 0, st, p); break;
+    case 8: hipLaunchKernelGGL((tu_kernel<8, MODE>), dim3((p.count + Cfg<8>::TUS - 1) / Cfg<8>::TUS), dim3(256), 0, st, p); break;
+    case 16: hipLaunchKernelGGL((tu_kernel<16, MODE>), dim3(p.count), dim3(256), 0, st, p); break;
+    case 32: hipLaunchKernelGGL((tu_kernel<32, MODE>), dim3(p.count), dim3(256), 0, st, p); break;
+    default: xmi::set_error("transform size %d not in {4,8,16,32}", n); return XMI_ERR_ARG;
+    }
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+int check_common(const char *who, int n, int count)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32, "%s: transform size %d not in {4,8,16,32}", who, n);
+    XMI_ARG(count >= 0, "%s: negative count", who);
+    return XMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t *d_pred, const uint8_t *d_qp,
+                           const uint8_t *d_flags, int16_t *d_level, uint8_t *d_rec, uint32_t *d_sum, void *stream)
+{
+    int rc = check_common("xmi_tu_chain_batch_dev", n, count);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count == 0 || (d_pix && d_pred && d_qp && d_flags && d_level && d_rec && d_sum), "xmi_tu_chain_batch_dev: null argument");
+    TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
+    return launch<MODE_CHAIN>(n, p, xmi::as_stream(stream));
+}
+
+int xmi_sub_dct_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t *d_pred, const uint8_t *d_flags,
+                          int16_t *d_coef, void *stream)
+{
+    int rc = check_common("xmi_sub_dct_batch_dev", n, count);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count == 0 || (d_pix && d_pred && d_coef), "xmi_sub_dct_batch_dev: null argument");
+    TuParams p = { d_pix, d_pred, nullptr, d_flags, nullptr, d_coef, nullptr, nullptr, count };
+    return launch<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
+}
+
+int xmi_quant_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_qp, const uint8_t *d_flags,
+                        int16_t *d_level, uint32_t *d_sum, void *stream)
+{
+    int rc = check_common("xmi_quant_batch_dev", n, count);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count == 0 || (d_coef && d_qp && d_level && d_sum), "xmi_quant_batch_dev: null argument");
+    TuParams p = { nullptr, nullptr, d_qp, d_flags, d_coef, d_level, nullptr, d_sum, count };
+    return launch<MODE_QUANT>(n, p, xmi::as_stream(stream));
+}
+
+int xmi_dequant_batch_dev(int n, int count, const int16_t *d_level, const uint8_t *d_qp, int16_t *d_coef, void *stream)
+{
+    int rc = check_common("xmi_dequant_batch_dev", n, count);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count == 0 || (d_level && d_qp && d_coef), "xmi_dequant_batch_dev: null argument");
+    TuParams p = { nullptr, nullptr, d_qp, nullptr, d_level, d_coef, nullptr, nullptr, count };
+    return launch<MODE_DEQUANT>(n, p, xmi::as_stream(stream));
+}
+
+int xmi_idct_add_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_pred, const uint8_t *d_flags,
+                           uint8_t *d_rec, void *stream)
+{
+    int rc = check_common("xmi_idct_add_batch_dev", n, count);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(count == 0 || (d_coef && d_pred && d_rec), "xmi_idct_add_batch_dev: null argument");
+    TuParams p = { nullptr, d_pred, nullptr, d_flags, d_coef, nullptr, d_rec, nullptr, count };
+    return launch<MODE_IDCT>(n, p, xmi::as_stream(stream));
+}
+
+}  // extern "C"

@@ -5,8 +5,12 @@ NBLK = (64, 16, 4, 1)
 
 
 def row_elems(rng, level):
-    t = rng // 8
-    return (t * 1024 + 64, t * 256 + 16, t * 64 + 4, t * 16 + 4)[level]
+    """elements per (ctu, dy) row of the main part (dx < +R) of a level's plane"""
+    return (rng // 8) * NBLK[level] * 16
+
+
+def plane_elems(nctu, rng, level):
+    return nctu * (2 * rng + 1) * (row_elems(rng, level) + NBLK[level])
 
 
 def _z16(by16, bx16):
@@ -25,8 +29,9 @@ def slot_of_block(level):
 def untile(plane, nctu, rng, level):
     """tiled plane (flat array) -> natural [ctu][blk (raster)][dy+R][dx+R] array"""
     nmv, t, nb = 2 * rng + 1, rng // 8, NBLK[level]
-    rows = np.asarray(plane).reshape(nctu, nmv, row_elems(rng, level))
-    full = rows[:, :, :t * nb * 16].reshape(nctu, nmv, t, nb, 16).transpose(0, 3, 1, 2, 4).reshape(nctu, nb, nmv, 2 * rng)
-    last = rows[:, :, t * nb * 16:t * nb * 16 + nb].transpose(0, 2, 1)[..., None]
+    plane = np.asarray(plane).reshape(-1)
+    nmain = nctu * nmv * t * nb * 16
+    full = plane[:nmain].reshape(nctu, nmv, t, nb, 16).transpose(0, 3, 1, 2, 4).reshape(nctu, nb, nmv, 2 * rng)
+    last = plane[nmain:nmain + nctu * nmv * nb].reshape(nctu, nmv, nb).transpose(0, 2, 1)[..., None]
     nat = np.concatenate([full, last], axis=3)
     return np.ascontiguousarray(nat[:, slot_of_block(level)])
