@@ -152,14 +152,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # average duration of the dominant kernel pair (main + edge column), HIP events on the launch stream
-    kern_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+    kern_ms_raw = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    kern_ms = sorted(kern_ms_raw)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    # a light end-of-segment exchange: per-rank statistics record (what a rate-control gather would carry)
-    rec = torch.tensor([rank, args.steps, float(s64[R * layout.row_elems(R, 3) + R].item()), kern_avg_ms], dtype=torch.float64, device=dev)
-    if world > 1:
-        recs = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(recs, rec)
+    # end-of-segment exchange (outside the timed region): one statistics record per processed frame, gathered
+    # on every rank - the only collective of the path (RCCL when world > 1)
+    from x265_amd import segments
+    fr = np.arange(args.steps) + rank * args.steps
+    rec = segments.make_records(fr, np.ones(args.steps), np.full(args.steps, 32), np.zeros(args.steps),
+                                np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
+    allrec = segments.gather_records(rec, device=dev)
+    assert allrec.shape[0] == args.steps * world
 
     if rank == 0:
         abytes, cands = algorithmic_bytes(w, h, R, PAD)

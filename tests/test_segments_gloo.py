@@ -1,0 +1,68 @@
+"""CPU: the N>1 host path (GOP-segment partition + record/segment gather) with world_size 2 over gloo."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from x265_amd import segments
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_covers_all_frames_once():
+    for n, world, gop in ((64, 8, None), (128, 8, 16), (63, 4, 16), (5, 8, None), (100, 3, 8)):
+        spans = [segments.partition_frames(n, world, r, gop) for r in range(world)]
+        seen = []
+        for b, e in spans:
+            assert 0 <= b <= e <= n
+            if gop:
+                assert b % gop == 0 or b == n
+            seen += list(range(b, e))
+        assert seen == list(range(n))
+
+
+def test_single_process_gather_is_identity():
+    rec = segments.make_records([2, 0, 1], [1, 2, 1], [32, 32, 32], [10.0, 9.0, 10.0], [5, 50, 5], [100, 900, 120])
+    out = segments.gather_records(rec)
+    assert list(out[:, 0]) == [0, 1, 2]
+    assert segments.gather_segments(b"abc") == [b"abc"]
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, os.environ["XROOT"])
+    import numpy as np, torch.distributed as dist
+    from x265_amd import segments
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    b, e = segments.partition_frames(21, world, rank, gop=8)
+    fr = np.arange(b, e)
+    rec = segments.make_records(fr, np.where(fr % 8 == 0, 2, 1), np.full(len(fr), 32), fr * 0.5, fr % 8 == 0, 1000 + fr)
+    allrec = segments.gather_records(rec)
+    assert allrec.shape == (21, 6) and list(allrec[:, 0]) == list(range(21)), allrec[:, 0]
+    assert np.allclose(allrec[:, 5], 1000 + np.arange(21))
+    segs = segments.gather_segments(bytes([rank + 1]) * (3 + 4 * rank))
+    assert segs == [bytes([1]) * 3, bytes([2]) * 7], segs
+    empty = segments.gather_segments(b"" if rank == 0 else b"xy")
+    assert empty == [b"", b"xy"]
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_gather_world2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, XROOT=ROOT, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("ok") == 2

@@ -6,16 +6,16 @@
 // src/pixel.cpp:578-696, 833-844). SAD is an exact integer sum, so any summation order is bit-exact.
 //
 // Mapping (one workgroup = one CTU x one band of dy rows, R/8 wavefronts):
-//   lane = z*4 + gl            z  = 16x16 block of the CTU in z-order (quadrant-major)
+//   lane = q*16 + gl*4 + b     z = q*4 + b = 16x16 block of the CTU in z-order (q = quadrant, b = block in it)
 //                              gl = one of 4 dx-groups owned by the wavefront; a dx-group is 4
 //                                   consecutive dx, produced at once by v_qsad_pk_u16_u8
 //   The lane walks down the reference window one row per step. A reference row r meets the 8 rows y
 //   of each 8x8 child, contributing to dy = r - y: a ring of 8 packed-u16 accumulators per child
 //   holds the 8 dy values in flight; one completes per step and is written out. Reference and
 //   current pixels are staged once in LDS; nothing is re-read from HBM.
-//   16x16 = sum of the lane's 4 children (still packed u16, max 65280); 32x32 = DPP row-rotate sum
-//   over the 4 lanes of a quadrant; 64x64 = cross-row shuffle sum over the 4 quadrants.
-//   The dx = +R column (one more than a multiple of 4) is produced by the EDGE instantiation.
+//   16x16 = sum of the lane's 4 children (still packed u16, max 65280); 32x32 = DPP quad reduce-scatter
+//   over the 4 lanes of a quadrant; 64x64 = swizzle/permute sum over the 4 quadrants.
+//   The dx = +R column (one more than a multiple of 4) is produced by a short v_sad_u8 pass at the end.
 //
 // Output layout (chosen so that every store instruction of a wavefront writes one contiguous run):
 //   main part, dx in [-R, R-1]: per (ctu, dy) a row of R/8 tiles of 16 consecutive dx (rows are
@@ -40,7 +40,7 @@ struct SadParams {
     u32 *sad32, *sad64;
     int cur_stride, ref_stride;
     int wc;         // CTUs per frame row
-    int seg_len;    // dy rows per workgroup (main) or per lane group (edge)
+    int seg_len;    // dy rows per workgroup (band height)
     int ctu_begin;
     int nctu_total;  // CTUs in the frame: the edge part of every plane starts after nctu_total main blocks
 };
@@ -54,55 +54,70 @@ __host__ __device__ constexpr int row_elems(int R, int level) { return (R / 8) *
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
 template <int CTRL>
-__device__ __forceinline__ u32 dpp_add(u32 x)
+__device__ __forceinline__ u32 dpp_mov(u32 x)
 {
-    return x + (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E;   // quad_perm [1,0,3,2] and [2,3,0,1]
+constexpr int kSwizzleXor16 = (16 << 10) | 0x1F;      // ds_swizzle bit mode: lane ^ 16 inside each half-wave
+
+// Sum a packed pair of u16x2 registers (lo = dx 0,1; hi = dx 2,3) over the 4 lanes of a quad so that
+// lane b (= lane & 3) ends up with the total for dx index b (a reduce-scatter: 8 VALU ops).
+__device__ __forceinline__ u32 quad_reduce_scatter(u32 lo, u32 hi, int b)
+{
+    const bool b1 = b & 2, b0 = b & 1;
+    const u32 keep = b1 ? hi : lo, send = b1 ? lo : hi;
+    const u32 got = dpp_mov<kQuadXor2>(send);
+    const u32 ya = (keep & 0xffffu) + (got & 0xffffu), yb = (keep >> 16) + (got >> 16);
+    const u32 keep2 = b0 ? yb : ya, send2 = b0 ? ya : yb;
+    return keep2 + dpp_mov<kQuadXor1>(send2);
 }
 
-template <int R, bool EDGE>
-__global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 4)) sad_surface_kernel(const SadParams p)
+// Workgroup = one CTU x one band of dy rows; R/8 wavefronts.
+// lane = q*16 + gl*4 + b: q = 32x32 quadrant (raster), b = 16x16 block inside it (raster), gl = dx group of the wavefront.
+template <int R>
+__global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *cur_lds = lds;
     unsigned char *ref_lds = lds + kCurLdsBytes;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int nwaves = R / 8;
     const int ctu = p.ctu_begin + blockIdx.x;
     const int cx0 = (ctu % p.wc) * 64, cy0 = (ctu / p.wc) * 64;
     constexpr int nmv = 2 * R + 1;
 
-    // window geometry
-    const int seg_base = EDGE ? 0 : (int)blockIdx.y * p.seg_len;      // first dy index of this workgroup
-    const int ndy_wg = EDGE ? nmv : min(p.seg_len, nmv - seg_base);   // dy rows staged for the workgroup
-    const int valid_rows = ndy_wg + 63;
-    constexpr int wb_dw = EDGE ? 17 : (R / 2 + 16);                   // window width in dwords
-    constexpr int rls = (wb_dw | 1) * 4;                                  // odd dword pitch: no bank conflicts
-    constexpr int col_origin = EDGE ? R : -R;
+    // window geometry: rows [dy band] + 63, columns [-R, R+67] (the last 4 bytes serve the dx = +R column)
+    const int seg_base = (int)blockIdx.y * p.seg_len;          // first dy index of this workgroup
+    const int ndy = min(p.seg_len, nmv - seg_base);            // dy rows of this workgroup
+    const int valid_rows = ndy + 63;
+    constexpr int wb_dw = R / 2 + 17;                          // window width in dwords (odd: conflict-free pitch)
+    constexpr int rls = wb_dw * 4;
 
-    // ---- stage current CTU: cur_lds[(r16*16 + z)*16 + byte] ----
-    for (int idx = tid; idx < 1024; idx += blockDim.x) {
+    // ---- stage current CTU: cur_lds[(r16*16 + z)*16 + byte], z = q*4 + b ----
+    for (int idx = tid; idx < 1024; idx += 8 * R) {
         const int row = idx >> 4, cd = idx & 15;
         const int bx16 = cd >> 2, by16 = row >> 4, r16 = row & 15;
-        const int z = ((((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1)));
+        const int zz = ((((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1)));
         const u32 v = *reinterpret_cast<const u32 *>(p.cur + (size_t)(cy0 + row) * p.cur_stride + cx0 + cd * 4);
-        reinterpret_cast<u32 *>(cur_lds)[(r16 * 16 + z) * 4 + (cd & 3)] = v;
+        reinterpret_cast<u32 *>(cur_lds)[(r16 * 16 + zz) * 4 + (cd & 3)] = v;
     }
-    // ---- stage reference window rows [cy0 - R + seg_base, +valid_rows) x [cx0 + col_origin, +4*wb_dw) ----
-    // flat dword index so that all lanes carry loads; 8 independent loads are in flight per thread
+    // ---- stage the reference window; flat dword index, 8 independent loads in flight per thread ----
     {
-        const uint8_t *src0 = p.ref + (ptrdiff_t)(cy0 - R + seg_base) * p.ref_stride + cx0 + col_origin;
+        const uint8_t *src0 = p.ref + (ptrdiff_t)(cy0 - R + seg_base) * p.ref_stride + cx0 - R;
         const int total = valid_rows * wb_dw;
-        for (int base = tid; base < total; base += 8 * (int)blockDim.x) {
+        for (int base = tid; base < total; base += 8 * (8 * R)) {
             u32 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int idx = base + k * (int)blockDim.x;
+                const int idx = base + k * (8 * R);
                 const int row = idx / wb_dw, col = idx - row * wb_dw;
                 v[k] = idx < total ? *reinterpret_cast<const u32 *>(src0 + (ptrdiff_t)row * p.ref_stride + col * 4) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int idx = base + k * (int)blockDim.x;
+                const int idx = base + k * (8 * R);
                 const int row = idx / wb_dw, col = idx - row * wb_dw;
                 if (idx < total) *reinterpret_cast<u32 *>(ref_lds + row * rls + col * 4) = v[k];
             }
@@ -111,31 +126,25 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
     __syncthreads();
 
     // ---- per-lane geometry ----
-    const int z = lane >> 2, gl = lane & 3;
-    const int bx16 = ((z >> 2) & 1) * 2 + (z & 1), by16 = (z >> 3) * 2 + ((z >> 1) & 1);
-    const int g = EDGE ? 0 : wave * 4 + gl;               // dx group (main); edge reads at window column 0
-    const int dy_lane0 = EDGE ? gl * p.seg_len : 0;       // first dy row (window-relative) of this lane
-    const int ndy_lane = EDGE ? p.seg_len : ndy_wg;
-    const int nsteps = (ndy_lane + 7 + 7) & ~7;
+    const int b = lane & 3, gl = (lane >> 2) & 3, q = lane >> 4;
+    const int z = q * 4 + b;
+    const int bx16 = (q & 1) * 2 + (b & 1), by16 = (q >> 1) * 2 + (b >> 1);
+    const int g = wave * 4 + gl;                              // dx group: dx = -R + 4g .. +3
+    const int nsteps = (ndy + 7 + 7) & ~7;
+    const unsigned char *ref_lane = ref_lds + (by16 * 16) * rls + (bx16 * 4 + g) * 4;
+    const u32 xor32_addr = (u32)((lane ^ 32) * 4);            // ds_bpermute address of the lane 32 away
 
-    const unsigned char *ref_lane = ref_lds + (by16 * 16 + dy_lane0) * rls + (bx16 * 4 + g) * 4;
-
-    // output offsets (elements): main rows are [tile][slot][16 dx]; the edge rows [slot] follow all main rows
-    constexpr int ROW8 = EDGE ? 64 : row_elems(R, 0), ROW16 = EDGE ? 16 : row_elems(R, 1);
-    constexpr int ROW32 = EDGE ? 4 : row_elems(R, 2), ROW64 = EDGE ? 1 : row_elems(R, 3);
-    const size_t rows_before = (EDGE ? (size_t)p.nctu_total * nmv : 0);
-    uint16_t *o8 = p.sad8 + rows_before * row_elems(R, 0) + (size_t)ctu * nmv * ROW8;
-    uint16_t *o16 = p.sad16 + rows_before * row_elems(R, 1) + (size_t)ctu * nmv * ROW16;
-    u32 *o32 = p.sad32 + rows_before * row_elems(R, 2) + (size_t)ctu * nmv * ROW32;
-    u32 *o64 = p.sad64 + rows_before * row_elems(R, 3) + (size_t)ctu * nmv * ROW64;
-    const int q = (by16 >> 1) * 2 + (bx16 >> 1);
-    const u32 off8 = EDGE ? z : wave * 1024 + z * 16 + gl * 4;       // child c adds c*16 slots
-    const u32 off16 = EDGE ? z : wave * 256 + z * 16 + gl * 4;
-    // 32x32 / 64x64: after the reductions every lane of a quadrant (of the wavefront) holds the same 4 sums;
-    // lane b = z&3 writes the b-th one, so all 64 (16) lanes store one dword each into one contiguous run
-    const u32 off32 = EDGE ? q : wave * 64 + q * 16 + gl * 4 + (z & 3);
-    const u32 off64 = EDGE ? 0 : wave * 16 + gl * 4 + (z & 3);
-    constexpr u32 CH = EDGE ? 16 : 256;                              // element step between children
+    // output rows (uniform per workgroup and step) and per-lane byte offsets inside a row
+    constexpr int ROW8 = row_elems(R, 0), ROW16 = row_elems(R, 1), ROW32 = row_elems(R, 2), ROW64 = row_elems(R, 3);
+    const size_t row0 = (size_t)ctu * nmv + seg_base;
+    char *o8 = reinterpret_cast<char *>(p.sad8 + row0 * ROW8);
+    char *o16 = reinterpret_cast<char *>(p.sad16 + row0 * ROW16);
+    char *o32 = reinterpret_cast<char *>(p.sad32 + row0 * ROW32);
+    char *o64 = reinterpret_cast<char *>(p.sad64 + row0 * ROW64);
+    const u32 off8 = (u32)(wave * 1024 + z * 16 + gl * 4) * 2u;   // child c adds c*512 bytes
+    const u32 off16 = (u32)(wave * 256 + z * 16 + gl * 4) * 2u;
+    const u32 off32 = (u32)(wave * 64 + q * 16 + gl * 4 + b) * 4u; // lane b stores the sum for dx = 4*gl + b
+    const u32 off64 = (u32)(wave * 16 + gl * 4 + b) * 4u;
 
     u64 acc[4][8];
 #pragma unroll
@@ -183,93 +192,93 @@ __global__ void __launch_bounds__(EDGE ? 64 : 8 * R, EDGE ? 1 : (R == 128 ? 4 : 
             for (int c = 0; c < 4; c++)
 #pragma unroll
                 for (int j = 0; j < 8; j++) asm volatile("" : "+v"(acc[c][j]));
-            // the accumulators that started 7 steps ago are complete: dy index (lane-relative) s-7
+            // the accumulators that started 7 steps ago are complete: dy index (band-relative) s-7
             const int jd = (u + 1) & 7;
             const int dyl = s - 7;
-            const int dyi = seg_base + dy_lane0 + dyl;
             const u64 v0 = acc[0][jd], v1 = acc[1][jd], v2 = acc[2][jd], v3 = acc[3][jd];
             const u64 v16 = v0 + v1 + v2 + v3;  // packed u16 lanes, each <= 65280: no carry between lanes
-            u32 x0 = (u32)v16 & 0xffffu, x1 = (u32)v16 >> 16, x2 = (u32)(v16 >> 32) & 0xffffu, x3 = (u32)(v16 >> 48);
-            // 32x32: sum over the quadrant's 4 blocks = lane bits 3:2 (row rotate by 4 and 8 inside 16 lanes)
-            x0 = dpp_add<0x128>(dpp_add<0x124>(x0));
-            x1 = dpp_add<0x128>(dpp_add<0x124>(x1));
-            x2 = dpp_add<0x128>(dpp_add<0x124>(x2));
-            x3 = dpp_add<0x128>(dpp_add<0x124>(x3));
-            // 64x64: sum over the 4 quadrants = lane bits 5:4
-            u32 t0 = x0 + (u32)__shfl_xor((int)x0, 16), t1 = x1 + (u32)__shfl_xor((int)x1, 16);
-            u32 t2 = x2 + (u32)__shfl_xor((int)x2, 16), t3 = x3 + (u32)__shfl_xor((int)x3, 16);
-            t0 += (u32)__shfl_xor((int)t0, 32);
-            t1 += (u32)__shfl_xor((int)t1, 32);
-            t2 += (u32)__shfl_xor((int)t2, 32);
-            t3 += (u32)__shfl_xor((int)t3, 32);
-
+            // 32x32: reduce-scatter over the quadrant's 4 lanes; 64x64: sum over the 4 quadrants (lane bits 5:4)
+            const u32 r32 = quad_reduce_scatter((u32)v16, (u32)(v16 >> 32), b);
+            u32 t64 = r32 + (u32)__builtin_amdgcn_ds_swizzle((int)r32, kSwizzleXor16);
+            t64 += (u32)__builtin_amdgcn_ds_bpermute((int)xor32_addr, (int)t64);
 #ifdef XMI_EXP_NOSTORE
-            if (dyl >= 0 && dyl < ndy_lane && dyi < nmv && v16 == 0x1234567812345678ull && t0 == 77u) {
+            if (dyl >= 0 && dyl < ndy && v16 == 0x1234567812345678ull && t64 == 77u) {
 #else
-            if (dyl >= 0 && dyl < ndy_lane && dyi < nmv) {
+            if (dyl >= 0 && dyl < ndy) {
 #endif
-                if (!EDGE) {
-#ifndef XMI_EXP_STORES
-#define XMI_EXP_STORES 15
-#endif
-                    u64 *r8 = reinterpret_cast<u64 *>(o8 + (u32)dyi * ROW8 + off8);
-                    if (XMI_EXP_STORES & 1) {
-                        r8[0] = v0;
-                        r8[CH / 4] = v1;
-                        r8[2 * CH / 4] = v2;
-                        r8[3 * CH / 4] = v3;
-                    }
-                    if (XMI_EXP_STORES & 2) *reinterpret_cast<u64 *>(o16 + (u32)dyi * ROW16 + off16) = v16;
-                    const int b = z & 3;
-                    if (XMI_EXP_STORES & 4) o32[(u32)dyi * ROW32 + off32] = b == 0 ? x0 : b == 1 ? x1 : b == 2 ? x2 : x3;
-                    if ((XMI_EXP_STORES & 8) && z < 4) o64[(u32)dyi * ROW64 + off64] = b == 0 ? t0 : b == 1 ? t1 : b == 2 ? t2 : t3;
-                } else {
-                    uint16_t *r8 = o8 + (u32)dyi * ROW8 + off8;
-                    r8[0] = (uint16_t)v0;
-                    r8[CH] = (uint16_t)v1;
-                    r8[2 * CH] = (uint16_t)v2;
-                    r8[3 * CH] = (uint16_t)v3;
-                    o16[(u32)dyi * ROW16 + off16] = (uint16_t)v16;
-                    if ((z & 3) == 0) o32[(u32)dyi * ROW32 + off32] = x0;
-                    if (z == 0) o64[(u32)dyi * ROW64 + off64] = t0;
+                char *r8 = o8 + (size_t)dyl * (ROW8 * 2);      // uniform row bases + 32-bit lane offsets
+                *reinterpret_cast<u64 *>(r8 + off8) = v0;
+                *reinterpret_cast<u64 *>(r8 + off8 + 512) = v1;
+                *reinterpret_cast<u64 *>(r8 + off8 + 1024) = v2;
+                *reinterpret_cast<u64 *>(r8 + off8 + 1536) = v3;
+                *reinterpret_cast<u64 *>(o16 + (size_t)dyl * (ROW16 * 2) + off16) = v16;
+                *reinterpret_cast<u32 *>(o32 + (size_t)dyl * (ROW32 * 4) + off32) = r32;
+                if (q == 0) *reinterpret_cast<u32 *>(o64 + (size_t)dyl * (ROW64 * 4) + off64) = t64;
+            }
+        }
+    }
+
+    // ---- the dx = +R column: one more than a multiple of 4, so it gets a plain v_sad_u8 pass of its own.
+    // lane (z, gl) of wavefront w takes the band rows d = (4w + gl), +4*nwaves, ...; the reference bytes of
+    // dx = +R start at window dword R/2 + 4*bx16, already staged.
+    {
+        constexpr int nlan = 4 * nwaves;
+        const unsigned char *ref_e = ref_lds + (by16 * 16) * rls + (R / 2 + bx16 * 4) * 4;
+        const unsigned char *cl = cur_lds + z * 16;
+        const size_t rows_main = (size_t)p.nctu_total * nmv;
+        uint16_t *e8 = p.sad8 + rows_main * ROW8 + row0 * 64;
+        uint16_t *e16 = p.sad16 + rows_main * ROW16 + row0 * 16;
+        u32 *e32 = p.sad32 + rows_main * ROW32 + row0 * 4;
+        u32 *e64 = p.sad64 + rows_main * ROW64 + row0;
+        for (int d0 = 0; d0 < ndy; d0 += nlan) {
+            const int d = d0 + wave * 4 + gl;
+            const int dr = min(d, ndy - 1);                    // lanes past the band recompute its last row (not stored)
+            u32 a[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const u32 *rr = reinterpret_cast<const u32 *>(ref_e + (cy * 8 + y + dr) * rls);
+                    const uint4 c = *reinterpret_cast<const uint4 *>(cl + (cy * 8 + y) * 256);
+                    a[cy * 2 + 0] = __builtin_amdgcn_sad_u8(rr[1], c.y, __builtin_amdgcn_sad_u8(rr[0], c.x, a[cy * 2 + 0]));
+                    a[cy * 2 + 1] = __builtin_amdgcn_sad_u8(rr[3], c.w, __builtin_amdgcn_sad_u8(rr[2], c.z, a[cy * 2 + 1]));
                 }
+            const u32 s16 = a[0] + a[1] + a[2] + a[3];
+            u32 s32 = s16 + dpp_mov<kQuadXor1>(s16);
+            s32 += dpp_mov<kQuadXor2>(s32);
+            u32 s64 = s32 + (u32)__builtin_amdgcn_ds_swizzle((int)s32, kSwizzleXor16);
+            s64 += (u32)__builtin_amdgcn_ds_bpermute((int)xor32_addr, (int)s64);
+            if (d < ndy) {
+                uint16_t *r8 = e8 + (size_t)d * 64 + z;
+                r8[0] = (uint16_t)a[0];
+                r8[16] = (uint16_t)a[1];
+                r8[32] = (uint16_t)a[2];
+                r8[48] = (uint16_t)a[3];
+                e16[(size_t)d * 16 + z] = (uint16_t)s16;
+                if (b == 0) e32[(size_t)d * 4 + q] = s32;
+                if (z == 0) e64[d] = s64;
             }
         }
     }
 }
 
-int seg_len_edge(int nmv) { return (nmv + 3) / 4; }
-
-size_t lds_bytes_main(int R, int seg_len)
+size_t lds_bytes(int R, int seg_len)
 {
     const int nsteps = (seg_len + 7 + 7) & ~7;
     const int rows = nsteps + 56;
-    return kCurLdsBytes + (size_t)rows * ((R / 2 + 16 + 1) * 4);
-}
-
-size_t lds_bytes_edge(int nmv)
-{
-    const int seg = seg_len_edge(nmv);
-    const int nsteps = (seg + 7 + 7) & ~7;
-    const int rows = 3 * seg + 56 + nsteps;
-    const int loaded = nmv + 63;
-    return kCurLdsBytes + (size_t)(rows > loaded ? rows : loaded) * (17 * 4);
+    return kCurLdsBytes + (size_t)rows * ((R / 2 + 17) * 4);
 }
 
 template <int R>
-int launch_pair(const SadParams &p, const SadParams &pe, int n, int nseg, size_t lds_main, size_t lds_edge, hipStream_t st)
+int launch_surface(const SadParams &p, int n, int nseg, size_t lds, hipStream_t st)
 {
     static bool attr_done = false;  // one flag per R instantiation
     if (!attr_done) {
-        XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<R, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<R, true>),
+        XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<R>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL((sad_surface_kernel<R, false>), dim3(n, nseg), dim3(8 * R), lds_main, st, p);
-    XMI_HIP(hipGetLastError());
-    hipLaunchKernelGGL((sad_surface_kernel<R, true>), dim3(n), dim3(64), lds_edge, st, pe);
+    hipLaunchKernelGGL((sad_surface_kernel<R>), dim3(n, nseg), dim3(8 * R), lds, st, p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
@@ -347,25 +356,19 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     hipStream_t st = xmi::as_stream(stream);
     const int n = ctu_end - ctu_begin;
 
-    // main: dx in [-R, R-1]; split the dy range into bands when there are too few CTUs to fill 256 CUs
+    // one workgroup per CTU; split the dy range into bands when there are too few CTUs to fill 256 CUs
     int nseg = 1;
     while (n * nseg < 256 && nseg < 8) nseg *= 2;
     p.seg_len = (nmv + nseg - 1) / nseg;
     nseg = (nmv + p.seg_len - 1) / p.seg_len;
-    const size_t lds_main = lds_bytes_main(R, p.seg_len);
-    XMI_ARG(lds_main <= 160 * 1024, "xmi_sad_surface_dev: LDS window %zu exceeds 160 KiB", lds_main);
-    const size_t lds_edge = lds_bytes_edge(nmv);
-    SadParams pe = p;
-    pe.seg_len = seg_len_edge(nmv);
-    // main: dx in [-R, R-1], R/8 wavefronts per CTU band.  edge: the dx = +R column, one wavefront per
-    // CTU whose 4 lane groups split the dy range.
+    const size_t lds = lds_bytes(R, p.seg_len);
+    XMI_ARG(lds <= 160 * 1024, "xmi_sad_surface_dev: LDS window %zu exceeds 160 KiB", lds);
     switch (R) {
-    case 16: rc = launch_pair<16>(p, pe, n, nseg, lds_main, lds_edge, st); break;
-    case 32: rc = launch_pair<32>(p, pe, n, nseg, lds_main, lds_edge, st); break;
-    case 64: rc = launch_pair<64>(p, pe, n, nseg, lds_main, lds_edge, st); break;
-    default: rc = launch_pair<128>(p, pe, n, nseg, lds_main, lds_edge, st); break;
+    case 16: return launch_surface<16>(p, n, nseg, lds, st);
+    case 32: return launch_surface<32>(p, n, nseg, lds, st);
+    case 64: return launch_surface<64>(p, n, nseg, lds, st);
+    default: return launch_surface<128>(p, n, nseg, lds, st);
     }
-    return rc;
 }
 
 int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *ref_origin, int pad,
