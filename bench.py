@@ -151,7 +151,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # average duration of the dominant kernel pair (main + edge column), HIP events on the launch stream
+    # average duration of the dominant kernel (one launch per step), HIP events on the launch stream
     kern_ms_raw = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     kern_ms = sorted(kern_ms_raw)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)

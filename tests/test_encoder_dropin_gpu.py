@@ -1,0 +1,41 @@
+"""GPU: the reference encoder's own control flow (objects compiled from the reference sources into
+oracle/_ref by `make -C oracle enc`) run with three sets of pixel primitives must write the same bitstream:
+  x265_refsse  reference C++/SSE4 primitives (+ oracle for the NASM-only SATD/SSD entries)
+  x265_oracle  all primitives from the CPU oracle
+  x265_gpu     all primitives from libx265_amd through the drop-in table (per-call GPU kernels)
+Config 0 of the baseline: 416x240, 8 frames, IPPP, CPU-sized. The md5s in tests/golden/encoder_md5.json were
+written in the development container by the refsse build (tools/enc_parity.py --write)."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+pytestmark = pytest.mark.gpu
+
+
+def encode(variant, yuv, out, w, h, frames, qp):
+    exe = os.path.join(REFDIR, f"x265_{variant}")
+    cmd = [exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(frames), "-q", str(qp), "-ip", "100",
+           "-sceneChange", "0", "-t", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu")), reason="integration harness not built (make -C oracle enc)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_primitives(tmp_path, qp, frames):
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    assert hashlib.md5(open(yuv, "rb").read()).hexdigest() == want["input_md5"]
+    got_o = encode("oracle", yuv, str(tmp_path / "o.265"), w, h, frames, qp)
+    got_g = encode("gpu", yuv, str(tmp_path / "g.265"), w, h, frames, qp)
+    assert got_o == (want["md5"], want["bytes"])
+    assert got_g == (want["md5"], want["bytes"])

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Run the encoder integration harness variants and compare bitstreams.
+  enc_parity.py --write            (development container) record refsse md5s into tests/golden/encoder_md5.json
+  enc_parity.py VARIANT...         print md5/size/time per variant for every recorded config"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "encoder_md5.json")
+CONFIGS = [(416, 240, 8, 32), (416, 240, 3, 22), (416, 240, 8, 27), (416, 240, 8, 37)]
+
+
+def run(variant, yuv, w, h, f, q, out):
+    exe = os.path.join(ROOT, "oracle", "_ref", f"x265_{variant}")
+    t = time.time()
+    subprocess.run([exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(f), "-q", str(q), "-ip", "100",
+                    "-sceneChange", "0", "-t", "1"], check=True, capture_output=True)
+    return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out), time.time() - t
+
+
+def main():
+    write = "--write" in sys.argv
+    variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["refsse", "oracle"]
+    gold = {} if write else json.load(open(GOLD))
+    with tempfile.TemporaryDirectory() as d:
+        for w, h, f, q in CONFIGS:
+            yuv = os.path.join(d, "in.yuv")
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), "1234", yuv])
+            key = f"{w}x{h}_f{f}_q{q}"
+            res = {v: run(v, yuv, w, h, f, q, os.path.join(d, v + ".265")) for v in variants}
+            for v, (m, n, t) in res.items():
+                print(f"{key:20s} {v:8s} {m} {n:8d} B {t:7.2f} s")
+            if write:
+                assert res["refsse"][:2] == res["oracle"][:2], "oracle primitives diverge from the reference's SSE primitives"
+                gold[key] = {"md5": res["refsse"][0], "bytes": res["refsse"][1],
+                             "input_md5": hashlib.md5(open(yuv, "rb").read()).hexdigest()}
+            else:
+                for v, (m, n, t) in res.items():
+                    assert (m, n) == (gold[key]["md5"], gold[key]["bytes"]), f"{v} differs on {key}"
+    if write:
+        json.dump(gold, open(GOLD, "w"), indent=1, sort_keys=True)
+        print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()

@@ -61,12 +61,25 @@ SSD_FN(4) SSD_FN(8) SSD_FN(16) SSD_FN(32) SSD_FN(64)
 HAD_FN(8) HAD_FN(16) HAD_FN(32) HAD_FN(64)
 
 // ---- the tables, with the reference's names (src/pixel.cpp:529, 711, 810, 833, 846) ----
-xSad *xSadN[MAX_CU_DEPTH] = { gpuSad4, gpuSad8, gpuSad16, gpuSad32, gpuSad64 };
-xSatd *xSatdN[MAX_CU_DEPTH] = { gpuSatd4, gpuSatd8, gpuSatd16, gpuSatd32 };
-xSSD *xSsdN[MAX_CU_DEPTH] = { gpuSsd4, gpuSsd8, gpuSsd16, gpuSsd32, gpuSsd64 };
+// The k_* copies are what xmi_install_primitives() hands out: when this library is loaded into an
+// encoder that still defines its own xSadN etc., the exported names below resolve to the ENCODER's
+// arrays (ELF interposition), the static ones never do.
+#define SAD_LIST gpuSad4, gpuSad8, gpuSad16, gpuSad32, gpuSad64
+#define SATD_LIST gpuSatd4, gpuSatd8, gpuSatd16, gpuSatd32
+#define SSD_LIST gpuSsd4, gpuSsd8, gpuSsd16, gpuSsd32, gpuSsd64
 // index = 2*xLog2(w-1) + xLog2(h-1) - 9; the encoder only uses the square entries 0, 3, 6, 9 (src/encode.cpp:2841, 3135)
-xME_SAD *xSad_AMP[10] = { gpuSad8, nullptr, nullptr, gpuSad16, nullptr, nullptr, gpuSad32, nullptr, nullptr, gpuSad64 };
-xME_SATD *xSatd_AMP[10] = { gpuHad8, nullptr, nullptr, gpuHad16, nullptr, nullptr, gpuHad32, nullptr, nullptr, gpuHad64 };
+#define SAD_AMP_LIST gpuSad8, nullptr, nullptr, gpuSad16, nullptr, nullptr, gpuSad32, nullptr, nullptr, gpuSad64
+#define SATD_AMP_LIST gpuHad8, nullptr, nullptr, gpuHad16, nullptr, nullptr, gpuHad32, nullptr, nullptr, gpuHad64
+static xSad *const k_sadN[MAX_CU_DEPTH] = { SAD_LIST };
+static xSatd *const k_satdN[MAX_CU_DEPTH] = { SATD_LIST };
+static xSSD *const k_ssdN[MAX_CU_DEPTH] = { SSD_LIST };
+static xME_SAD *const k_sadAmp[10] = { SAD_AMP_LIST };
+static xME_SATD *const k_satdAmp[10] = { SATD_AMP_LIST };
+xSad *xSadN[MAX_CU_DEPTH] = { SAD_LIST };
+xSatd *xSatdN[MAX_CU_DEPTH] = { SATD_LIST };
+xSSD *xSsdN[MAX_CU_DEPTH] = { SSD_LIST };
+xME_SAD *xSad_AMP[10] = { SAD_AMP_LIST };
+xME_SATD *xSatd_AMP[10] = { SATD_AMP_LIST };
 
 // ---- the free functions (inc/x265.h:652-655) ----
 void xSubDct(Int16 *pDst, UInt8 *pSrc, UInt nStride, UInt8 *pRef, UInt nStrideRef, Int16 *, Int16 *, Int iWidth, UInt nMode)
@@ -92,9 +105,9 @@ void xDeQuant(Int16 *pDst, Int16 *pSrc, UInt nStride, UInt nQP, Int iWidth, Int 
 // ---- hook for an unmodified encoder: overwrite the entries of ITS tables (passed by address) ----
 extern "C" void xmi_install_primitives(xSad **sadN, xME_SAD **sadAmp, xSatd **satdN, xSSD **ssdN, xME_SATD **satdAmp)
 {
-    if (sadN) for (int i = 0; i < MAX_CU_DEPTH; i++) sadN[i] = xSadN[i];
-    if (sadAmp) for (int i = 0; i < 10; i += 3) sadAmp[i] = xSad_AMP[i];
-    if (satdN) for (int i = 0; i < 4; i++) satdN[i] = xSatdN[i];
-    if (ssdN) for (int i = 0; i < MAX_CU_DEPTH; i++) ssdN[i] = xSsdN[i];
-    if (satdAmp) for (int i = 0; i < 10; i += 3) satdAmp[i] = xSatd_AMP[i];
+    if (sadN) for (int i = 0; i < MAX_CU_DEPTH; i++) sadN[i] = k_sadN[i];
+    if (sadAmp) for (int i = 0; i < 10; i += 3) sadAmp[i] = k_sadAmp[i];
+    if (satdN) for (int i = 0; i < 4; i++) satdN[i] = k_satdN[i];
+    if (ssdN) for (int i = 0; i < MAX_CU_DEPTH; i++) ssdN[i] = k_ssdN[i];
+    if (satdAmp) for (int i = 0; i < 10; i += 3) satdAmp[i] = k_satdAmp[i];
 }
