@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Secondary kernels: TU chain and block metrics, device-resident batches, HIP-event timing.
+Prints one JSON line per kernel/size with the HBM roofline fraction (algorithmic bytes: 5N^2+4 per TU,
+2N^2+4 per metric pair; peak 8 TB/s)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from x265_amd import capi  # noqa: E402
+
+L = capi.load()
+capi.check(L.xmi_init(0))
+PEAK = 8000.0
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+g = torch.Generator(device="cuda").manual_seed(1)
+for n in (4, 8, 16, 32):
+    cnt = (256 << 20) // (n * n)
+    pix = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
+    pred = (pix.to(torch.int16) + torch.randint(-12, 13, pix.shape, dtype=torch.int16, device="cuda", generator=g)).clamp(0, 255).to(torch.uint8)
+    qp = torch.full((cnt,), 27, dtype=torch.uint8, device="cuda")
+    fl = torch.zeros(cnt, dtype=torch.uint8, device="cuda")
+    lev = torch.empty((cnt, n, n), dtype=torch.int16, device="cuda")
+    rec = torch.empty((cnt, n, n), dtype=torch.uint8, device="cuda")
+    sm = torch.empty(cnt, dtype=torch.int32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    t = timeit(lambda: capi.check(L.xmi_tu_chain_batch_dev(n, cnt, pix.data_ptr(), pred.data_ptr(), qp.data_ptr(), fl.data_ptr(),
+                                                           lev.data_ptr(), rec.data_ptr(), sm.data_ptr(), s)))
+    by = cnt * (5 * n * n + 4)
+    print(json.dumps({"kernel": f"tu_chain {n}x{n}", "count": cnt, "ms": round(t * 1e3, 3), "MTU_per_s": round(cnt / t / 1e6, 1),
+                      "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+    del pix, pred, lev, rec
+for metric, name in ((capi.METRIC_SAD, "sad"), (capi.METRIC_SATD_HM, "satd_hm"), (capi.METRIC_SATD_X264, "satd_x264"), (capi.METRIC_SSD, "ssd")):
+    for n in (4, 8, 16, 32, 64):
+        if metric == capi.METRIC_SATD_X264 and n > 16:
+            continue
+        cnt = (256 << 20) // (n * n)
+        a = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
+        b = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
+        out = torch.empty(cnt, dtype=torch.int32, device="cuda")
+        s = torch.cuda.current_stream().cuda_stream
+        t = timeit(lambda: capi.check(L.xmi_block_metric_batch_dev(metric, n, cnt, a.data_ptr(), b.data_ptr(), out.data_ptr(), s)))
+        by = cnt * (2 * n * n + 4)
+        print(json.dumps({"kernel": f"{name} {n}x{n}", "count": cnt, "ms": round(t * 1e3, 3), "Meval_per_s": round(cnt / t / 1e6, 1),
+                          "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+        del a, b
