@@ -28,6 +28,8 @@
 //   xmi_sad_surface_index() does this arithmetic.
 #include "xmi_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef unsigned long long u64;
@@ -152,7 +154,11 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[c][j] = 0;
 
-    for (int s0 = 0; s0 < nsteps; s0 += 8) {
+    // One 8-step group (the accumulator ring period). PHASE 0 / 2 are the first / last group of a full-range
+    // band (ndy = 1 mod 8): there the row pairs whose dy falls outside the band are skipped at compile time
+    // (y > u in the first group, y < u in the last); PHASE 1 is the generic group.
+    auto group = [&](auto phase_tag, const int s0) {
+        constexpr int PHASE = decltype(phase_tag)::value;
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int s = s0 + u;
@@ -169,14 +175,17 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
                 const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3), p34 = pack64(w3, w4);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
+#ifndef XMI_EXP_NOSCHEDBAR
                     asm volatile("" ::: "memory");  // bound the live range of the current-pixel registers:
                     __builtin_amdgcn_sched_barrier(0);  // neither the compiler nor the scheduler may hoist these reads
+#endif
                     uint4 c[4];
 #pragma unroll
                     for (int yy = 0; yy < 4; yy++) c[yy] = *reinterpret_cast<const uint4 *>(cl + (cy * 8 + h * 4 + yy) * 256);
 #pragma unroll
                     for (int yy = 0; yy < 4; yy++) {
                         const int y = h * 4 + yy;
+                        if ((PHASE == 0 && y > u) || (PHASE == 2 && y < u)) continue;
                         const int j = (u - y) & 7;
                         const u64 a0 = (y == 0) ? 0ull : acc[cy * 2 + 0][j];
                         const u64 a1 = (y == 0) ? 0ull : acc[cy * 2 + 1][j];
@@ -216,7 +225,19 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
                 if (q == 0) *reinterpret_cast<u32 *>(o64 + (size_t)dyl * (ROW64 * 4) + off64) = t64;
             }
         }
+    };
+    const bool peel = (ndy & 7) == 1 && nsteps >= 24;
+#ifdef XMI_EXP_NOPEEL
+    for (int s0 = 0; s0 < nsteps; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
+#else
+    if (peel) {
+        group(std::integral_constant<int, 0>{}, 0);
+        for (int s0 = 8; s0 < nsteps - 8; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
+        group(std::integral_constant<int, 2>{}, nsteps - 8);
+    } else {
+        for (int s0 = 0; s0 < nsteps; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
     }
+#endif
 
     // ---- the dx = +R column: one more than a multiple of 4, so it gets a plain v_sad_u8 pass of its own.
     // lane (z, gl) of wavefront w takes the band rows d = (4w + gl), +4*nwaves, ...; the reference bytes of
