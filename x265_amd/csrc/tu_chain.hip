@@ -181,6 +181,175 @@ __global__ void __launch_bounds__(256) tu_kernel(const TuParams p)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 32x32 chain on the matrix cores: one wavefront per TU, the whole chain register to register.
+//
+// v_mfma_i32_32x32x32_i8 computes D[m][n] = sum_k A[m][k] * B[k][n] (+C) with, for lane l (r = l & 31, h = l >> 5):
+//   A fragment byte j = A[r][16h + j],  B fragment byte j = B[16h + j][r],  D register g = D[rho(h,g)][r],
+//   rho(h,g) = (g & 3) + 8 (g >> 2) + 4h          (checked with exact integer data, tools/microbench/mfma_i8_probe.hip).
+// A result tile therefore has its column on the lane and its rows in the registers, so it can feed the
+// next product directly as long as that product contracts over the tile's ROW index; the contraction
+// order inside the instruction is then rho(h, .) instead of 16h + ., which is absorbed by permuting the
+// constant (matrix) operand the same way. Chain (R = residual, M = core matrix):
+//   F1  D1 = R  * M^T      A = residual rows (from memory),          B = M (natural)      -> D1[i][k] = tmp[k][i]
+//   F2  D2 = M  * D1       A = M with columns permuted by rho,       B = D1 (registers)   -> D2[k][i] = coef[k][i]
+//   I1  D3 = D2^T * M      A = D2 (registers, k permuted by rho),    B = M rows permuted  -> D3[i][j] = t0[i][j]
+//   I2  D4 = M^T * D3      A = M rows permuted (same fragment),      B = D3 (registers)   -> D4[j][i] = t1[i][j]
+// 16-bit operands are fed as two int8 slices, t = 256 * hi + (lo' + 128) with hi = t >> 8 (signed) and
+// lo' = (t & 255) - 128, so sum M t = 256 sum M hi + sum M lo' + 128 sum M: two MFMAs and a constant that is
+// folded into the accumulator input together with the rounding offset. The residual of F1 is
+// (src - 128) - (pred - 128): two MFMAs against M and -M. Everything is exact 32-bit integer arithmetic.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int rho(int h, int g) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
+
+// pack bits 15:8 (signed high byte) and bits 7:0 minus 128 of 16 ints into two 16-byte MFMA fragments
+__device__ __forceinline__ void slice16(const int (&t)[16], v4i &hi, v4i &lo)
+{
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned p01 = __builtin_amdgcn_perm((unsigned)t[4 * w + 1], (unsigned)t[4 * w + 0], 0x05040100u);
+        const unsigned p23 = __builtin_amdgcn_perm((unsigned)t[4 * w + 3], (unsigned)t[4 * w + 2], 0x05040100u);
+        hi[w] = (int)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
+        lo[w] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
+    }
+}
+
+__global__ void __launch_bounds__(256) tu32_mfma_kernel(const TuParams p)
+{
+    __shared__ int s_colsum[32];
+    __shared__ int8_t s_m[32 * 33];   // core matrix, built once per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int e = tid; e < 1024; e += 256) s_m[(e >> 5) * 33 + (e & 31)] = (int8_t)dct_coef(32, e >> 5, e & 31);
+    __syncthreads();
+    if (tid < 32) {
+        int s = 0;
+        for (int k = 0; k < 32; k++) s += s_m[k * 33 + tid];
+        s_colsum[tid] = s;
+    }
+    __syncthreads();
+
+    // constant fragments (built once per wavefront; the wavefront then loops over its TUs)
+    v4i m_nat, m_neg, m_colperm, m_rowperm;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        unsigned a = 0, b = 0, c = 0, d = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int j = 4 * w + e;
+            const int nat = s_m[r * 33 + 16 * h + j];
+            a |= (unsigned)(nat & 255) << (8 * e);
+            b |= (unsigned)((-nat) & 255) << (8 * e);
+            c |= (unsigned)(s_m[r * 33 + rho(h, j)] & 255) << (8 * e);
+            d |= (unsigned)(s_m[rho(h, j) * 33 + r] & 255) << (8 * e);
+        }
+        m_nat[w] = (int)a;
+        m_neg[w] = (int)b;
+        m_colperm[w] = (int)c;
+        m_rowperm[w] = (int)d;
+    }
+    const int cs_lane = 128 * s_colsum[r];
+    int cs_reg[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) cs_reg[g] = (1 << 11) + 128 * s_colsum[rho(h, g)];
+
+    for (int tu = blockIdx.x * 4 + wave; tu < p.count; tu += gridDim.x * 4) {
+    const int flags = p.flags[tu], qp = p.qp[tu];
+    const size_t base = (size_t)tu * 1024;
+    const uint8_t *pix = p.pix + base, *pred = p.pred + base;
+
+    // ---- F1: residual rows x M^T ----
+    v4i s_frag = *reinterpret_cast<const v4i *>(pix + r * 32 + 16 * h);
+    v4i p_frag = *reinterpret_cast<const v4i *>(pred + r * 32 + 16 * h);
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        s_frag[w] ^= (int)0x80808080u;
+        p_frag[w] ^= (int)0x80808080u;
+    }
+    v16i acc;
+#pragma unroll
+    for (int g = 0; g < 16; g++) acc[g] = 1 << 3;   // rounding of the >> 4
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag, m_nat, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag, m_neg, acc, 0, 0, 0);
+    int t[16];
+#pragma unroll
+    for (int g = 0; g < 16; g++) t[g] = acc[g] >> 4;          // tmp[k = r][i = rho(h,g)], fits int16
+
+    // ---- F2: M x D1 ----
+    v4i hi, lo;
+    slice16(t, hi, lo);
+    v16i acc_hi, acc_lo;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        acc_hi[g] = 0;
+        acc_lo[g] = (1 << 10) + (rho(h, g) == 0 ? 128 * 2048 : 0);   // rounding of the >> 11 + 128 * rowsum(M[k]) (only row 0 is non-zero)
+    }
+    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
+
+    // ---- quant / dequant on coef[k = rho(h,g)][i = r] ----
+    const int qbits = 14 + qp / 6 + (15 - 8 - 5);
+    const int q = k_quant_scales[qp % 6];
+    const int qrnd = ((flags & 1) ? 171 : 85) << (qbits - 9);
+    const int dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
+    uint32_t local = 0;
+    int16_t *lev = p.out16 + base;
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> 11;
+        const int mag = (abs(c) * q + qrnd) >> qbits;
+        local += (uint32_t)mag;
+        const int level = clip16(c < 0 ? -mag : mag);
+        lev[rho(h, g) * 32 + r] = (int16_t)level;
+        t[g] = clip16((level * dscale + (1 << 3)) >> 4);      // dequant shift for 32x32 is 4
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) local += (uint32_t)__shfl_xor((int)local, sh);
+    if (lane == 0) p.sum[tu] = local;
+
+    // ---- I1: D2^T x M ----
+    slice16(t, hi, lo);
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        acc_hi[g] = 0;
+        acc_lo[g] = (1 << 6) + cs_lane;
+    }
+    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 16; g++) t[g] = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 7);   // t0[i = rho(h,g)][j = r]
+
+    // ---- I2: M^T x D3 ----
+    slice16(t, hi, lo);
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+        acc_hi[g] = 0;
+        acc_lo[g] = cs_reg[g];
+    }
+    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, hi, acc_hi, 0, 0, 0);
+    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, lo, acc_lo, 0, 0, 0);
+
+    // ---- reconstruct: residual t1[i = r][j = rho(h,g)]; 4 groups of 4 consecutive pixels per lane ----
+    uint8_t *rec = p.rec + base;
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+        const int off = r * 32 + 8 * qd + 4 * h;
+        const unsigned pv = *reinterpret_cast<const unsigned *>(pred + off);
+        unsigned out = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int g = 4 * qd + e;
+            const int res = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 12);
+            const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
+            out |= (unsigned)v << (8 * e);
+        }
+        *reinterpret_cast<unsigned *>(rec + off) = out;
+    }
+    }  // TU loop
+}
+
 template <int MODE>
 int launch(int n, const TuParams &p, hipStream_t st)
 {
@@ -216,6 +385,14 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_pix && d_pred && d_qp && d_flags && d_level && d_rec && d_sum), "xmi_tu_chain_batch_dev: null argument");
     TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
+#ifndef XMI_EXP_TU_VALU
+    if (n == 32 && count > 0 && ((((uintptr_t)d_pix | (uintptr_t)d_pred) & 15) == 0) && (((uintptr_t)d_rec & 3) == 0)) {
+        const int blocks = (count + 3) / 4 < 2048 ? (count + 3) / 4 : 2048;   // 8 workgroups per CU, each wavefront loops over its TUs
+        hipLaunchKernelGGL(tu32_mfma_kernel, dim3(blocks), dim3(256), 0, xmi::as_stream(stream), p);
+        XMI_HIP(hipGetLastError());
+        return XMI_OK;
+    }
+#endif
     return launch<MODE_CHAIN>(n, p, xmi::as_stream(stream));
 }
 
