@@ -255,14 +255,31 @@ __global__ void __launch_bounds__(256) tu32_mfma_kernel(const TuParams p)
 #pragma unroll
     for (int g = 0; g < 16; g++) cs_reg[g] = (1 << 11) + 128 * s_colsum[rho(h, g)];
 
-    for (int tu = blockIdx.x * 4 + wave; tu < p.count; tu += gridDim.x * 4) {
-    const int flags = p.flags[tu], qp = p.qp[tu];
+    // software pipeline: the operands of the next TU are requested before the current one is computed
+    const int tu0 = blockIdx.x * 4 + wave, tu_step = gridDim.x * 4;
+    v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
+    unsigned pv_next[4] = { 0, 0, 0, 0 };
+    int flags_next = 0, qp_next = 0;
+    auto fetch = [&](int tu) {
+        const size_t b = (size_t)tu * 1024;
+        s_next = *reinterpret_cast<const v4i *>(p.pix + b + r * 32 + 16 * h);
+        p_next = *reinterpret_cast<const v4i *>(p.pred + b + r * 32 + 16 * h);
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) pv_next[qd] = *reinterpret_cast<const unsigned *>(p.pred + b + r * 32 + 8 * qd + 4 * h);
+        flags_next = p.flags[tu];
+        qp_next = p.qp[tu];
+    };
+    if (tu0 < p.count) fetch(tu0);
+    for (int tu = tu0; tu < p.count; tu += tu_step) {
+    const int flags = flags_next, qp = qp_next;
     const size_t base = (size_t)tu * 1024;
-    const uint8_t *pix = p.pix + base, *pred = p.pred + base;
+    v4i s_frag = s_next, p_frag = p_next;
+    unsigned pv_cur[4];
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) pv_cur[qd] = pv_next[qd];
+    if (tu + tu_step < p.count) fetch(tu + tu_step);
 
     // ---- F1: residual rows x M^T ----
-    v4i s_frag = *reinterpret_cast<const v4i *>(pix + r * 32 + 16 * h);
-    v4i p_frag = *reinterpret_cast<const v4i *>(pred + r * 32 + 16 * h);
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         s_frag[w] ^= (int)0x80808080u;
@@ -336,7 +353,7 @@ __global__ void __launch_bounds__(256) tu32_mfma_kernel(const TuParams p)
 #pragma unroll
     for (int qd = 0; qd < 4; qd++) {
         const int off = r * 32 + 8 * qd + 4 * h;
-        const unsigned pv = *reinterpret_cast<const unsigned *>(pred + off);
+        const unsigned pv = pv_cur[qd];
         unsigned out = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
