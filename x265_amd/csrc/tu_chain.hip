@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) tu_kernel(const TuParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// 32x32 chain on the matrix cores: one wavefront per TU, the whole chain register to register.
+// 8x8 / 16x16 / 32x32 chain on the matrix cores: one wavefront per 32x32 tile, the whole chain register to register.
 //
 // v_mfma_i32_32x32x32_i8 computes D[m][n] = sum_k A[m][k] * B[k][n] (+C) with, for lane l (r = l & 31, h = l >> 5):
 //   A fragment byte j = A[r][16h + j],  B fragment byte j = B[16h + j][r],  D register g = D[rho(h,g)][r],
@@ -216,22 +216,32 @@ __device__ __forceinline__ void slice16(const int (&t)[16], v4i &hi, v4i &lo)
     }
 }
 
-__global__ void __launch_bounds__(256) tu32_mfma_kernel(const TuParams p)
+// N = 32: one TU per 32x32 tile. N = 16 / 8: a tile holds (32/N)^2 independent TUs side by side and the
+// constant operand is the block-diagonal matrix diag(M_N, ..): block (a,b) of M R M^T is then M_N R_ab M_N^T,
+// so the same four products transform every TU of the tile at once (TU t of tile s: t = s*S + a*(32/N) + b).
+template <int N>
+__global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 {
+    constexpr int NB = 32 / N;            // TUs per tile row / column
+    constexpr int S = NB * NB;            // TUs per tile
+    constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : 3;
     __shared__ int s_colsum[32];
-    __shared__ int8_t s_m[32 * 33];   // core matrix, built once per workgroup
+    __shared__ int8_t s_m[32 * 33];       // block-diagonal core matrix, built once per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    for (int e = tid; e < 1024; e += 256) s_m[(e >> 5) * 33 + (e & 31)] = (int8_t)dct_coef(32, e >> 5, e & 31);
+    for (int e = tid; e < 1024; e += 256) {
+        const int k = e >> 5, j = e & 31;
+        s_m[k * 33 + j] = (k / N == j / N) ? (int8_t)dct_coef(N, k % N, j % N) : (int8_t)0;
+    }
     __syncthreads();
     if (tid < 32) {
-        int s = 0;
-        for (int k = 0; k < 32; k++) s += s_m[k * 33 + tid];
-        s_colsum[tid] = s;
+        int sum = 0;
+        for (int k = 0; k < 32; k++) sum += s_m[k * 33 + tid];
+        s_colsum[tid] = sum;
     }
     __syncthreads();
 
-    // constant fragments (built once per wavefront; the wavefront then loops over its TUs)
+    // constant fragments (built once per wavefront; the wavefront then loops over its tiles)
     v4i m_nat, m_neg, m_colperm, m_rowperm;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -255,116 +265,158 @@ __global__ void __launch_bounds__(256) tu32_mfma_kernel(const TuParams p)
 #pragma unroll
     for (int g = 0; g < 16; g++) cs_reg[g] = (1 << 11) + 128 * s_colsum[rho(h, g)];
 
-    // software pipeline: the operands of the next TU are requested before the current one is computed
-    const int tu0 = blockIdx.x * 4 + wave, tu_step = gridDim.x * 4;
+    // byte offset of pixel (row, col) of a tile inside the packed TU arrays, relative to the tile's first TU
+    auto pix_off = [](int row, int col) { return ((row / N) * NB + col / N) * (N * N) + (row % N) * N + col % N; };
+    const int ntiles = (p.count + S - 1) / S;
+    const int cb = r / N;                 // this lane's column block in every result tile
+
+    // software pipeline: the operands of the next tile are requested before the current one is computed
+    const int t0 = blockIdx.x * 4 + wave, t_step = gridDim.x * 4;
     v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
     unsigned pv_next[4] = { 0, 0, 0, 0 };
-    int flags_next = 0, qp_next = 0;
-    auto fetch = [&](int tu) {
-        const size_t b = (size_t)tu * 1024;
-        s_next = *reinterpret_cast<const v4i *>(p.pix + b + r * 32 + 16 * h);
-        p_next = *reinterpret_cast<const v4i *>(p.pred + b + r * 32 + 16 * h);
+    int qpf_next[NB];                     // qp | flags << 8 of TU (rb, cb) for rb = 0..NB-1; -1 = TU beyond count
+    auto fetch = [&](int tile) {
+        const int tu_first = tile * S;
+        const size_t b = (size_t)tu_first * (N * N);
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) pv_next[qd] = *reinterpret_cast<const unsigned *>(p.pred + b + r * 32 + 8 * qd + 4 * h);
-        flags_next = p.flags[tu];
-        qp_next = p.qp[tu];
-    };
-    if (tu0 < p.count) fetch(tu0);
-    for (int tu = tu0; tu < p.count; tu += tu_step) {
-    const int flags = flags_next, qp = qp_next;
-    const size_t base = (size_t)tu * 1024;
-    v4i s_frag = s_next, p_frag = p_next;
-    unsigned pv_cur[4];
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++) pv_cur[qd] = pv_next[qd];
-    if (tu + tu_step < p.count) fetch(tu + tu_step);
-
-    // ---- F1: residual rows x M^T ----
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        s_frag[w] ^= (int)0x80808080u;
-        p_frag[w] ^= (int)0x80808080u;
-    }
-    v16i acc;
-#pragma unroll
-    for (int g = 0; g < 16; g++) acc[g] = 1 << 3;   // rounding of the >> 4
-    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag, m_nat, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag, m_neg, acc, 0, 0, 0);
-    int t[16];
-#pragma unroll
-    for (int g = 0; g < 16; g++) t[g] = acc[g] >> 4;          // tmp[k = r][i = rho(h,g)], fits int16
-
-    // ---- F2: M x D1 ----
-    v4i hi, lo;
-    slice16(t, hi, lo);
-    v16i acc_hi, acc_lo;
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        acc_hi[g] = 0;
-        acc_lo[g] = (1 << 10) + (rho(h, g) == 0 ? 128 * 2048 : 0);   // rounding of the >> 11 + 128 * rowsum(M[k]) (only row 0 is non-zero)
-    }
-    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
-    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
-
-    // ---- quant / dequant on coef[k = rho(h,g)][i = r] ----
-    const int qbits = 14 + qp / 6 + (15 - 8 - 5);
-    const int q = k_quant_scales[qp % 6];
-    const int qrnd = ((flags & 1) ? 171 : 85) << (qbits - 9);
-    const int dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
-    uint32_t local = 0;
-    int16_t *lev = p.out16 + base;
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> 11;
-        const int mag = (abs(c) * q + qrnd) >> qbits;
-        local += (uint32_t)mag;
-        const int level = clip16(c < 0 ? -mag : mag);
-        lev[rho(h, g) * 32 + r] = (int16_t)level;
-        t[g] = clip16((level * dscale + (1 << 3)) >> 4);      // dequant shift for 32x32 is 4
-    }
-#pragma unroll
-    for (int sh = 1; sh < 64; sh <<= 1) local += (uint32_t)__shfl_xor((int)local, sh);
-    if (lane == 0) p.sum[tu] = local;
-
-    // ---- I1: D2^T x M ----
-    slice16(t, hi, lo);
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        acc_hi[g] = 0;
-        acc_lo[g] = (1 << 6) + cs_lane;
-    }
-    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
-    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 16; g++) t[g] = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 7);   // t0[i = rho(h,g)][j = r]
-
-    // ---- I2: M^T x D3 ----
-    slice16(t, hi, lo);
-#pragma unroll
-    for (int g = 0; g < 16; g++) {
-        acc_hi[g] = 0;
-        acc_lo[g] = cs_reg[g];
-    }
-    acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, hi, acc_hi, 0, 0, 0);
-    acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, lo, acc_lo, 0, 0, 0);
-
-    // ---- reconstruct: residual t1[i = r][j = rho(h,g)]; 4 groups of 4 consecutive pixels per lane ----
-    uint8_t *rec = p.rec + base;
-#pragma unroll
-    for (int qd = 0; qd < 4; qd++) {
-        const int off = r * 32 + 8 * qd + 4 * h;
-        const unsigned pv = pv_cur[qd];
-        unsigned out = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int g = 4 * qd + e;
-            const int res = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 12);
-            const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
-            out |= (unsigned)v << (8 * e);
+        for (int w = 0; w < 4; w++) {
+            const int off = pix_off(r, 16 * h + 4 * w);
+            const bool ok = tu_first + off / (N * N) < p.count;
+            s_next[w] = ok ? *reinterpret_cast<const int *>(p.pix + b + off) : 0;
+            p_next[w] = ok ? *reinterpret_cast<const int *>(p.pred + b + off) : 0;
         }
-        *reinterpret_cast<unsigned *>(rec + off) = out;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const int off = pix_off(r, 8 * qd + 4 * h);
+            pv_next[qd] = tu_first + off / (N * N) < p.count ? *reinterpret_cast<const unsigned *>(p.pred + b + off) : 0u;
+        }
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) {
+            const int tu = tu_first + rb * NB + cb;
+            qpf_next[rb] = tu < p.count ? ((int)p.qp[tu] | ((int)p.flags[tu] << 8)) : -1;
+        }
+    };
+    if (t0 < ntiles) fetch(t0);
+    for (int tile = t0; tile < ntiles; tile += t_step) {
+        const int tu_first = tile * S;
+        const size_t base = (size_t)tu_first * (N * N);
+        v4i s_frag = s_next, p_frag = p_next;
+        unsigned pv_cur[4];
+        int qpf[NB];
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) pv_cur[qd] = pv_next[qd];
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) qpf[rb] = qpf_next[rb];
+        if (tile + t_step < ntiles) fetch(tile + t_step);
+
+        // ---- F1: residual rows x M^T ----
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            s_frag[w] ^= (int)0x80808080u;
+            p_frag[w] ^= (int)0x80808080u;
+        }
+        v16i acc;
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[g] = 1 << (LG - 2);   // rounding of the >> (log2 N - 1)
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag, m_nat, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag, m_neg, acc, 0, 0, 0);
+        int t[16];
+#pragma unroll
+        for (int g = 0; g < 16; g++) t[g] = acc[g] >> (LG - 1);          // tmp[k = r][i = rho(h,g)], fits int16
+
+        // ---- F2: M x D1 ----
+        v4i hi, lo;
+        slice16(t, hi, lo);
+        v16i acc_hi, acc_lo;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            acc_hi[g] = 0;
+            // rounding of the >> (log2 N + 6) + 128 * rowsum(M[k]) (only the DC row of each block has a non-zero sum)
+            acc_lo[g] = (1 << (LG + 5)) + (rho(h, g) % N == 0 ? 128 * 64 * N : 0);
+        }
+        acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
+
+        // ---- quant / dequant on coef[k = rho(h,g)][i = r]; the TU (and its qp) depends on the row block of g ----
+        int q[NB], qbits[NB], qrnd[NB], dscale[NB];
+        uint32_t local[NB];
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) {
+            const int qp = qpf[rb] & 255, fl = (qpf[rb] >> 8) & 255;
+            qbits[rb] = 14 + qp / 6 + (15 - 8 - LG);
+            q[rb] = k_quant_scales[qp % 6];
+            qrnd[rb] = ((fl & 1) ? 171 : 85) << (qbits[rb] - 9);
+            dscale[rb] = k_inv_quant_scales[qp % 6] << (qp / 6);
+            local[rb] = 0;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int rb = (8 * (g >> 2)) / N;                             // = rho(h,g) / N for either h
+            const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
+            const int mag = (abs(c) * q[rb] + qrnd[rb]) >> qbits[rb];
+            local[rb] += (uint32_t)mag;
+            const int level = clip16(c < 0 ? -mag : mag);
+            if (qpf[rb] >= 0) p.out16[base + pix_off(rho(h, g), r)] = (int16_t)level;
+            t[g] = clip16((level * dscale[rb] + (1 << (LG - 2))) >> (LG - 1));
+        }
+#pragma unroll
+        for (int rb = 0; rb < NB; rb++) {
+            uint32_t v = local[rb];
+#pragma unroll
+            for (int sh = 1; sh < N; sh <<= 1) v += (uint32_t)__shfl_xor((int)v, sh);   // the N lanes of the column block
+            v += (uint32_t)__shfl_xor((int)v, 32);                                      // both lane halves
+            if (r % N == 0 && h == 0 && qpf[rb] >= 0) p.sum[tu_first + rb * NB + cb] = v;
+        }
+
+        // ---- I1: D2^T x M ----
+        slice16(t, hi, lo);
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            acc_hi[g] = 0;
+            acc_lo[g] = (1 << 6) + cs_lane;
+        }
+        acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 16; g++) t[g] = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 7);   // t0[i = rho(h,g)][j = r]
+
+        // ---- I2: M^T x D3 ----
+        slice16(t, hi, lo);
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            acc_hi[g] = 0;
+            acc_lo[g] = cs_reg[g];
+        }
+        acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, hi, acc_hi, 0, 0, 0);
+        acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, lo, acc_lo, 0, 0, 0);
+
+        // ---- reconstruct: residual t1[i = r][j = rho(h,g)]; 4 groups of 4 consecutive pixels per lane ----
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++) {
+            const int off = pix_off(r, 8 * qd + 4 * h);
+            const unsigned pv = pv_cur[qd];
+            unsigned out = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int g = 4 * qd + e;
+                const int res = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 12);
+                const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
+                out |= (unsigned)v << (8 * e);
+            }
+            if (tu_first + off / (N * N) < p.count) *reinterpret_cast<unsigned *>(p.rec + base + off) = out;
+        }
     }
-    }  // TU loop
+}
+
+template <int N>
+int launch_mfma(const TuParams &p, hipStream_t st)
+{
+    constexpr int S = (32 / N) * (32 / N);
+    const int tiles = (p.count + S - 1) / S;
+    const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;   // 8 workgroups per CU; wavefronts loop over tiles
+    hipLaunchKernelGGL((tu_mfma_kernel<N>), dim3(blocks), dim3(256), 0, st, p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
 }
 
 template <int MODE>
@@ -403,11 +455,11 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     XMI_ARG(count == 0 || (d_pix && d_pred && d_qp && d_flags && d_level && d_rec && d_sum), "xmi_tu_chain_batch_dev: null argument");
     TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
 #ifndef XMI_EXP_TU_VALU
-    if (n == 32 && count > 0 && ((((uintptr_t)d_pix | (uintptr_t)d_pred) & 15) == 0) && (((uintptr_t)d_rec & 3) == 0)) {
-        const int blocks = (count + 3) / 4 < 2048 ? (count + 3) / 4 : 2048;   // 8 workgroups per CU, each wavefront loops over its TUs
-        hipLaunchKernelGGL(tu32_mfma_kernel, dim3(blocks), dim3(256), 0, xmi::as_stream(stream), p);
-        XMI_HIP(hipGetLastError());
-        return XMI_OK;
+    // 8x8 .. 32x32 run on the matrix cores; 4x4 (per-TU DCT/DST choice) stays on the VALU path
+    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec) & 3) == 0) {
+        if (n == 32) return launch_mfma<32>(p, xmi::as_stream(stream));
+        if (n == 16) return launch_mfma<16>(p, xmi::as_stream(stream));
+        return launch_mfma<8>(p, xmi::as_stream(stream));
     }
 #endif
     return launch<MODE_CHAIN>(n, p, xmi::as_stream(stream));
