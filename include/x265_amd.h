@@ -78,6 +78,15 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
 int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *ref_origin, int pad,
                     uint16_t *sad8, uint16_t *sad16, uint32_t *sad32, uint32_t *sad64);
 
+/* ---- quarter-pel luma interpolation planes ---------------------------------------------------
+ * Replaces the per-block filtering of xPredInterLumaBlk (src/pixel.cpp:8745-8795; filters src/pixel.cpp:7705,
+ * 8137, 8690; taps src/table.cpp:525-530) by one pass per reference frame: plane[(yFrac*4 + xFrac)] holds, at
+ * every position of the padded reference buffer, the sample xPredInterLumaBlk would produce there for that
+ * phase, so   pred(x0,y0,mv)[i][j] = plane[(mv.y&3)*4 + (mv.x&3)][y0 + (mv.y>>2) + i][x0 + (mv.x>>2) + j].
+ * d_ref_base: top-left of the padded buffer (`rows` x `stride` bytes, `cols` valid per row); d_planes: 16
+ * planes of rows*stride bytes each. Samples closer than 4 to the buffer edge are not written. */
+int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, void *stream);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

@@ -47,6 +47,9 @@ def load():
     L.xmi_sad_surface_dev.argtypes = [C.POINTER(SadGeom), vp, vp, vp, vp, vp, vp, i, i, vp]
     L.xmi_sad_surface.restype = i
     L.xmi_sad_surface.argtypes = [C.POINTER(SadGeom), vp, vp, i, vp, vp, vp, vp]
+    if hasattr(L, "xmi_interp_planes_dev"):
+        L.xmi_interp_planes_dev.restype = i
+        L.xmi_interp_planes_dev.argtypes = [vp, i, i, i, vp, vp]
     if hasattr(L, "xmi_block_metric_batch_dev"):
         L.xmi_block_metric_batch_dev.restype = i
         L.xmi_block_metric_batch_dev.argtypes = [i, i, i, vp, vp, vp, vp]
