@@ -87,6 +87,32 @@ int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *re
  * planes of rows*stride bytes each. Samples closer than 4 to the buffer edge are not written. */
 int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, void *stream);
 
+/* ---- batched motion search ------------------------------------------------------------------
+ * Replays xMotionSearch (src/encode.cpp:2815-3003) for `n` independent PUs: same candidate order, same cost,
+ * same tie-breaking and early exits, same clip quirk - so MV, cost, SAD of the chosen predictor and predictor
+ * index equal the reference's out-parameters. Sub-pel candidates read the interpolation planes made by
+ * xmi_interp_planes_dev from the previous reconstruction (pixel (0,0) of the frame at (pad, pad) of every
+ * plane); integer candidates read plane 0. The caller must guarantee what the reference's frame padding
+ * guarantees: every block a candidate can address lies at least 4 samples inside the padded buffer.
+ * Requests: PU origin and size (8/16/32/64; x0, y0 multiples of 4), the two MV predictors (quarter-pel), bZeroMV,
+ * the integer clip box of xCuMvClip (src/encode.cpp:3794) and (UInt32)sqrt(lambda). me_range = ME_RANGE (32). */
+typedef struct xmi_me_request {
+    int32_t x0, y0, size;
+    int16_t mvp[2][2];            /* [candidate][x,y] */
+    int32_t zero_mv_tested;
+    int16_t mv_min_ipel[2], mv_max_ipel[2];
+    uint32_t sqrt_lambda;
+} xmi_me_request;
+typedef struct xmi_me_result {
+    int16_t mv[2];                /* returned quarter-pel MV */
+    uint32_t best_cost;           /* *uiBestRDCostY */
+    uint32_t best_sad;            /* *pSad_best */
+    int32_t mvp_idx;              /* *pMVPIdx */
+    int32_t n_int_sads, n_sub_sads;
+} xmi_me_result;
+int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows, int pad,
+                            const xmi_me_request *d_req, int n, int me_range, xmi_me_result *d_res, void *stream);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

@@ -1,0 +1,103 @@
+"""GPU: batched xMotionSearch replay (xmi_me_search_batch_dev) against the oracle's restatement of
+src/encode.cpp:2815-3003 on synthetic moving video. Every out-parameter must match exactly."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from x265_amd import capi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+PAD = 80
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = capi.load()
+    capi.check(lib.xmi_init(0))
+    return lib
+
+
+def make_video(w, h, seed, motion=(3, 2), noise=6):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h + 2 * PAD, 0:w + 2 * PAD]
+    base = 128 + 60 * np.sin(xx / 17.0) + 40 * np.cos(yy / 11.0) + 25 * np.sin((xx + 2 * yy) / 5.0)
+    ref = np.clip(base + rng.integers(-noise, noise + 1, base.shape), 0, 255).astype(np.uint8)
+    dx, dy = motion
+    cur = np.clip(ref[PAD + dy:PAD + dy + h, PAD + dx:PAD + dx + w].astype(int) + rng.integers(-noise, noise + 1, (h, w)), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(cur), np.ascontiguousarray(ref)
+
+
+def run_case(L, orc, w, h, seed, nreq, motion, lambdas, noise=6):
+    cur, ref = make_video(w, h, seed, motion, noise)
+    rows, stride = ref.shape
+    d_ref = torch.from_numpy(ref).cuda()
+    planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_interp_planes_dev(d_ref.data_ptr(), stride, rows, stride, planes.data_ptr(), None))
+    d_cur = torch.from_numpy(cur).cuda()
+    rng = np.random.default_rng(seed + 1)
+    reqs = (capi.MeRequest * nreq)()
+    for i in range(nreq):
+        n = int(rng.choice([8, 16, 32, 64]))
+        rq = reqs[i]
+        rq.size = n
+        rq.x0 = int(rng.integers(0, (w - n) // 8 + 1)) * 8
+        rq.y0 = int(rng.integers(0, (h - n) // 8 + 1)) * 8
+        style = i % 4
+        near = (-4 * motion[0] + int(rng.integers(-6, 7)), -4 * motion[1] + int(rng.integers(-6, 7)))
+        if style == 0:      # both predictors near the true motion
+            m0, m1 = near, (near[0] + int(rng.integers(-3, 4)), near[1] + int(rng.integers(-3, 4)))
+        elif style == 1:    # far apart: two MVP passes
+            m0, m1 = (int(rng.integers(-200, 201)), int(rng.integers(-200, 201))), near
+        elif style == 2:    # zero predictors
+            m0, m1 = (0, 0), (0, 0)
+        else:               # anything
+            m0, m1 = (int(rng.integers(-256, 257)), int(rng.integers(-256, 257))), (int(rng.integers(-256, 257)), int(rng.integers(-256, 257)))
+        rq.mvp[0][0], rq.mvp[0][1], rq.mvp[1][0], rq.mvp[1][1] = m0[0], m0[1], m1[0], m1[1]
+        rq.zero_mv_tested = int(rng.integers(0, 2))
+        lim = 64 if i % 7 else int(rng.integers(2, 40))      # sometimes a tight clip box
+        rq.mv_min_ipel[0], rq.mv_min_ipel[1] = -lim, -(64 if i % 5 else lim // 2)
+        rq.mv_max_ipel[0], rq.mv_max_ipel[1] = lim, 64 if i % 3 else lim
+        rq.sqrt_lambda = int(math.sqrt(lambdas[i % len(lambdas)]))
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_me_search_batch_dev(d_cur.data_ptr(), cur.strides[0], planes.data_ptr(), stride, rows, PAD,
+                                         d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
+    torch.cuda.synchronize()
+    res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
+    blk = np.zeros((64, 64), np.uint8)
+    moved = 0
+    for i in range(nreq):
+        rq = reqs[i]
+        n = rq.size
+        blk[:] = 0
+        blk[:n, :n] = cur[rq.y0:rq.y0 + n, rq.x0:rq.x0 + n]
+        mvp = (O.OrcMV * 2)(O.OrcMV(rq.mvp[0][0], rq.mvp[0][1]), O.OrcMV(rq.mvp[1][0], rq.mvp[1][1]))
+        out = O.OrcMEResult()
+        orc.orc_motion_search(O.p(blk), O.at(ref, PAD + rq.y0, PAD + rq.x0), ref.strides[0], n, mvp, rq.zero_mv_tested,
+                              O.OrcMV(rq.mv_min_ipel[0], rq.mv_min_ipel[1]), O.OrcMV(rq.mv_max_ipel[0], rq.mv_max_ipel[1]),
+                              float(lambdas[i % len(lambdas)]), 32, C.byref(out))
+        got = (res[i].mv[0], res[i].mv[1], res[i].best_cost, res[i].best_sad, res[i].mvp_idx, res[i].n_int_sads, res[i].n_sub_sads)
+        want = (out.mv.x, out.mv.y, out.best_cost, out.best_sad, out.mvp_idx, out.n_int_sads, out.n_sub_sads)
+        assert got == want, f"request {i} (size {n} at {rq.x0},{rq.y0}): gpu {got} oracle {want}"
+        moved += out.n_int_sads > 6
+    return moved
+
+
+def test_me_search_matches_oracle(L):
+    orc = O.load()
+    # lambda of P slices: 0.578 * 2^((QP-12)/3) for QP 22/27/32/37 (src/encode.cpp:5406)
+    lambdas = [0.578 * 2 ** ((qp - 12) / 3.0) for qp in (22, 27, 32, 37)] + [400.0, 2500.0]
+    moved = run_case(L, orc, 256, 192, seed=5, nreq=240, motion=(3, 2), lambdas=lambdas)
+    assert moved > 20       # the diamond walk is exercised, not only the early exits
+    run_case(L, orc, 192, 128, seed=9, nreq=120, motion=(-7, 5), lambdas=lambdas, noise=2)
+    run_case(L, orc, 128, 128, seed=2, nreq=60, motion=(0, 0), lambdas=[1.0, 50.0], noise=0)   # exact match: cost < 800 exits
+
+
+def test_me_search_empty_and_errors(L):
+    assert L.xmi_me_search_batch_dev(None, 0, None, 0, 0, 0, None, 0, 32, None, None) == 0
+    a = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert L.xmi_me_search_batch_dev(a.data_ptr(), 6, a.data_ptr(), 8, 8, 0, a.data_ptr(), 1, 32, a.data_ptr(), None) == -1

@@ -20,6 +20,17 @@ class SadGeom(C.Structure):
                 ("range", C.c_int)]
 
 
+class MeRequest(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_int32), ("mvp", (C.c_int16 * 2) * 2),
+                ("zero_mv_tested", C.c_int32), ("mv_min_ipel", C.c_int16 * 2), ("mv_max_ipel", C.c_int16 * 2),
+                ("sqrt_lambda", C.c_uint32)]
+
+
+class MeResult(C.Structure):
+    _fields_ = [("mv", C.c_int16 * 2), ("best_cost", C.c_uint32), ("best_sad", C.c_uint32), ("mvp_idx", C.c_int32),
+                ("n_int_sads", C.c_int32), ("n_sub_sads", C.c_int32)]
+
+
 _lib = None
 
 
@@ -50,6 +61,9 @@ def load():
     if hasattr(L, "xmi_interp_planes_dev"):
         L.xmi_interp_planes_dev.restype = i
         L.xmi_interp_planes_dev.argtypes = [vp, i, i, i, vp, vp]
+    if hasattr(L, "xmi_me_search_batch_dev"):
+        L.xmi_me_search_batch_dev.restype = i
+        L.xmi_me_search_batch_dev.argtypes = [vp, i, vp, i, i, i, vp, i, i, vp, vp]
     if hasattr(L, "xmi_block_metric_batch_dev"):
         L.xmi_block_metric_batch_dev.restype = i
         L.xmi_block_metric_batch_dev.argtypes = [i, i, i, vp, vp, vp, vp]
