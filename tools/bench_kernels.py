@@ -61,3 +61,45 @@ for metric, name in ((capi.METRIC_SAD, "sad"), (capi.METRIC_SATD_HM, "satd_hm"),
         print(json.dumps({"kernel": f"{name} {n}x{n}", "count": cnt, "ms": round(t * 1e3, 3), "Meval_per_s": round(cnt / t / 1e6, 1),
                           "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
         del a, b
+
+# ---- interpolation planes + batched motion-search replay on a 1080p frame pair ----
+import ctypes as C  # noqa: E402
+import math  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+
+W, H, PAD = 1920, 1088, 80
+f0, f1 = B.synth_frame(W, H, 0, 7), B.synth_frame(W, H, 1, 7)
+ref = torch.from_numpy(B.pad_frame(f0, PAD)).cuda()
+cur = torch.from_numpy(f1).cuda()
+rows, stride = ref.shape
+planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+t = timeit(lambda: capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, rows, stride, planes.data_ptr(), s)))
+by = rows * stride * 17
+print(json.dumps({"kernel": "interp_planes 1080p (+pad 80)", "ms": round(t * 1e3, 3), "GBps": round(by / t / 1e9, 1),
+                  "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+rng = np.random.default_rng(3)
+for size, nreq in ((8, 28000), (16, 9500), (32, 2400), (64, 600), (0, 39000)):
+    reqs = (capi.MeRequest * nreq)()
+    for i in range(nreq):
+        n = size or int(rng.choice([8, 8, 8, 8, 8, 8, 16, 16, 32, 64]))
+        rq = reqs[i]
+        rq.size = n
+        rq.x0 = int(rng.integers(0, (W - n) // 8 + 1)) * 8
+        rq.y0 = int(rng.integers(0, (H - n) // 8 + 1)) * 8
+        rq.mvp[0][0], rq.mvp[0][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+        rq.mvp[1][0], rq.mvp[1][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+        rq.zero_mv_tested = 0
+        rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+        rq.sqrt_lambda = int(math.sqrt(0.578 * 2 ** ((22 - 12) / 3.0)))
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+    t = timeit(lambda: capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD,
+                                                            d_req.data_ptr(), nreq, 32, d_res.data_ptr(), s)), iters=5)
+    res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
+    sads = sum(r.n_int_sads + r.n_sub_sads for r in res)
+    print(json.dumps({"kernel": f"me_search {'mixed' if not size else str(size) + 'x' + str(size)}", "requests": nreq, "ms": round(t * 1e3, 3),
+                      "Msearch_per_s": round(nreq / t / 1e6, 2), "sads_per_search": round(sads / nreq, 1),
+                      "Msad_per_s": round(sads / t / 1e6, 1)}))
