@@ -25,7 +25,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak; measured copy ceiling is ~6.3 TB/s
-PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/config.h:52)
+PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/config.h:52); grown to R+16 for R > 64
+
+
+def measured_traffic(w, h, rng):
+    """HBM bytes per launch from the committed PMC passes of this workload (x265_amd/measured_traffic.json), else None.
+    Counters cannot be collected from inside this process; tools/profile_round.sh refreshes the file."""
+    try:
+        with open(os.path.join(ROOT, "x265_amd", "measured_traffic.json")) as f:
+            return json.load(f).get(f"{w}x{h}_R{rng}", {}).get("bytes_per_launch")
+    except OSError:
+        return None
 
 
 def synth_frame(w, h, t, seed):
@@ -86,6 +96,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global PAD
+    PAD = max(PAD, args.range + 16)
 
     import torch
     import torch.distributed as dist
@@ -179,7 +191,7 @@ def main():
                        "cands_per_step": cands, "frames_per_s": round(args.steps * world / elapsed, 2),
                        "parallelism": f"gop-segments x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(w, h, R),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),
                          "kernel_ms_min": round(kern_ms[0], 4)},
         }

@@ -11,6 +11,7 @@ Functions called (mangled C++ names; signatures from inc/x265.h:650-670 and src/
   xCalcHADs4x4/8x8/16x16/32x32/64x64, xCalcHADs32x32_test   src/pixel.cpp:63-527
   xSubDct / xQuant / xDeQuant / xIDctAdd                      src/pixel.cpp:3446, 1054, 1244, 5938
   xPredInterLumaBlk                                           src/pixel.cpp:8745
+  xMotionSearch (from oracle/_ref/libx265ref_me.so, `make -C oracle ref_me`)   src/encode.cpp:2815
 """
 import ctypes as C
 import os
@@ -21,6 +22,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "..", "tests", "golden")
 LIB = os.path.join(HERE, "_ref", "libx265ref_pixel.so")
+LIB_ME = os.path.join(HERE, "_ref", "libx265ref_me.so")
 
 SLICE_P, SLICE_I, MODE_INVALID = 1, 2, 255
 
@@ -241,7 +243,73 @@ def main():
         out[f"ref{n}"], out[f"mv{n}"], out[f"pred{n}"] = frames, mvs, res
     out["origin"] = np.array([16, 16], np.int32)
     np.savez_compressed(os.path.join(OUT, "interp.npz"), **out)
+    if os.path.exists(LIB_ME):
+        gen_me()
+    else:
+        print("skipping me_search.npz: make -C oracle ref_me first")
     print("golden vectors written to", os.path.normpath(OUT))
+
+
+def gen_me():
+    """Motion-search known answers: the reference's compiled xMotionSearch (src/encode.cpp:2815-3003, with the
+    reference's ME_RANGE, MV_CLIP, MVD_COST_BY_TABLE and SATD_FOR_FRAC_ME settings) on seeded moving video.
+    Stored per clip: cur, padded ref, request table and the four outputs."""
+    lib = C.CDLL(LIB_ME)
+    fme = lib._Z13xMotionSearchPKhS0_PsjjjPjP3xMVPiiS3_S3_dS2_
+    fme.restype = XMV
+    fme.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint, C.c_uint, C.POINTER(C.c_uint32),
+                    C.POINTER(XMV), C.POINTER(C.c_int), C.c_int, XMV, XMV, C.c_double, C.POINTER(C.c_uint)]
+    PAD = 80
+    out = {}
+    lambdas = [0.578 * 2 ** ((qp - 12) / 3.0) for qp in (22, 27, 32, 37)] + [400.0, 2500.0]
+    clips = (("a", 192, 128, 11, (3, 2), 6, 200), ("b", 128, 128, 12, (-7, 5), 2, 120), ("c", 128, 64, 13, (0, 0), 0, 60))
+    for tag, w, h, seed, motion, noise, nreq in clips:
+        rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[0:h + 2 * PAD, 0:w + 2 * PAD]
+        base = 128 + 60 * np.sin(xx / 17.0) + 40 * np.cos(yy / 11.0) + 25 * np.sin((xx + 2 * yy) / 5.0)
+        ref = aligned(base.shape, np.uint8)
+        ref[:] = np.clip(base + rng.integers(-noise, noise + 1, base.shape), 0, 255).astype(np.uint8)
+        dx, dy = motion
+        cur = np.clip(ref[PAD + dy:PAD + dy + h, PAD + dx:PAD + dx + w].astype(int)
+                      + rng.integers(-noise, noise + 1, (h, w)), 0, 255).astype(np.uint8)
+        # request columns: x0 y0 size mvp0x mvp0y mvp1x mvp1y zero_tested minx miny maxx maxy lambda_index
+        req = np.zeros((nreq, 13), np.int32)
+        res = np.zeros((nreq, 5), np.int64)   # mvx mvy best_cost best_sad mvp_idx
+        blk = aligned((64, 64), np.uint8)
+        tmp = aligned(((64 + 16) * 64,), np.int16)
+        for i in range(nreq):
+            n = int(rng.choice([8, 16, 32, 64]))
+            x0 = int(rng.integers(0, (w - n) // 8 + 1)) * 8
+            y0 = int(rng.integers(0, (h - n) // 8 + 1)) * 8
+            near = (-4 * dx + int(rng.integers(-6, 7)), -4 * dy + int(rng.integers(-6, 7)))
+            style = i % 4
+            if style == 0:
+                m0, m1 = near, (near[0] + int(rng.integers(-3, 4)), near[1] + int(rng.integers(-3, 4)))
+            elif style == 1:
+                m0, m1 = (int(rng.integers(-200, 201)), int(rng.integers(-200, 201))), near
+            elif style == 2:
+                m0, m1 = (0, 0), (0, 0)
+            else:
+                m0 = (int(rng.integers(-256, 257)), int(rng.integers(-256, 257)))
+                m1 = (int(rng.integers(-256, 257)), int(rng.integers(-256, 257)))
+            zero = int(rng.integers(0, 2))
+            lim = 64 if i % 7 else int(rng.integers(6, 40))
+            mn = (-lim, -(64 if i % 5 else max(lim // 2, 5)))
+            mx = (lim, 64 if i % 3 else lim)
+            li = i % len(lambdas)
+            req[i] = (x0, y0, n, m0[0], m0[1], m1[0], m1[1], zero, mn[0], mn[1], mx[0], mx[1], li)
+            blk[:] = 0
+            blk[:n, :n] = cur[y0:y0 + n, x0:x0 + n]
+            mvp = (XMV * 2)(XMV(*m0), XMV(*m1))
+            cost, sad, idx = C.c_uint32(0), C.c_uint(0), C.c_int(-7)
+            origin = C.c_void_p(ref.ctypes.data + (PAD + y0) * ref.strides[0] + PAD + x0)
+            mv = fme(ptr(blk), origin, ptr(tmp), ref.strides[0], n, n, C.byref(cost), mvp, C.byref(idx), zero,
+                     XMV(*mn), XMV(*mx), lambdas[li], C.byref(sad))
+            res[i] = (mv.x, mv.y, cost.value, sad.value, idx.value)
+        out[f"{tag}_cur"], out[f"{tag}_ref"], out[f"{tag}_req"], out[f"{tag}_res"] = cur, np.array(ref), req, res
+    out["lambdas"] = np.array(lambdas, np.float64)
+    out["pad"] = np.array([PAD], np.int32)
+    np.savez_compressed(os.path.join(OUT, "me_search.npz"), **out)
 
 
 if __name__ == "__main__":
