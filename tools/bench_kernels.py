@@ -30,8 +30,9 @@ def timeit(fn, iters=20):
     return a.elapsed_time(b) / iters * 1e-3
 
 
+ONLY = os.environ.get("XMI_BENCH_ONLY", "")     # "", "tu", "metric" or "me"
 g = torch.Generator(device="cuda").manual_seed(1)
-for n in (4, 8, 16, 32):
+for n in (4, 8, 16, 32) if ONLY in ("", "tu") else ():
     cnt = (256 << 20) // (n * n)
     pix = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
     pred = (pix.to(torch.int16) + torch.randint(-12, 13, pix.shape, dtype=torch.int16, device="cuda", generator=g)).clamp(0, 255).to(torch.uint8)
@@ -48,7 +49,7 @@ for n in (4, 8, 16, 32):
                       "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
     del pix, pred, lev, rec
 for metric, name in ((capi.METRIC_SAD, "sad"), (capi.METRIC_SATD_HM, "satd_hm"), (capi.METRIC_SATD_X264, "satd_x264"), (capi.METRIC_SSD, "ssd")):
-    for n in (4, 8, 16, 32, 64):
+    for n in (4, 8, 16, 32, 64) if ONLY in ("", "metric") else ():
         if metric == capi.METRIC_SATD_X264 and n > 16:
             continue
         cnt = (256 << 20) // (n * n)
@@ -62,6 +63,8 @@ for metric, name in ((capi.METRIC_SAD, "sad"), (capi.METRIC_SATD_HM, "satd_hm"),
                           "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
         del a, b
 
+if ONLY not in ("", "me"):
+    sys.exit(0)
 # ---- interpolation planes + batched motion-search replay on a 1080p frame pair ----
 import ctypes as C  # noqa: E402
 import math  # noqa: E402

@@ -4,7 +4,8 @@ set -e
 name=$1; shift
 mkdir -p build/variants/obj_$name
 for f in x265_amd/csrc/*.hip; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $f -o build/variants/obj_$name/$(basename $f .hip).o &
+  extra=""; [ "$(basename $f)" = tu_chain.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o build/variants/obj_$name/$(basename $f .hip).o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC build/variants/obj_$name/*.o -o build/variants/libx265_amd_$name.so

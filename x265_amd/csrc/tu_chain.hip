@@ -216,23 +216,41 @@ __device__ __forceinline__ void slice16(const int (&t)[16], v4i &hi, v4i &lo)
     }
 }
 
+// sum over aligned groups of W consecutive lanes (W = 8, 16 or 32); the total lands in the last lane of each group
+template <int W>
+__device__ __forceinline__ int group_sum_to_last_lane(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    if (W >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    if (W >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    return v;
+}
+
 // N = 32: one TU per 32x32 tile. N = 16 / 8: a tile holds (32/N)^2 independent TUs side by side and the
 // constant operand is the block-diagonal matrix diag(M_N, ..): block (a,b) of M R M^T is then M_N R_ab M_N^T,
 // so the same four products transform every TU of the tile at once (TU t of tile s: t = s*S + a*(32/N) + b).
+// A lane holds column r of a result tile and the 16 rows rho(h, 0..15): four groups of four consecutive rows
+// (group w = rows 8w+4h .. 8w+4h+3), so it sees G = min(4, 32/N) TUs of its column block; slot(w) names them.
 template <int N>
 __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 {
     constexpr int NB = 32 / N;            // TUs per tile row / column
     constexpr int S = NB * NB;            // TUs per tile
     constexpr int LG = N == 32 ? 5 : N == 16 ? 4 : 3;
-    __shared__ int s_colsum[32];
+    constexpr int G = N == 32 ? 1 : N == 16 ? 2 : 4;
+    auto slot = [](int w) { return N == 32 ? 0 : N == 16 ? (w >> 1) : w; };
+    __shared__ __align__(16) int s_colsum[32];
     __shared__ int8_t s_m[32 * 33];       // block-diagonal core matrix, built once per workgroup
+    __shared__ int2 s_qtab[52];           // per qp: { quant scale | qbits << 16, dequant scale << qp/6 }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     for (int e = tid; e < 1024; e += 256) {
         const int k = e >> 5, j = e & 31;
         s_m[k * 33 + j] = (k / N == j / N) ? (int8_t)dct_coef(N, k % N, j % N) : (int8_t)0;
     }
+    if (tid < 52) s_qtab[tid] = make_int2(k_quant_scales[tid % 6] | ((14 + tid / 6 + (15 - 8 - LG)) << 16), k_inv_quant_scales[tid % 6] << (tid / 6));
     __syncthreads();
     if (tid < 32) {
         int sum = 0;
@@ -260,53 +278,66 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         m_colperm[w] = (int)c;
         m_rowperm[w] = (int)d;
     }
-    const int cs_lane = 128 * s_colsum[r];
-    int cs_reg[16];
-#pragma unroll
-    for (int g = 0; g < 16; g++) cs_reg[g] = (1 << 11) + 128 * s_colsum[rho(h, g)];
+    const int cs_lane = (1 << 6) + 128 * s_colsum[r];
+    __syncthreads();
+    if (tid < 32) s_colsum[tid] = (1 << 11) + 128 * s_colsum[tid];      // accumulator input of the last product, per output row
+    __syncthreads();
 
     // byte offset of pixel (row, col) of a tile inside the packed TU arrays, relative to the tile's first TU
     auto pix_off = [](int row, int col) { return ((row / N) * NB + col / N) * (N * N) + (row % N) * N + col % N; };
-    const int ntiles = (p.count + S - 1) / S;
+    const int ntiles = p.count / S;       // whole tiles only: the host sends the remainder of a batch to tu_kernel
     const int cb = r / N;                 // this lane's column block in every result tile
+    int tu_rel[G];                        // tile-relative index of the TU of slot s
+#pragma unroll
+    for (int sl = 0; sl < G; sl++) tu_rel[sl] = sl * NB + cb;
 
-    // software pipeline: the operands of the next tile are requested before the current one is computed
-    const int t0 = blockIdx.x * 4 + wave, t_step = gridDim.x * 4;
+    // software pipeline: the operands of the next tile are requested before the current one is computed.
+    // Nothing is derived from them until the next iteration, so no wait separates the requests from the arithmetic.
+    const int t0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), t_step = gridDim.x * 4;   // wavefront-uniform
     v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
-    unsigned pv_next[4] = { 0, 0, 0, 0 };
-    int qpf_next[NB];                     // qp | flags << 8 of TU (rb, cb) for rb = 0..NB-1; -1 = TU beyond count
+    int qp_next[G], fl_next[G];
+#pragma unroll
+    for (int sl = 0; sl < G; sl++) qp_next[sl] = fl_next[sl] = 0;
     auto fetch = [&](int tile) {
         const int tu_first = tile * S;
         const size_t b = (size_t)tu_first * (N * N);
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const int off = pix_off(r, 16 * h + 4 * w);
-            const bool ok = tu_first + off / (N * N) < p.count;
-            s_next[w] = ok ? *reinterpret_cast<const int *>(p.pix + b + off) : 0;
-            p_next[w] = ok ? *reinterpret_cast<const int *>(p.pred + b + off) : 0;
+            const unsigned off = (unsigned)pix_off(r, 16 * h + 4 * w);
+            s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
+            p_next[w] = *reinterpret_cast<const int *>(p.pred + b + off);
         }
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) {
-            const int off = pix_off(r, 8 * qd + 4 * h);
-            pv_next[qd] = tu_first + off / (N * N) < p.count ? *reinterpret_cast<const unsigned *>(p.pred + b + off) : 0u;
-        }
-#pragma unroll
-        for (int rb = 0; rb < NB; rb++) {
-            const int tu = tu_first + rb * NB + cb;
-            qpf_next[rb] = tu < p.count ? ((int)p.qp[tu] | ((int)p.flags[tu] << 8)) : -1;
+        for (int sl = 0; sl < G; sl++) {
+            qp_next[sl] = (int)p.qp[tu_first + tu_rel[sl]];
+            fl_next[sl] = (int)p.flags[tu_first + tu_rel[sl]];
         }
     };
+    auto claim = [&]() {
+#pragma unroll
+        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]));
+#pragma unroll
+        for (int sl = 0; sl < G; sl++) asm volatile("" : "+v"(qp_next[sl]), "+v"(fl_next[sl]));
+    };
     if (t0 < ntiles) fetch(t0);
+    claim();
     for (int tile = t0; tile < ntiles; tile += t_step) {
         const int tu_first = tile * S;
         const size_t base = (size_t)tu_first * (N * N);
         v4i s_frag = s_next, p_frag = p_next;
-        unsigned pv_cur[4];
-        int qpf[NB];
+        int q[G], qbits[G], qadd_pos[G], qadd_neg[G], dscale[G];
+        const v4i p_raw = p_next;
 #pragma unroll
-        for (int qd = 0; qd < 4; qd++) pv_cur[qd] = pv_next[qd];
-#pragma unroll
-        for (int rb = 0; rb < NB; rb++) qpf[rb] = qpf_next[rb];
+        for (int sl = 0; sl < G; sl++) {
+            // xQuant: level = sign(c) * ((|c| * Q + rnd) >> qbits). With floor division by 2^qbits this is
+            // (c * Q + rnd) >> qbits for c >= 0 and (c * Q + (2^qbits - 1 - rnd)) >> qbits for c < 0.
+            const int2 e = s_qtab[min(qp_next[sl], 51)];
+            q[sl] = e.x & 0xffff;
+            qbits[sl] = e.x >> 16;
+            dscale[sl] = e.y;
+            qadd_pos[sl] = (85 + 86 * (fl_next[sl] & 1)) << (qbits[sl] - 9);   // 171 for I slices, 85 otherwise
+            qadd_neg[sl] = (1 << qbits[sl]) - 1 - qadd_pos[sl];
+        }
         if (tile + t_step < ntiles) fetch(tile + t_step);
 
         // ---- F1: residual rows x M^T ----
@@ -337,35 +368,24 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
 
-        // ---- quant / dequant on coef[k = rho(h,g)][i = r]; the TU (and its qp) depends on the row block of g ----
-        int q[NB], qbits[NB], qrnd[NB], dscale[NB];
-        uint32_t local[NB];
+        // ---- quant / dequant on coef[k = rho(h,g)][i = r]; the TU (and its qp) depends on the row group of g ----
+        int local[G];
 #pragma unroll
-        for (int rb = 0; rb < NB; rb++) {
-            const int qp = qpf[rb] & 255, fl = (qpf[rb] >> 8) & 255;
-            qbits[rb] = 14 + qp / 6 + (15 - 8 - LG);
-            q[rb] = k_quant_scales[qp % 6];
-            qrnd[rb] = ((fl & 1) ? 171 : 85) << (qbits[rb] - 9);
-            dscale[rb] = k_inv_quant_scales[qp % 6] << (qp / 6);
-            local[rb] = 0;
-        }
+        for (int sl = 0; sl < G; sl++) local[sl] = 0;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
-            const int rb = (8 * (g >> 2)) / N;                             // = rho(h,g) / N for either h
-            const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
-            const int mag = (abs(c) * q[rb] + qrnd[rb]) >> qbits[rb];
-            local[rb] += (uint32_t)mag;
-            const int level = clip16(c < 0 ? -mag : mag);
-            if (qpf[rb] >= 0) p.out16[base + pix_off(rho(h, g), r)] = (int16_t)level;
-            t[g] = clip16((level * dscale[rb] + (1 << (LG - 2))) >> (LG - 1));
+            const int sl = slot(g >> 2);
+            const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);            // |c| < 2^15 for 8-bit video
+            const int level = (__mul24(c, q[sl]) + (c < 0 ? qadd_neg[sl] : qadd_pos[sl])) >> qbits[sl];   // |level| < 2^14: no clipping
+            local[sl] += abs(level);
+            p.out16[base + pix_off(rho(h, g), r)] = (int16_t)level;
+            t[g] = clip16((__mul24(level, dscale[sl]) + (1 << (LG - 2))) >> (LG - 1));   // xDeQuant
         }
 #pragma unroll
-        for (int rb = 0; rb < NB; rb++) {
-            uint32_t v = local[rb];
-#pragma unroll
-            for (int sh = 1; sh < N; sh <<= 1) v += (uint32_t)__shfl_xor((int)v, sh);   // the N lanes of the column block
-            v += (uint32_t)__shfl_xor((int)v, 32);                                      // both lane halves
-            if (r % N == 0 && h == 0 && qpf[rb] >= 0) p.sum[tu_first + rb * NB + cb] = v;
+        for (int sl = 0; sl < G; sl++) {
+            int v = local[sl] + __shfl_xor(local[sl], 32);                      // both lane halves
+            v = group_sum_to_last_lane<N>(v);                                   // the N lanes of the column block
+            if (r % N == N - 1 && h == 0) p.sum[tu_first + tu_rel[sl]] = (uint32_t)v;
         }
 
         // ---- I1: D2^T x M ----
@@ -373,7 +393,7 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             acc_hi[g] = 0;
-            acc_lo[g] = (1 << 6) + cs_lane;
+            acc_lo[g] = cs_lane;
         }
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
@@ -383,14 +403,37 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         // ---- I2: M^T x D3 ----
         slice16(t, hi, lo);
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            acc_hi[g] = 0;
-            acc_lo[g] = cs_reg[g];
+        for (int g = 0; g < 16; g++) acc_hi[g] = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {       // rows rho(h, 4w .. 4w+3) = 8w + 4h .. + 3
+            const int4 c4 = *reinterpret_cast<const int4 *>(&s_colsum[8 * w + 4 * h]);
+            acc_lo[4 * w + 0] = c4.x;
+            acc_lo[4 * w + 1] = c4.y;
+            acc_lo[4 * w + 2] = c4.z;
+            acc_lo[4 * w + 3] = c4.w;
         }
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, hi, acc_hi, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, lo, acc_lo, 0, 0, 0);
 
-        // ---- reconstruct: residual t1[i = r][j = rho(h,g)]; 4 groups of 4 consecutive pixels per lane ----
+        // The prefetched registers are claimed here, before the last stores of the iteration are issued: the wait
+        // the compiler places in front of this statement then covers the loads (requested most of an iteration
+        // ago) but none of the stores that follow, and nothing is pending when the next iteration starts.
+        claim();
+
+        // ---- reconstruct: residual t1[i = r][j = rho(h,g)]; 4 groups of 4 consecutive pixels per lane. The int16
+        // clip of the residual is dropped: a residual beyond +-32767 saturates the 8-bit sum either way. ----
+        // prediction bytes of the lane's output pixels (row r, columns 8 qd + 4h .. + 3): half of them sit in the
+        // partner lane (r, 1 - h) of the A fragment; v_permlane32_swap trades lanes 32..63 of its first operand
+        // against lanes 0..31 of its second
+        unsigned pv_cur[4];
+        {
+            const auto x = __builtin_amdgcn_permlane32_swap((unsigned)p_raw[0], (unsigned)p_raw[1], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap((unsigned)p_raw[2], (unsigned)p_raw[3], false, false);
+            pv_cur[0] = x[0];
+            pv_cur[2] = x[1];
+            pv_cur[1] = y[0];
+            pv_cur[3] = y[1];
+        }
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
             const int off = pix_off(r, 8 * qd + 4 * h);
@@ -399,11 +442,11 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int g = 4 * qd + e;
-                const int res = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 12);
+                const int res = ((acc_hi[g] << 8) + acc_lo[g]) >> 12;
                 const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
                 out |= (unsigned)v << (8 * e);
             }
-            if (tu_first + off / (N * N) < p.count) *reinterpret_cast<unsigned *>(p.rec + base + off) = out;
+            *reinterpret_cast<unsigned *>(p.rec + base + off) = out;
         }
     }
 }
@@ -412,10 +455,19 @@ template <int N>
 int launch_mfma(const TuParams &p, hipStream_t st)
 {
     constexpr int S = (32 / N) * (32 / N);
-    const int tiles = (p.count + S - 1) / S;
-    const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;   // 8 workgroups per CU; wavefronts loop over tiles
-    hipLaunchKernelGGL((tu_mfma_kernel<N>), dim3(blocks), dim3(256), 0, st, p);
-    XMI_HIP(hipGetLastError());
+    const int tiles = p.count / S;
+    if (tiles > 0) {
+        const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;   // 8 workgroups per CU; wavefronts loop over tiles
+        hipLaunchKernelGGL((tu_mfma_kernel<N>), dim3(blocks), dim3(256), 0, st, p);
+        XMI_HIP(hipGetLastError());
+    }
+    const int rest = p.count - tiles * S;                                     // < S TUs: one partial tile, on the VALU kernel
+    if (rest > 0) {
+        const size_t tu0 = (size_t)tiles * S, px0 = tu0 * N * N;
+        TuParams q = { p.pix + px0, p.pred + px0, p.qp + tu0, p.flags + tu0, nullptr, p.out16 + px0, p.rec + px0, p.sum + tu0, rest };
+        hipLaunchKernelGGL((tu_kernel<N, MODE_CHAIN>), dim3((rest + Cfg<N>::TUS - 1) / Cfg<N>::TUS), dim3(256), 0, st, q);
+        XMI_HIP(hipGetLastError());
+    }
     return XMI_OK;
 }
 
