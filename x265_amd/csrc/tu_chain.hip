@@ -204,13 +204,22 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int rho(int h, int g) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
-// pack bits 15:8 (signed high byte) and bits 7:0 minus 128 of 16 ints into two 16-byte MFMA fragments
+// pack bits 15:8 (signed high byte) and bits 7:0 minus 128 of 16 ints into two 16-byte MFMA fragments.
+// SAT: the ints are first clipped to int16 (v_cvt_pk_i16_i32 packs two of them with signed saturation).
+template <bool SAT>
 __device__ __forceinline__ void slice16(const int (&t)[16], v4i &hi, v4i &lo)
 {
+    typedef short s2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const unsigned p01 = __builtin_amdgcn_perm((unsigned)t[4 * w + 1], (unsigned)t[4 * w + 0], 0x05040100u);
-        const unsigned p23 = __builtin_amdgcn_perm((unsigned)t[4 * w + 3], (unsigned)t[4 * w + 2], 0x05040100u);
+        unsigned p01, p23;
+        if (SAT) {
+            p01 = __builtin_bit_cast(unsigned, (s2)__builtin_amdgcn_cvt_pk_i16(t[4 * w + 0], t[4 * w + 1]));
+            p23 = __builtin_bit_cast(unsigned, (s2)__builtin_amdgcn_cvt_pk_i16(t[4 * w + 2], t[4 * w + 3]));
+        } else {
+            p01 = __builtin_amdgcn_perm((unsigned)t[4 * w + 1], (unsigned)t[4 * w + 0], 0x05040100u);
+            p23 = __builtin_amdgcn_perm((unsigned)t[4 * w + 3], (unsigned)t[4 * w + 2], 0x05040100u);
+        }
         hi[w] = (int)__builtin_amdgcn_perm(p23, p01, 0x07050301u);
         lo[w] = (int)(__builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080u);
     }
@@ -230,7 +239,8 @@ __device__ __forceinline__ int group_sum_to_last_lane(int v)
 
 // N = 32: one TU per 32x32 tile. N = 16 / 8: a tile holds (32/N)^2 independent TUs side by side and the
 // constant operand is the block-diagonal matrix diag(M_N, ..): block (a,b) of M R M^T is then M_N R_ab M_N^T,
-// so the same four products transform every TU of the tile at once (TU t of tile s: t = s*S + a*(32/N) + b).
+// so the same four products transform every TU of the tile at once (TU t of tile s sits at block row a, block
+// column b with t = s*S + b*(32/N) + a, so the TUs a lane works on are consecutive).
 // A lane holds column r of a result tile and the 16 rows rho(h, 0..15): four groups of four consecutive rows
 // (group w = rows 8w+4h .. 8w+4h+3), so it sees G = min(4, 32/N) TUs of its column block; slot(w) names them.
 template <int N>
@@ -284,20 +294,15 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     __syncthreads();
 
     // byte offset of pixel (row, col) of a tile inside the packed TU arrays, relative to the tile's first TU
-    auto pix_off = [](int row, int col) { return ((row / N) * NB + col / N) * (N * N) + (row % N) * N + col % N; };
+    auto pix_off = [](int row, int col) { return ((col / N) * NB + row / N) * (N * N) + (row % N) * N + col % N; };
     const int ntiles = p.count / S;       // whole tiles only: the host sends the remainder of a batch to tu_kernel
     const int cb = r / N;                 // this lane's column block in every result tile
-    int tu_rel[G];                        // tile-relative index of the TU of slot s
-#pragma unroll
-    for (int sl = 0; sl < G; sl++) tu_rel[sl] = sl * NB + cb;
-
+    const int tu_rel0 = cb * NB;          // tile-relative index of the first TU of the lane's column block (slot s: + s)
     // software pipeline: the operands of the next tile are requested before the current one is computed.
     // Nothing is derived from them until the next iteration, so no wait separates the requests from the arithmetic.
     const int t0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), t_step = gridDim.x * 4;   // wavefront-uniform
     v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
-    int qp_next[G], fl_next[G];
-#pragma unroll
-    for (int sl = 0; sl < G; sl++) qp_next[sl] = fl_next[sl] = 0;
+    unsigned qp_next = 0, fl_next = 0;    // G consecutive bytes each
     auto fetch = [&](int tile) {
         const int tu_first = tile * S;
         const size_t b = (size_t)tu_first * (N * N);
@@ -307,17 +312,21 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
             s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
             p_next[w] = *reinterpret_cast<const int *>(p.pred + b + off);
         }
-#pragma unroll
-        for (int sl = 0; sl < G; sl++) {
-            qp_next[sl] = (int)p.qp[tu_first + tu_rel[sl]];
-            fl_next[sl] = (int)p.flags[tu_first + tu_rel[sl]];
+        if (G == 1) {
+            qp_next = p.qp[tu_first + tu_rel0];
+            fl_next = p.flags[tu_first + tu_rel0];
+        } else if (G == 2) {
+            qp_next = *reinterpret_cast<const uint16_t *>(p.qp + tu_first + tu_rel0);
+            fl_next = *reinterpret_cast<const uint16_t *>(p.flags + tu_first + tu_rel0);
+        } else {
+            qp_next = *reinterpret_cast<const uint32_t *>(p.qp + tu_first + tu_rel0);
+            fl_next = *reinterpret_cast<const uint32_t *>(p.flags + tu_first + tu_rel0);
         }
     };
     auto claim = [&]() {
 #pragma unroll
         for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]));
-#pragma unroll
-        for (int sl = 0; sl < G; sl++) asm volatile("" : "+v"(qp_next[sl]), "+v"(fl_next[sl]));
+        asm volatile("" : "+v"(qp_next), "+v"(fl_next));
     };
     if (t0 < ntiles) fetch(t0);
     claim();
@@ -325,19 +334,8 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         const int tu_first = tile * S;
         const size_t base = (size_t)tu_first * (N * N);
         v4i s_frag = s_next, p_frag = p_next;
-        int q[G], qbits[G], qadd_pos[G], qadd_neg[G], dscale[G];
+        const unsigned qp_cur = qp_next, fl_cur = fl_next;
         const v4i p_raw = p_next;
-#pragma unroll
-        for (int sl = 0; sl < G; sl++) {
-            // xQuant: level = sign(c) * ((|c| * Q + rnd) >> qbits). With floor division by 2^qbits this is
-            // (c * Q + rnd) >> qbits for c >= 0 and (c * Q + (2^qbits - 1 - rnd)) >> qbits for c < 0.
-            const int2 e = s_qtab[min(qp_next[sl], 51)];
-            q[sl] = e.x & 0xffff;
-            qbits[sl] = e.x >> 16;
-            dscale[sl] = e.y;
-            qadd_pos[sl] = (85 + 86 * (fl_next[sl] & 1)) << (qbits[sl] - 9);   // 171 for I slices, 85 otherwise
-            qadd_neg[sl] = (1 << qbits[sl]) - 1 - qadd_pos[sl];
-        }
         if (tile + t_step < ntiles) fetch(tile + t_step);
 
         // ---- F1: residual rows x M^T ----
@@ -357,51 +355,77 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 
         // ---- F2: M x D1 ----
         v4i hi, lo;
-        slice16(t, hi, lo);
+        slice16<false>(t, hi, lo);
+        // Accumulator inputs are rebuilt per tile from a register the compiler cannot see through: kept as loop
+        // invariants they would pin 32 VGPRs and cost a wavefront of occupancy.
+        int zero = 0, bias1 = cs_lane;
+        asm volatile("" : "+v"(zero), "+v"(bias1));
         v16i acc_hi, acc_lo;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             acc_hi[g] = 0;
             // rounding of the >> (log2 N + 6) + 128 * rowsum(M[k]) (only the DC row of each block has a non-zero sum)
-            acc_lo[g] = (1 << (LG + 5)) + (rho(h, g) % N == 0 ? 128 * 64 * N : 0);
+            acc_lo[g] = zero + ((1 << (LG + 5)) + (rho(h, g) % N == 0 ? 128 * 64 * N : 0));
         }
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
 
         // ---- quant / dequant on coef[k = rho(h,g)][i = r]; the TU (and its qp) depends on the row group of g ----
-        int local[G];
+        // xQuant: level = sign(c) * ((|c| * Q + rnd) >> qbits). With floor division by 2^qbits this is
+        // (c * Q + rnd) >> qbits for c >= 0 and (c * Q + (2^qbits - 1 - rnd)) >> qbits for c < 0.
+        int q = 0, qbits = 0, qadd_pos = 0, qadd_neg = 0, dscale = 0, local = 0;
 #pragma unroll
-        for (int sl = 0; sl < G; sl++) local[sl] = 0;
+        for (int w = 0; w < 4; w++) {
+            const int sl = slot(w);
+            if (w == 0 || slot(w) != slot(w - 1)) {      // parameters of the TU of this row group
+                const int2 e = s_qtab[min((qp_cur >> (8 * sl)) & 255u, 51u)];
+                q = e.x & 0xffff;
+                qbits = e.x >> 16;
+                dscale = e.y;
+                qadd_pos = (85 + 86 * (int)((fl_cur >> (8 * sl)) & 1u)) << (qbits - 9);   // 171 for I slices, 85 otherwise
+                qadd_neg = (1 << qbits) - 1 - qadd_pos;
+                local = 0;
+            }
+            int lvl[4];
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int sl = slot(g >> 2);
-            const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);            // |c| < 2^15 for 8-bit video
-            const int level = (__mul24(c, q[sl]) + (c < 0 ? qadd_neg[sl] : qadd_pos[sl])) >> qbits[sl];   // |level| < 2^14: no clipping
-            local[sl] += abs(level);
-            p.out16[base + pix_off(rho(h, g), r)] = (int16_t)level;
-            t[g] = clip16((__mul24(level, dscale[sl]) + (1 << (LG - 2))) >> (LG - 1));   // xDeQuant
-        }
+            for (int e4 = 0; e4 < 4; e4++) {
+                const int g = 4 * w + e4;
+                const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);            // |c| < 2^15 for 8-bit video
+                const int level = (__mul24(c, q) + (c < 0 ? qadd_neg : qadd_pos)) >> qbits;   // |level| < 2^14: no clipping
+                local += abs(level);
+                lvl[e4] = level;
+                t[g] = (__mul24(level, dscale) + (1 << (LG - 2))) >> (LG - 1);   // xDeQuant; clipped to int16 by the slicing
+            }
+            // Level rows 8w + 4h + e of column r: trading lane halves between registers e and e + 1 leaves rows
+            // 8w + e (+ 4) in lanes 0..31 and rows 8w + e + 1 (+ 4) in lanes 32..63, so that one store instruction
+            // writes two adjacent 64-byte rows = one full 128-byte line.
 #pragma unroll
-        for (int sl = 0; sl < G; sl++) {
-            int v = local[sl] + __shfl_xor(local[sl], 32);                      // both lane halves
-            v = group_sum_to_last_lane<N>(v);                                   // the N lanes of the column block
-            if (r % N == N - 1 && h == 0) p.sum[tu_first + tu_rel[sl]] = (uint32_t)v;
+            for (int e4 = 0; e4 < 4; e4 += 2) {
+                const auto x = __builtin_amdgcn_permlane32_swap((unsigned)lvl[e4], (unsigned)lvl[e4 + 1], false, false);
+                p.out16[base + pix_off(8 * w + e4 + h, r)] = (int16_t)x[0];
+                p.out16[base + pix_off(8 * w + 4 + e4 + h, r)] = (int16_t)x[1];
+            }
+            if (w == 3 || slot(w + 1) != slot(w)) {      // sum of |level| of this TU
+                int v = local + __shfl_xor(local, 32);                          // both lane halves
+                v = group_sum_to_last_lane<N>(v);                               // the N lanes of the column block
+                if (r % N == N - 1 && h == 0) p.sum[tu_first + tu_rel0 + sl] = (uint32_t)v;
+            }
         }
 
         // ---- I1: D2^T x M ----
-        slice16(t, hi, lo);
+        slice16<true>(t, hi, lo);
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             acc_hi[g] = 0;
-            acc_lo[g] = cs_lane;
+            acc_lo[g] = bias1;
         }
         acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
         acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
 #pragma unroll
-        for (int g = 0; g < 16; g++) t[g] = clip16(((acc_hi[g] << 8) + acc_lo[g]) >> 7);   // t0[i = rho(h,g)][j = r]
+        for (int g = 0; g < 16; g++) t[g] = ((acc_hi[g] << 8) + acc_lo[g]) >> 7;   // t0[i = rho(h,g)][j = r], clipped by the slicing
 
         // ---- I2: M^T x D3 ----
-        slice16(t, hi, lo);
+        slice16<true>(t, hi, lo);
 #pragma unroll
         for (int g = 0; g < 16; g++) acc_hi[g] = 0;
 #pragma unroll
@@ -434,19 +458,29 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
             pv_cur[1] = y[0];
             pv_cur[3] = y[1];
         }
+        unsigned out[4];
 #pragma unroll
         for (int qd = 0; qd < 4; qd++) {
-            const int off = pix_off(r, 8 * qd + 4 * h);
             const unsigned pv = pv_cur[qd];
-            unsigned out = 0;
+            out[qd] = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int g = 4 * qd + e;
                 const int res = ((acc_hi[g] << 8) + acc_lo[g]) >> 12;
                 const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
-                out |= (unsigned)v << (8 * e);
+                out[qd] |= (unsigned)v << (8 * e);
             }
-            *reinterpret_cast<unsigned *>(p.rec + base + off) = out;
+        }
+        {   // back to the layout of the loads (row r, columns 16h .. 16h + 15): one 16-byte store per lane
+            const auto x = __builtin_amdgcn_permlane32_swap(out[0], out[2], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(out[1], out[3], false, false);
+            v4i o = { (int)x[0], (int)x[1], (int)y[0], (int)y[1] };
+            if (N >= 16) {
+                *reinterpret_cast<v4i *>(p.rec + base + pix_off(r, 16 * h)) = o;
+            } else {   // 8x8: the 16 bytes span two TUs
+                *reinterpret_cast<int2 *>(p.rec + base + pix_off(r, 16 * h)) = make_int2(o[0], o[1]);
+                *reinterpret_cast<int2 *>(p.rec + base + pix_off(r, 16 * h + 8)) = make_int2(o[2], o[3]);
+            }
         }
     }
 }
@@ -508,7 +542,8 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
 #ifndef XMI_EXP_TU_VALU
     // 8x8 .. 32x32 run on the matrix cores; 4x4 (per-TU DCT/DST choice) stays on the VALU path
-    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec) & 3) == 0) {
+    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec) & 15) == 0 &&
+        (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 3) == 0) {
         if (n == 32) return launch_mfma<32>(p, xmi::as_stream(stream));
         if (n == 16) return launch_mfma<16>(p, xmi::as_stream(stream));
         return launch_mfma<8>(p, xmi::as_stream(stream));
