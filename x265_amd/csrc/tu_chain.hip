@@ -254,6 +254,10 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     __shared__ __align__(16) int s_colsum[32];
     __shared__ int8_t s_m[32 * 33];       // block-diagonal core matrix, built once per workgroup
     __shared__ int2 s_qtab[52];           // per qp: { quant scale | qbits << 16, dequant scale << qp/6 }
+    // per wavefront: the 1024 levels of a tile in memory order; 8x8 tiles skew each TU column by 16 bytes so that
+    // the four TU columns a store instruction touches fall into different banks
+    constexpr bool LVL_LDS = N == 8;
+    __shared__ __align__(16) int16_t s_lvl[LVL_LDS ? 4 : 1][LVL_LDS ? 1024 + 32 : 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     for (int e = tid; e < 1024; e += 256) {
@@ -297,6 +301,8 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     auto pix_off = [](int row, int col) { return ((col / N) * NB + row / N) * (N * N) + (row % N) * N + col % N; };
     const int ntiles = p.count / S;       // whole tiles only: the host sends the remainder of a batch to tu_kernel
     const int cb = r / N;                 // this lane's column block in every result tile
+    int16_t *lv = s_lvl[LVL_LDS ? wave : 0];
+    const int lv_skew_w = N == 8 ? cb * 8 : 0;
     const int tu_rel0 = cb * NB;          // tile-relative index of the first TU of the lane's column block (slot s: + s)
     // software pipeline: the operands of the next tile are requested before the current one is computed.
     // Nothing is derived from them until the next iteration, so no wait separates the requests from the arithmetic.
@@ -396,6 +402,7 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
                 lvl[e4] = level;
                 t[g] = (__mul24(level, dscale) + (1 << (LG - 2))) >> (LG - 1);   // xDeQuant; clipped to int16 by the slicing
             }
+            if (!LVL_LDS) {
             // Level rows 8w + 4h + e of column r: trading lane halves between registers e and e + 1 leaves rows
             // 8w + e (+ 4) in lanes 0..31 and rows 8w + e + 1 (+ 4) in lanes 32..63, so that one store instruction
             // writes two adjacent 64-byte rows = one full 128-byte line.
@@ -405,11 +412,25 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
                 p.out16[base + pix_off(8 * w + e4 + h, r)] = (int16_t)x[0];
                 p.out16[base + pix_off(8 * w + 4 + e4 + h, r)] = (int16_t)x[1];
             }
+            } else {
+            // 8x8 rows are only 16 bytes: the levels go through the wavefront's LDS patch (memory order) and leave
+            // as 16-byte stores, 1 KB per instruction
+#pragma unroll
+            for (int e4 = 0; e4 < 4; e4++) lv[pix_off(8 * w + 4 * h + e4, r) + lv_skew_w] = (int16_t)lvl[e4];
+            }
             if (w == 3 || slot(w + 1) != slot(w)) {      // sum of |level| of this TU
                 int v = local + __shfl_xor(local, 32);                          // both lane halves
                 v = group_sum_to_last_lane<N>(v);                               // the N lanes of the column block
                 if (r % N == N - 1 && h == 0) p.sum[tu_first + tu_rel0 + sl] = (uint32_t)v;
             }
+        }
+
+        if (LVL_LDS) {
+#pragma unroll
+        for (int c = lane; c < 128; c += 64) {           // chunk c = 8 consecutive levels in memory order
+            const v4i d = *reinterpret_cast<const v4i *>(lv + c * 8 + (N == 8 ? (c >> 5) * 8 : 0));
+            *reinterpret_cast<v4i *>(p.out16 + base + c * 8) = d;
+        }
         }
 
         // ---- I1: D2^T x M ----
@@ -542,7 +563,7 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
 #ifndef XMI_EXP_TU_VALU
     // 8x8 .. 32x32 run on the matrix cores; 4x4 (per-TU DCT/DST choice) stays on the VALU path
-    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec) & 15) == 0 &&
+    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec | (uintptr_t)d_level) & 15) == 0 &&
         (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 3) == 0) {
         if (n == 32) return launch_mfma<32>(p, xmi::as_stream(stream));
         if (n == 16) return launch_mfma<16>(p, xmi::as_stream(stream));
