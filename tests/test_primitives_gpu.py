@@ -176,6 +176,43 @@ def test_tu_chain_random_vs_oracle(L, orc, n):
         np.testing.assert_array_equal(rec[i], wr, err_msg=f"rec TU {i}")
 
 
+@pytest.mark.parametrize("n,cnt,style", [(4, 600_037, "mixed"), (4, 600_000, "dst"), (8, 140_005, "p"), (16, 40_003, "p"), (32, 9_001, "p")])
+def test_tu_chain_large_batch_matrix_core_vs_valu(L, n, cnt, style):
+    """More tiles than resident wavefronts (the persistent loop and its prefetch) plus a ragged tail: the
+    matrix-core kernels against the VALU kernel, which a misaligned per-TU array selects and which the
+    oracle tests above pin."""
+    g = torch.Generator(device="cuda").manual_seed(n + cnt)
+    pix = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
+    pred = (pix.to(torch.int16) + torch.randint(-40, 41, pix.shape, dtype=torch.int16, device="cuda", generator=g)).clamp(0, 255).to(torch.uint8)
+    pred[::7] = torch.randint(0, 256, pred[::7].shape, dtype=torch.uint8, device="cuda", generator=g)
+    qp_buf = torch.randint(0, 52, (cnt + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    fl_buf = torch.randint(0, 2, (cnt + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    if style == "mixed":      # DCT and DST TUs interleaved in runs of random length, so tiles are uniform and mixed
+        runs = torch.randint(0, 2, ((cnt + 16) // 48 + 1,), dtype=torch.uint8, device="cuda", generator=g).repeat_interleave(48)[:cnt + 16]
+        fl_buf |= runs * 2
+    elif style == "dst":
+        fl_buf |= 2
+    outs = []
+    for shift in (0, 1):      # 0: aligned -> matrix cores; 1: per-TU arrays start at an odd address -> VALU kernel
+        qp = qp_buf[shift:shift + cnt]
+        fl = fl_buf[shift:shift + cnt]
+        if shift:             # same values at the shifted address
+            qp.copy_(qp_buf[:cnt].clone())
+            fl.copy_(fl_buf[:cnt].clone())
+        lev = torch.zeros((cnt, n, n), dtype=torch.int16, device="cuda")
+        rec = torch.zeros((cnt, n, n), dtype=torch.uint8, device="cuda")
+        sm = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+        capi.check(L.xmi_tu_chain_batch_dev(n, cnt, pix.data_ptr(), pred.data_ptr(), qp.data_ptr(), fl.data_ptr(),
+                                            lev.data_ptr(), rec.data_ptr(), sm.data_ptr(), None))
+        torch.cuda.synchronize()
+        outs.append((lev, rec, sm, qp.clone(), fl.clone()))
+    assert torch.equal(outs[0][3], outs[1][3]) and torch.equal(outs[0][4], outs[1][4])
+    assert torch.equal(outs[0][0], outs[1][0]), "levels differ"
+    assert torch.equal(outs[0][1], outs[1][1]), "reconstruction differs"
+    assert torch.equal(outs[0][2], outs[1][2]), "level sums differ"
+    assert outs[0][2].any()
+
+
 def test_tu_roundtrip_property_full_size(L):
     """size-independent property at a large batch: qp 0 on an all-equal block reconstructs it exactly, and
     a zero residual gives zero levels / rec == pred for every TU of the batch"""

@@ -11,6 +11,8 @@
 // The inner product runs on v_dot2c_i32_i16 over LDS-resident int16 rows with an odd dword pitch.
 #include "xmi_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -506,6 +508,245 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     }
 }
 
+// 4x4 chain on the matrix cores: a 32x32 tile holds 64 TUs (8x8 grid, TU t of tile s at block row a, block
+// column b with t = 64 s + 8 b + a) and the constant operand is diag(M4, ..) with M4 the DCT or, for TUs with
+// flag bit 1, the DST. A tile whose 64 TUs agree on the transform runs the chain once with that matrix; a mixed
+// tile runs it twice and each pass stores only its own TUs. Everything that depends on the matrix (operand
+// fragments, accumulator inputs) is read from LDS per pass, so nothing of it is pinned in registers.
+// Layouts along the chain (lane = (r, h), register group w = rows 8w + 4h .. + 3 of a result tile):
+//   loads / reconstruction:  lane row r, columns 16h + 4w .. + 3      -> TU (a = r/4, b = 4h + w)
+//   after F1, F2 (quant):     rows 8w + 4h + e, column r                -> TU (a = 2w + h, b = r/4)
+//   after I1, I2:             lane row r, columns 8w + 4h + e           -> TU (a = r/4, b = 2w + h)
+__global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
+{
+    constexpr int S = 64, LG = 2;
+    __shared__ __align__(16) v4i s_frag[2][4][64];     // [dct | dst][natural, negated, columns permuted, rows permuted][lane]
+    __shared__ __align__(16) int s_bias[2][12];        // [dct | dst]: F2 input by row % 4, I2 input by row % 4, I1 input by column % 4
+    __shared__ int2 s_qtab[52];                        // per qp: { quant scale | qbits << 16, dequant scale << qp/6 }
+    __shared__ __align__(16) int16_t s_lvl[4][1024];   // per wavefront: levels of a tile, TU (a, b) at (8a + b) * 16
+    __shared__ uint32_t s_sum[4][64];                  // per wavefront: sum of |level| of the 64 TUs, memory order
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    auto mat4 = [](int type, int k, int j) { return type ? (int)k_dst4[k * 4 + j] : dct_coef(4, k, j); };
+    auto mat = [&](int type, int k, int j) { return (k >> 2) == (j >> 2) ? mat4(type, k & 3, j & 3) : 0; };
+    for (int e = tid; e < 512; e += 256) {
+        const int type = e >> 8, kind = (e >> 6) & 3, rr = e & 31, hh = (e >> 5) & 1;
+        v4i f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            unsigned a = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int j = 4 * w + b;
+                const int v = kind == 0 ? mat(type, rr, 16 * hh + j) : kind == 1 ? -mat(type, rr, 16 * hh + j)
+                            : kind == 2 ? mat(type, rr, rho(hh, j)) : mat(type, rho(hh, j), rr);
+                a |= (unsigned)(v & 255) << (8 * b);
+            }
+            f[w] = (int)a;
+        }
+        s_frag[type][kind][e & 63] = f;
+    }
+    if (tid < 24) {
+        const int type = tid / 12, i = tid % 12, c = i & 3;
+        int rowsum = 0, colsum = 0;
+        for (int k = 0; k < 4; k++) {
+            rowsum += mat4(type, c, k);
+            colsum += mat4(type, k, c);
+        }
+        s_bias[type][i] = i < 4 ? (1 << (LG + 5)) + 128 * rowsum : i < 8 ? (1 << 11) + 128 * colsum : (1 << 6) + 128 * colsum;
+    }
+    if (tid < 52) s_qtab[tid] = make_int2(k_quant_scales[tid % 6] | ((14 + tid / 6 + (15 - 8 - LG)) << 16), k_inv_quant_scales[tid % 6] << (tid / 6));
+    __syncthreads();
+
+    auto pix_off = [](int row, int col) { return ((col >> 2) * 8 + (row >> 2)) * 16 + (row & 3) * 4 + (col & 3); };
+    const int ntiles = p.count / S;
+    int16_t *lv = s_lvl[wave];
+    uint32_t *sm = s_sum[wave];
+    const int t0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), t_step = gridDim.x * 4;
+    v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
+    uint2 qp_next = { 0, 0 }, fl_next = { 0, 0 };       // the 8 TUs of block column b = r/4, byte a
+    auto fetch = [&](int tile) {
+        const int tu_first = tile * S;
+        const size_t b = (size_t)tu_first * 16;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const unsigned off = (unsigned)pix_off(r, 16 * h + 4 * w);
+            s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
+            p_next[w] = *reinterpret_cast<const int *>(p.pred + b + off);
+        }
+        qp_next = *reinterpret_cast<const uint2 *>(p.qp + tu_first + (r >> 2) * 8);
+        fl_next = *reinterpret_cast<const uint2 *>(p.flags + tu_first + (r >> 2) * 8);
+    };
+    auto claim = [&]() {
+#pragma unroll
+        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]));
+        asm volatile("" : "+v"(qp_next.x), "+v"(qp_next.y), "+v"(fl_next.x), "+v"(fl_next.y));
+    };
+    if (t0 < ntiles) fetch(t0);
+    claim();
+    for (int tile = t0; tile < ntiles; tile += t_step) {
+        const int tu_first = tile * S;
+        const size_t base = (size_t)tu_first * 16;
+        const v4i s_raw = s_next, p_raw = p_next;
+        const uint2 qp_cur = qp_next, fl_cur = fl_next;
+        if (tile + t_step < ntiles) fetch(tile + t_step);
+
+        // prediction bytes in the reconstruction layout (row r, columns 8 qd + 4h .. + 3), see tu_mfma_kernel
+        unsigned pv_cur[4];
+        {
+            const auto x = __builtin_amdgcn_permlane32_swap((unsigned)p_raw[0], (unsigned)p_raw[1], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap((unsigned)p_raw[2], (unsigned)p_raw[3], false, false);
+            pv_cur[0] = x[0];
+            pv_cur[2] = x[1];
+            pv_cur[1] = y[0];
+            pv_cur[3] = y[1];
+        }
+
+        // uniform tile: one pass with its transform; mixed tile: a DCT pass and a DST pass, each storing its own TUs
+        const bool dst_lane = ((fl_cur.x & fl_cur.y) & 0x02020202u) == 0x02020202u;
+        const bool dct_lane = ((fl_cur.x | fl_cur.y) & 0x02020202u) == 0u;
+        const bool all_dst = __all(dst_lane), all_dct = __all(dct_lane);
+        const bool MIXED = !(all_dst || all_dct);
+        for (int pass_i = 0; pass_i < (MIXED ? 2 : 1); pass_i++) {
+            const int type = MIXED ? pass_i : (all_dst ? 1 : 0);
+            const v4i m_nat = s_frag[type][0][lane], m_neg = s_frag[type][1][lane];
+            const v4i m_colperm = s_frag[type][2][lane], m_rowperm = s_frag[type][3][lane];
+            const int4 b_f2 = *reinterpret_cast<const int4 *>(&s_bias[type][0]);
+            const int4 b_i2 = *reinterpret_cast<const int4 *>(&s_bias[type][4]);
+            const int b_i1 = s_bias[type][8 + (r & 3)];
+
+            // ---- F1 ----
+            v4i s_frag4, p_frag4;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                s_frag4[w] = s_raw[w] ^ (int)0x80808080u;
+                p_frag4[w] = p_raw[w] ^ (int)0x80808080u;
+            }
+            v16i acc;
+#pragma unroll
+            for (int g = 0; g < 16; g++) acc[g] = 1 << (LG - 2);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag4, m_nat, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag4, m_neg, acc, 0, 0, 0);
+            int t[16];
+#pragma unroll
+            for (int g = 0; g < 16; g++) t[g] = acc[g] >> (LG - 1);
+
+            // ---- F2 ----
+            v4i hi, lo;
+            slice16<false>(t, hi, lo);
+            v16i acc_hi, acc_lo;
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                acc_hi[g] = 0;
+                acc_lo[g] = (g & 3) == 0 ? b_f2.x : (g & 3) == 1 ? b_f2.y : (g & 3) == 2 ? b_f2.z : b_f2.w;
+            }
+            acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, hi, acc_hi, 0, 0, 0);
+            acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_colperm, lo, acc_lo, 0, 0, 0);
+
+            // ---- quant / dequant: register group w belongs to TU (a = 2w + h, b = r/4) ----
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const unsigned sh = 16 * (w & 1) + 8 * h;
+                const unsigned qpb = ((w < 2 ? qp_cur.x : qp_cur.y) >> sh) & 255u, flb = ((w < 2 ? fl_cur.x : fl_cur.y) >> sh) & 255u;
+                const bool mine = !MIXED || (int)((flb >> 1) & 1u) == type;
+                const int2 e = s_qtab[min(qpb, 51u)];
+                const int q = e.x & 0xffff, qbits = e.x >> 16, dscale = e.y;
+                const int qadd_pos = (85 + 86 * (int)(flb & 1u)) << (qbits - 9);
+                const int qadd_neg = (1 << qbits) - 1 - qadd_pos;
+                int local = 0;
+                const int a = 2 * w + h, b = r >> 2;
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++) {
+                    const int g = 4 * w + e4;
+                    const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
+                    const int level = (__mul24(c, q) + (c < 0 ? qadd_neg : qadd_pos)) >> qbits;
+                    local += abs(level);
+                    if (mine) lv[(a * 8 + b) * 16 + e4 * 4 + (r & 3)] = (int16_t)level;
+                    t[g] = (__mul24(level, dscale) + (1 << (LG - 2))) >> (LG - 1);
+                }
+                local += __builtin_amdgcn_update_dpp(0, local, 0x111, 0xf, 0xf, true);   // row_shr:1
+                local += __builtin_amdgcn_update_dpp(0, local, 0x112, 0xf, 0xf, true);   // row_shr:2
+                if ((r & 3) == 3 && mine) sm[b * 8 + a] = (uint32_t)local;
+            }
+
+            // ---- I1 ----
+            slice16<true>(t, hi, lo);
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                acc_hi[g] = 0;
+                acc_lo[g] = b_i1;
+            }
+            acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, m_rowperm, acc_hi, 0, 0, 0);
+            acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, m_rowperm, acc_lo, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 16; g++) t[g] = ((acc_hi[g] << 8) + acc_lo[g]) >> 7;
+
+            // ---- I2 ----
+            slice16<true>(t, hi, lo);
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                acc_hi[g] = 0;
+                acc_lo[g] = (g & 3) == 0 ? b_i2.x : (g & 3) == 1 ? b_i2.y : (g & 3) == 2 ? b_i2.z : b_i2.w;
+            }
+            acc_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, hi, acc_hi, 0, 0, 0);
+            acc_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(m_rowperm, lo, acc_lo, 0, 0, 0);
+
+            // ---- reconstruct (row r, columns 8 qd + 4h + e), then back to the layout of the loads ----
+            unsigned out[4];
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const unsigned pv = pv_cur[qd];
+                out[qd] = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int g = 4 * qd + e;
+                    const int res = ((acc_hi[g] << 8) + acc_lo[g]) >> 12;
+                    const int v = min(255, max(0, res + (int)((pv >> (8 * e)) & 255)));
+                    out[qd] |= (unsigned)v << (8 * e);
+                }
+            }
+            const auto x = __builtin_amdgcn_permlane32_swap(out[0], out[2], false, false);
+            const auto y = __builtin_amdgcn_permlane32_swap(out[1], out[3], false, false);
+            const unsigned o[4] = { x[0], x[1], y[0], y[1] };
+#pragma unroll
+            for (int w = 0; w < 4; w++) {      // TU (a = r/4, b = 4h + w)
+                bool mine = true;
+                if (MIXED) mine = (int)((p.flags[tu_first + (4 * h + w) * 8 + (r >> 2)] >> 1) & 1) == type;
+                if (mine) *reinterpret_cast<unsigned *>(p.rec + base + pix_off(r, 16 * h + 4 * w)) = o[w];
+            }
+        }
+        claim();
+
+        // levels: LDS patch -> memory order (TU t = 8b + a at t * 16), 16 bytes = two TU rows per lane and step
+#pragma unroll
+        for (int c = lane; c < 128; c += 64) {
+            const int tu = c >> 1, a = tu & 7, b = tu >> 3;
+            const v4i d = *reinterpret_cast<const v4i *>(lv + (a * 8 + b) * 16 + (c & 1) * 8);
+            *reinterpret_cast<v4i *>(p.out16 + base + c * 8) = d;
+        }
+        p.sum[tu_first + lane] = sm[lane];
+    }
+}
+
+int launch_mfma4(const TuParams &p, hipStream_t st)
+{
+    constexpr int S = 64;
+    const int tiles = p.count / S;
+    if (tiles > 0) {
+        const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;
+        hipLaunchKernelGGL(tu_mfma4_kernel, dim3(blocks), dim3(256), 0, st, p);
+        XMI_HIP(hipGetLastError());
+    }
+    const int rest = p.count - tiles * S;
+    if (rest > 0) {
+        const size_t tu0 = (size_t)tiles * S, px0 = tu0 * 16;
+        TuParams q = { p.pix + px0, p.pred + px0, p.qp + tu0, p.flags + tu0, nullptr, p.out16 + px0, p.rec + px0, p.sum + tu0, rest };
+        hipLaunchKernelGGL((tu_kernel<4, MODE_CHAIN>), dim3((rest + Cfg<4>::TUS - 1) / Cfg<4>::TUS), dim3(256), 0, st, q);
+        XMI_HIP(hipGetLastError());
+    }
+    return XMI_OK;
+}
+
 template <int N>
 int launch_mfma(const TuParams &p, hipStream_t st)
 {
@@ -562,9 +803,11 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     XMI_ARG(count == 0 || (d_pix && d_pred && d_qp && d_flags && d_level && d_rec && d_sum), "xmi_tu_chain_batch_dev: null argument");
     TuParams p = { d_pix, d_pred, d_qp, d_flags, nullptr, d_level, d_rec, d_sum, count };
 #ifndef XMI_EXP_TU_VALU
-    // 8x8 .. 32x32 run on the matrix cores; 4x4 (per-TU DCT/DST choice) stays on the VALU path
-    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec | (uintptr_t)d_level) & 15) == 0 &&
-        (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 3) == 0) {
+    // the matrix-core kernels want 16-byte aligned pixel/level arrays and word-aligned per-TU arrays; anything else
+    // (and the last partial tile of a batch) takes the VALU kernel
+    if (count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec | (uintptr_t)d_level) & 15) == 0 &&
+        (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 7) == 0) {
+        if (n == 4) return launch_mfma4(p, xmi::as_stream(stream));
         if (n == 32) return launch_mfma<32>(p, xmi::as_stream(stream));
         if (n == 16) return launch_mfma<16>(p, xmi::as_stream(stream));
         return launch_mfma<8>(p, xmi::as_stream(stream));
