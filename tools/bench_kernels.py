@@ -47,7 +47,20 @@ for n in (4, 8, 16, 32) if ONLY in ("", "tu") else ():
     by = cnt * (5 * n * n + 4)
     print(json.dumps({"kernel": f"tu_chain {n}x{n}", "count": cnt, "ms": round(t * 1e3, 3), "MTU_per_s": round(cnt / t / 1e6, 1),
                       "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
-    del pix, pred, lev, rec
+    # the four stages on their own (xSubDct, xQuant, xDeQuant, xIDctAdd batches)
+    coef = torch.empty((cnt, n, n), dtype=torch.int16, device="cuda")
+    stages = (
+        ("sub_dct", 4 * n * n, lambda: L.xmi_sub_dct_batch_dev(n, cnt, pix.data_ptr(), pred.data_ptr(), fl.data_ptr(), coef.data_ptr(), s)),
+        ("quant", 4 * n * n + 4, lambda: L.xmi_quant_batch_dev(n, cnt, coef.data_ptr(), qp.data_ptr(), fl.data_ptr(), lev.data_ptr(), sm.data_ptr(), s)),
+        ("dequant", 4 * n * n, lambda: L.xmi_dequant_batch_dev(n, cnt, lev.data_ptr(), qp.data_ptr(), coef.data_ptr(), s)),
+        ("idct_add", 4 * n * n, lambda: L.xmi_idct_add_batch_dev(n, cnt, coef.data_ptr(), pred.data_ptr(), fl.data_ptr(), rec.data_ptr(), s)),
+    )
+    for name, bpt, fn in stages:
+        t = timeit(lambda: capi.check(fn()))
+        by = cnt * bpt
+        print(json.dumps({"kernel": f"{name} {n}x{n}", "count": cnt, "ms": round(t * 1e3, 3), "MTU_per_s": round(cnt / t / 1e6, 1),
+                          "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+    del pix, pred, lev, rec, coef
 for metric, name in ((capi.METRIC_SAD, "sad"), (capi.METRIC_SATD_HM, "satd_hm"), (capi.METRIC_SATD_X264, "satd_x264"), (capi.METRIC_SSD, "ssd")):
     for n in (4, 8, 16, 32, 64) if ONLY in ("", "metric") else ():
         if metric == capi.METRIC_SATD_X264 and n > 16:

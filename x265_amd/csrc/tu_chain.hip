@@ -227,16 +227,98 @@ __device__ __forceinline__ void slice16(const int (&t)[16], v4i &hi, v4i &lo)
     }
 }
 
-// sum over aligned groups of W consecutive lanes (W = 8, 16 or 32); the total lands in the last lane of each group
+// sum over aligned groups of W consecutive lanes (W = 2 .. 64); the total lands in the last lane of each group
 template <int W>
 __device__ __forceinline__ int group_sum_to_last_lane(int v)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    if (W >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
-    if (W >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);                 // row_shr:1
+    if (W >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    if (W >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    if (W >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    if (W >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1 and 3
+    if (W >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// xQuant / xDeQuant on their own are streaming kernels: a wavefront takes 1024 coefficients (whole TUs) per step,
+// 8 per lane and 16-byte access, fully coalesced; the per-TU sum of |level| is a segmented DPP reduction.
+typedef short v8s __attribute__((ext_vector_type(8)));
+
+template <int N, bool DEQUANT>
+__global__ void __launch_bounds__(256) quant_stream_kernel(const TuParams p)
+{
+    constexpr int LG = Cfg<N>::LOG2, NN = N * N;
+    constexpr int LPT = NN / 8 < 64 ? NN / 8 : 64;       // lanes per TU within one 512-coefficient half step
+    __shared__ int2 s_qtab[52];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 52) s_qtab[tid] = make_int2(k_quant_scales[tid % 6] | ((14 + tid / 6 + (15 - 8 - LG)) << 16), k_inv_quant_scales[tid % 6] << (tid / 6));
+    __syncthreads();
+    const size_t total = (size_t)p.count * NN;            // coefficients, a multiple of 16
+    const size_t nsteps = (total + 1023) / 1024;
+    for (size_t step = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave); step < nsteps; step += (size_t)gridDim.x * 4) {
+        int part[2] = { 0, 0 };
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const size_t e0 = step * 1024 + half * 512 + lane * 8;
+            if (e0 < total) {
+                const int tu = (int)(e0 / NN);
+                const v8s c = *reinterpret_cast<const v8s *>(p.coef_in + e0);
+                const int2 e = s_qtab[min((int)p.qp[tu], 51)];
+                v8s o;
+                if (DEQUANT) {
+                    const int dscale = e.y;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) o[k] = (short)clip16((__mul24((int)c[k], dscale) + (1 << (LG - 2))) >> (LG - 1));
+                } else {
+                    const int q = e.x & 0xffff, qbits = e.x >> 16;
+                    const int qrnd = (85 + 86 * (p.flags ? (int)(p.flags[tu] & 1) : 0)) << (qbits - 9);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int v = c[k];
+                        const int mag = (int)((__umul24((unsigned)abs(v), (unsigned)q) + (unsigned)qrnd) >> qbits);
+                        part[half] += mag;
+                        o[k] = (short)clip16(v < 0 ? -mag : mag);
+                    }
+                }
+                *reinterpret_cast<v8s *>(p.out16 + e0) = o;
+            }
+        }
+        if (!DEQUANT) {
+            if (N == 32) {          // both halves belong to one TU
+                const int v = group_sum_to_last_lane<64>(part[0] + part[1]);
+                const size_t tu = step;
+                if (lane == 63 && tu < (size_t)p.count) p.sum[tu] = (uint32_t)v;
+            } else {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int v = group_sum_to_last_lane<LPT>(part[half]);
+                    const size_t tu = (step * 1024 + half * 512 + lane * 8) / NN;
+                    if ((lane & (LPT - 1)) == LPT - 1 && tu < (size_t)p.count) p.sum[tu] = (uint32_t)v;
+                }
+            }
+        }
+    }
+}
+
+template <int N, bool DEQUANT>
+int launch_quant_stream(const TuParams &p, hipStream_t st)
+{
+    const size_t nsteps = ((size_t)p.count * N * N + 1023) / 1024;
+    const int blocks = (int)((nsteps + 3) / 4 < 8192 ? (nsteps + 3) / 4 : 8192);
+    hipLaunchKernelGGL((quant_stream_kernel<N, DEQUANT>), dim3(blocks), dim3(256), 0, st, p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+template <bool DEQUANT>
+int launch_quant_stream_n(int n, const TuParams &p, hipStream_t st)
+{
+    switch (n) {
+    case 4: return launch_quant_stream<4, DEQUANT>(p, st);
+    case 8: return launch_quant_stream<8, DEQUANT>(p, st);
+    case 16: return launch_quant_stream<16, DEQUANT>(p, st);
+    default: return launch_quant_stream<32, DEQUANT>(p, st);
+    }
 }
 
 // N = 32: one TU per 32x32 tile. N = 16 / 8: a tile holds (32/N)^2 independent TUs side by side and the
@@ -245,7 +327,9 @@ __device__ __forceinline__ int group_sum_to_last_lane(int v)
 // column b with t = s*S + b*(32/N) + a, so the TUs a lane works on are consecutive).
 // A lane holds column r of a result tile and the 16 rows rho(h, 0..15): four groups of four consecutive rows
 // (group w = rows 8w+4h .. 8w+4h+3), so it sees G = min(4, 32/N) TUs of its column block; slot(w) names them.
-template <int N>
+// MODE_CHAIN: the whole chain. MODE_SUBDCT: F1, F2 and the coefficients are stored (xSubDct). MODE_IDCT: the
+// coefficients are read, I1, I2 and the reconstruction follow (xIDctAdd).
+template <int N, int MODE>
 __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 {
     constexpr int NB = 32 / N;            // TUs per tile row / column
@@ -256,10 +340,13 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     __shared__ __align__(16) int s_colsum[32];
     __shared__ int8_t s_m[32 * 33];       // block-diagonal core matrix, built once per workgroup
     __shared__ int2 s_qtab[52];           // per qp: { quant scale | qbits << 16, dequant scale << qp/6 }
-    // per wavefront: the 1024 levels of a tile in memory order; 8x8 tiles skew each TU column by 16 bytes so that
-    // the four TU columns a store instruction touches fall into different banks
-    constexpr bool LVL_LDS = N == 8;
-    __shared__ __align__(16) int16_t s_lvl[LVL_LDS ? 4 : 1][LVL_LDS ? 1024 + 32 : 8];
+    // per wavefront: the 1024 levels / coefficients of a tile in memory order, used where a row of a TU is too short
+    // for good stores (8x8) and to turn the row-major coefficient input of MODE_IDCT into columns. TU column b is
+    // skewed by 2bN bytes so that the TU columns one LDS instruction touches fall into different banks.
+    constexpr bool LVL_LDS = N == 8 && MODE != MODE_IDCT;
+    constexpr bool PATCH = LVL_LDS || MODE == MODE_IDCT;
+    __shared__ __align__(16) int16_t s_lvl[PATCH ? 4 : 1][PATCH ? 1024 + 64 : 8];
+    auto chunk_skew = [](int c) { return N < 32 ? ((c * 8) / (NB * N * N)) * N : 0; };   // chunk c = 8 values in memory order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     for (int e = tid; e < 1024; e += 256) {
@@ -303,13 +390,14 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     auto pix_off = [](int row, int col) { return ((col / N) * NB + row / N) * (N * N) + (row % N) * N + col % N; };
     const int ntiles = p.count / S;       // whole tiles only: the host sends the remainder of a batch to tu_kernel
     const int cb = r / N;                 // this lane's column block in every result tile
-    int16_t *lv = s_lvl[LVL_LDS ? wave : 0];
-    const int lv_skew_w = N == 8 ? cb * 8 : 0;
+    int16_t *lv = s_lvl[PATCH ? wave : 0];
+    const int lv_skew_w = N < 32 ? cb * N : 0;
     const int tu_rel0 = cb * NB;          // tile-relative index of the first TU of the lane's column block (slot s: + s)
     // software pipeline: the operands of the next tile are requested before the current one is computed.
     // Nothing is derived from them until the next iteration, so no wait separates the requests from the arithmetic.
     const int t0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), t_step = gridDim.x * 4;   // wavefront-uniform
     v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
+    v4i c_next[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };   // MODE_IDCT: chunks lane and lane + 64 of the coefficient tile
     unsigned qp_next = 0, fl_next = 0;    // G consecutive bytes each
     auto fetch = [&](int tile) {
         const int tu_first = tile * S;
@@ -317,10 +405,15 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const unsigned off = (unsigned)pix_off(r, 16 * h + 4 * w);
-            s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
+            if (MODE != MODE_IDCT) s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
             p_next[w] = *reinterpret_cast<const int *>(p.pred + b + off);
         }
-        if (G == 1) {
+        if (MODE == MODE_IDCT) {
+            c_next[0] = *reinterpret_cast<const v4i *>(p.coef_in + b + lane * 8);
+            c_next[1] = *reinterpret_cast<const v4i *>(p.coef_in + b + 512 + lane * 8);
+        }
+        if (MODE != MODE_CHAIN) {
+        } else if (G == 1) {
             qp_next = p.qp[tu_first + tu_rel0];
             fl_next = p.flags[tu_first + tu_rel0];
         } else if (G == 2) {
@@ -333,7 +426,7 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
     };
     auto claim = [&]() {
 #pragma unroll
-        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]));
+        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]), "+v"(c_next[0][w]), "+v"(c_next[1][w]));
         asm volatile("" : "+v"(qp_next), "+v"(fl_next));
     };
     if (t0 < ntiles) fetch(t0);
@@ -344,7 +437,23 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         v4i s_frag = s_next, p_frag = p_next;
         const unsigned qp_cur = qp_next, fl_cur = fl_next;
         const v4i p_raw = p_next;
+        const v4i c_cur0 = c_next[0], c_cur1 = c_next[1];
         if (tile + t_step < ntiles) fetch(tile + t_step);
+        int t[16];
+        v4i hi, lo;
+        v16i acc_hi, acc_lo;
+        int zero = 0, bias1 = cs_lane;
+        // Accumulator inputs are rebuilt per tile from a register the compiler cannot see through: kept as loop
+        // invariants they would pin 32 VGPRs and cost a wavefront of occupancy.
+        asm volatile("" : "+v"(zero), "+v"(bias1));
+
+        if (MODE == MODE_IDCT) {
+            // coefficient tile: memory order -> LDS patch -> column r, rows rho(h, g)
+            *reinterpret_cast<v4i *>(lv + lane * 8 + chunk_skew(lane)) = c_cur0;
+            *reinterpret_cast<v4i *>(lv + (lane + 64) * 8 + chunk_skew(lane + 64)) = c_cur1;
+#pragma unroll
+            for (int g = 0; g < 16; g++) t[g] = (int)lv[pix_off(rho(h, g), r) + lv_skew_w];
+        } else {
 
         // ---- F1: residual rows x M^T ----
 #pragma unroll
@@ -357,18 +466,11 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
         for (int g = 0; g < 16; g++) acc[g] = 1 << (LG - 2);   // rounding of the >> (log2 N - 1)
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag, m_nat, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag, m_neg, acc, 0, 0, 0);
-        int t[16];
 #pragma unroll
         for (int g = 0; g < 16; g++) t[g] = acc[g] >> (LG - 1);          // tmp[k = r][i = rho(h,g)], fits int16
 
         // ---- F2: M x D1 ----
-        v4i hi, lo;
         slice16<false>(t, hi, lo);
-        // Accumulator inputs are rebuilt per tile from a register the compiler cannot see through: kept as loop
-        // invariants they would pin 32 VGPRs and cost a wavefront of occupancy.
-        int zero = 0, bias1 = cs_lane;
-        asm volatile("" : "+v"(zero), "+v"(bias1));
-        v16i acc_hi, acc_lo;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             acc_hi[g] = 0;
@@ -385,7 +487,7 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const int sl = slot(w);
-            if (w == 0 || slot(w) != slot(w - 1)) {      // parameters of the TU of this row group
+            if (MODE == MODE_CHAIN && (w == 0 || slot(w) != slot(w - 1))) {      // parameters of the TU of this row group
                 const int2 e = s_qtab[min((qp_cur >> (8 * sl)) & 255u, 51u)];
                 q = e.x & 0xffff;
                 qbits = e.x >> 16;
@@ -399,6 +501,10 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
             for (int e4 = 0; e4 < 4; e4++) {
                 const int g = 4 * w + e4;
                 const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);            // |c| < 2^15 for 8-bit video
+                if (MODE == MODE_SUBDCT) {
+                    lvl[e4] = c;
+                    continue;
+                }
                 const int level = (__mul24(c, q) + (c < 0 ? qadd_neg : qadd_pos)) >> qbits;   // |level| < 2^14: no clipping
                 local += abs(level);
                 lvl[e4] = level;
@@ -420,20 +526,23 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 #pragma unroll
             for (int e4 = 0; e4 < 4; e4++) lv[pix_off(8 * w + 4 * h + e4, r) + lv_skew_w] = (int16_t)lvl[e4];
             }
-            if (w == 3 || slot(w + 1) != slot(w)) {      // sum of |level| of this TU
+            if (MODE == MODE_CHAIN && (w == 3 || slot(w + 1) != slot(w))) {      // sum of |level| of this TU
                 int v = local + __shfl_xor(local, 32);                          // both lane halves
                 v = group_sum_to_last_lane<N>(v);                               // the N lanes of the column block
                 if (r % N == N - 1 && h == 0) p.sum[tu_first + tu_rel0 + sl] = (uint32_t)v;
             }
         }
 
+        if (MODE == MODE_SUBDCT) claim();
         if (LVL_LDS) {
 #pragma unroll
         for (int c = lane; c < 128; c += 64) {           // chunk c = 8 consecutive levels in memory order
-            const v4i d = *reinterpret_cast<const v4i *>(lv + c * 8 + (N == 8 ? (c >> 5) * 8 : 0));
+            const v4i d = *reinterpret_cast<const v4i *>(lv + c * 8 + chunk_skew(c));
             *reinterpret_cast<v4i *>(p.out16 + base + c * 8) = d;
         }
         }
+        if (MODE == MODE_SUBDCT) continue;
+        }   // MODE != MODE_IDCT
 
         // ---- I1: D2^T x M ----
         slice16<true>(t, hi, lo);
@@ -747,24 +856,34 @@ int launch_mfma4(const TuParams &p, hipStream_t st)
     return XMI_OK;
 }
 
-template <int N>
+template <int N, int MODE>
 int launch_mfma(const TuParams &p, hipStream_t st)
 {
     constexpr int S = (32 / N) * (32 / N);
     const int tiles = p.count / S;
     if (tiles > 0) {
         const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;   // 8 workgroups per CU; wavefronts loop over tiles
-        hipLaunchKernelGGL((tu_mfma_kernel<N>), dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((tu_mfma_kernel<N, MODE>), dim3(blocks), dim3(256), 0, st, p);
         XMI_HIP(hipGetLastError());
     }
     const int rest = p.count - tiles * S;                                     // < S TUs: one partial tile, on the VALU kernel
     if (rest > 0) {
         const size_t tu0 = (size_t)tiles * S, px0 = tu0 * N * N;
-        TuParams q = { p.pix + px0, p.pred + px0, p.qp + tu0, p.flags + tu0, nullptr, p.out16 + px0, p.rec + px0, p.sum + tu0, rest };
-        hipLaunchKernelGGL((tu_kernel<N, MODE_CHAIN>), dim3((rest + Cfg<N>::TUS - 1) / Cfg<N>::TUS), dim3(256), 0, st, q);
+        auto at = [](auto *ptr, size_t off) { return ptr ? ptr + off : ptr; };
+        TuParams q = { at(p.pix, px0), at(p.pred, px0), at(p.qp, tu0), at(p.flags, tu0), at(p.coef_in, px0), at(p.out16, px0),
+                       at(p.rec, px0), at(p.sum, tu0), rest };
+        hipLaunchKernelGGL((tu_kernel<N, MODE>), dim3((rest + Cfg<N>::TUS - 1) / Cfg<N>::TUS), dim3(256), 0, st, q);
         XMI_HIP(hipGetLastError());
     }
     return XMI_OK;
+}
+
+template <int MODE>
+int launch_mfma_n(int n, const TuParams &p, hipStream_t st)
+{
+    if (n == 32) return launch_mfma<32, MODE>(p, st);
+    if (n == 16) return launch_mfma<16, MODE>(p, st);
+    return launch_mfma<8, MODE>(p, st);
 }
 
 template <int MODE>
@@ -808,9 +927,7 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     if (count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec | (uintptr_t)d_level) & 15) == 0 &&
         (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 7) == 0) {
         if (n == 4) return launch_mfma4(p, xmi::as_stream(stream));
-        if (n == 32) return launch_mfma<32>(p, xmi::as_stream(stream));
-        if (n == 16) return launch_mfma<16>(p, xmi::as_stream(stream));
-        return launch_mfma<8>(p, xmi::as_stream(stream));
+        return launch_mfma_n<MODE_CHAIN>(n, p, xmi::as_stream(stream));
     }
 #endif
     return launch<MODE_CHAIN>(n, p, xmi::as_stream(stream));
@@ -823,6 +940,8 @@ int xmi_sub_dct_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t 
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_pix && d_pred && d_coef), "xmi_sub_dct_batch_dev: null argument");
     TuParams p = { d_pix, d_pred, nullptr, d_flags, nullptr, d_coef, nullptr, nullptr, count };
+    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_coef) & 15) == 0)
+        return launch_mfma_n<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
     return launch<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
 }
 
@@ -833,6 +952,7 @@ int xmi_quant_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_coef && d_qp && d_level && d_sum), "xmi_quant_batch_dev: null argument");
     TuParams p = { nullptr, nullptr, d_qp, d_flags, d_coef, d_level, nullptr, d_sum, count };
+    if (count > 0 && (((uintptr_t)d_coef | (uintptr_t)d_level) & 15) == 0) return launch_quant_stream_n<false>(n, p, xmi::as_stream(stream));
     return launch<MODE_QUANT>(n, p, xmi::as_stream(stream));
 }
 
@@ -842,6 +962,7 @@ int xmi_dequant_batch_dev(int n, int count, const int16_t *d_level, const uint8_
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_level && d_qp && d_coef), "xmi_dequant_batch_dev: null argument");
     TuParams p = { nullptr, nullptr, d_qp, nullptr, d_level, d_coef, nullptr, nullptr, count };
+    if (count > 0 && (((uintptr_t)d_level | (uintptr_t)d_coef) & 15) == 0) return launch_quant_stream_n<true>(n, p, xmi::as_stream(stream));
     return launch<MODE_DEQUANT>(n, p, xmi::as_stream(stream));
 }
 
@@ -852,6 +973,8 @@ int xmi_idct_add_batch_dev(int n, int count, const int16_t *d_coef, const uint8_
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_coef && d_pred && d_rec), "xmi_idct_add_batch_dev: null argument");
     TuParams p = { nullptr, d_pred, nullptr, d_flags, d_coef, nullptr, d_rec, nullptr, count };
+    if (n >= 8 && count > 0 && (((uintptr_t)d_coef | (uintptr_t)d_pred | (uintptr_t)d_rec) & 15) == 0)
+        return launch_mfma_n<MODE_IDCT>(n, p, xmi::as_stream(stream));
     return launch<MODE_IDCT>(n, p, xmi::as_stream(stream));
 }
 
