@@ -213,6 +213,46 @@ def test_tu_chain_large_batch_matrix_core_vs_valu(L, n, cnt, style):
     assert outs[0][2].any()
 
 
+@pytest.mark.parametrize("n,cnt", [(4, 600_037), (8, 140_005), (16, 40_003), (32, 9_001)])
+def test_tu_stages_large_batch_fast_vs_valu(L, n, cnt):
+    """xSubDct / xQuant / xDeQuant / xIDctAdd batches: the matrix-core and streaming kernels (16-byte aligned
+    arrays) against the VALU kernel (the int16 array starts 2 bytes off), large ragged batches, mixed DCT/DST for 4x4."""
+    g = torch.Generator(device="cuda").manual_seed(7 * n + cnt)
+    pix = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device="cuda", generator=g)
+    pred = (pix.to(torch.int16) + torch.randint(-60, 61, pix.shape, dtype=torch.int16, device="cuda", generator=g)).clamp(0, 255).to(torch.uint8)
+    qp = torch.randint(0, 52, (cnt,), dtype=torch.uint8, device="cuda", generator=g)
+    fl = torch.randint(0, 2, (cnt,), dtype=torch.uint8, device="cuda", generator=g)
+    if n == 4:
+        fl |= torch.randint(0, 2, (cnt // 48 + 1,), dtype=torch.uint8, device="cuda", generator=g).repeat_interleave(48)[:cnt] * 2
+    nn = cnt * n * n
+
+    def i16(shift):       # int16 buffer whose data pointer is 16-byte aligned (shift 0) or 2 bytes past that (shift 1)
+        buf = torch.zeros(nn + 8, dtype=torch.int16, device="cuda")
+        return buf[shift:shift + nn]
+
+    res = []
+    for shift in (0, 1):
+        coef, lev, deq = i16(shift), i16(shift), i16(shift)
+        rec = torch.zeros((cnt, n, n), dtype=torch.uint8, device="cuda")
+        sm = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+        capi.check(L.xmi_sub_dct_batch_dev(n, cnt, pix.data_ptr(), pred.data_ptr(), fl.data_ptr(), coef.data_ptr(), None))
+        capi.check(L.xmi_quant_batch_dev(n, cnt, coef.data_ptr(), qp.data_ptr(), fl.data_ptr(), lev.data_ptr(), sm.data_ptr(), None))
+        capi.check(L.xmi_dequant_batch_dev(n, cnt, lev.data_ptr(), qp.data_ptr(), deq.data_ptr(), None))
+        capi.check(L.xmi_idct_add_batch_dev(n, cnt, deq.data_ptr(), pred.data_ptr(), fl.data_ptr(), rec.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append((coef.clone(), lev.clone(), sm, deq.clone(), rec))
+    for name, a, b in zip(("coefficients", "levels", "sums", "dequantised", "reconstruction"), res[0], res[1]):
+        assert torch.equal(a, b), name + " differ"
+    # and the four stages chained equal the fused chain
+    lev = torch.zeros(nn, dtype=torch.int16, device="cuda")
+    rec = torch.zeros((cnt, n, n), dtype=torch.uint8, device="cuda")
+    sm = torch.zeros(cnt, dtype=torch.int32, device="cuda")
+    capi.check(L.xmi_tu_chain_batch_dev(n, cnt, pix.data_ptr(), pred.data_ptr(), qp.data_ptr(), fl.data_ptr(),
+                                        lev.data_ptr(), rec.data_ptr(), sm.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(lev, res[0][1]) and torch.equal(sm, res[0][2]) and torch.equal(rec, res[0][4])
+
+
 def test_tu_roundtrip_property_full_size(L):
     """size-independent property at a large batch: qp 0 on an all-equal block reconstructs it exactly, and
     a zero residual gives zero levels / rec == pred for every TU of the batch"""

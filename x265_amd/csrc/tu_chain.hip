@@ -626,6 +626,7 @@ __global__ void __launch_bounds__(256) tu_mfma_kernel(const TuParams p)
 //   loads / reconstruction:  lane row r, columns 16h + 4w .. + 3      -> TU (a = r/4, b = 4h + w)
 //   after F1, F2 (quant):     rows 8w + 4h + e, column r                -> TU (a = 2w + h, b = r/4)
 //   after I1, I2:             lane row r, columns 8w + 4h + e           -> TU (a = r/4, b = 2w + h)
+template <int MODE>
 __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
 {
     constexpr int S = 64, LG = 2;
@@ -673,6 +674,7 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
     uint32_t *sm = s_sum[wave];
     const int t0 = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave), t_step = gridDim.x * 4;
     v4i s_next = { 0, 0, 0, 0 }, p_next = { 0, 0, 0, 0 };
+    v4i c_next[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } }; // MODE_IDCT: chunks lane and lane + 64 of the coefficient tile
     uint2 qp_next = { 0, 0 }, fl_next = { 0, 0 };       // the 8 TUs of block column b = r/4, byte a
     auto fetch = [&](int tile) {
         const int tu_first = tile * S;
@@ -680,15 +682,19 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const unsigned off = (unsigned)pix_off(r, 16 * h + 4 * w);
-            s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
+            if (MODE != MODE_IDCT) s_next[w] = *reinterpret_cast<const int *>(p.pix + b + off);
             p_next[w] = *reinterpret_cast<const int *>(p.pred + b + off);
         }
-        qp_next = *reinterpret_cast<const uint2 *>(p.qp + tu_first + (r >> 2) * 8);
-        fl_next = *reinterpret_cast<const uint2 *>(p.flags + tu_first + (r >> 2) * 8);
+        if (MODE == MODE_IDCT) {
+            c_next[0] = *reinterpret_cast<const v4i *>(p.coef_in + b + lane * 8);
+            c_next[1] = *reinterpret_cast<const v4i *>(p.coef_in + b + 512 + lane * 8);
+        }
+        if (MODE == MODE_CHAIN) qp_next = *reinterpret_cast<const uint2 *>(p.qp + tu_first + (r >> 2) * 8);
+        if (p.flags) fl_next = *reinterpret_cast<const uint2 *>(p.flags + tu_first + (r >> 2) * 8);
     };
     auto claim = [&]() {
 #pragma unroll
-        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]));
+        for (int w = 0; w < 4; w++) asm volatile("" : "+v"(s_next[w]), "+v"(p_next[w]), "+v"(c_next[0][w]), "+v"(c_next[1][w]));
         asm volatile("" : "+v"(qp_next.x), "+v"(qp_next.y), "+v"(fl_next.x), "+v"(fl_next.y));
     };
     if (t0 < ntiles) fetch(t0);
@@ -698,7 +704,16 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
         const size_t base = (size_t)tu_first * 16;
         const v4i s_raw = s_next, p_raw = p_next;
         const uint2 qp_cur = qp_next, fl_cur = fl_next;
+        const v4i c_cur0 = c_next[0], c_cur1 = c_next[1];
         if (tile + t_step < ntiles) fetch(tile + t_step);
+        if (MODE == MODE_IDCT) {
+            // coefficient tile: memory order (TU t = 8b + a at t * 16) -> LDS patch (TU (a, b) at (8a + b) * 16)
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int c = lane + 64 * half, tu = c >> 1;
+                *reinterpret_cast<v4i *>(lv + ((tu & 7) * 8 + (tu >> 3)) * 16 + (c & 1) * 8) = half ? c_cur1 : c_cur0;
+            }
+        }
 
         // prediction bytes in the reconstruction layout (row r, columns 8 qd + 4h .. + 3), see tu_mfma_kernel
         unsigned pv_cur[4];
@@ -724,6 +739,14 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
             const int4 b_i2 = *reinterpret_cast<const int4 *>(&s_bias[type][4]);
             const int b_i1 = s_bias[type][8 + (r & 3)];
 
+            int t[16];
+            v4i hi, lo;
+            v16i acc_hi, acc_lo;
+            if (MODE == MODE_IDCT) {
+#pragma unroll
+                for (int g = 0; g < 16; g++)       // coef[k = 8w + 4h + e][i = r] of TU (a = 2w + h, b = r/4)
+                    t[g] = (int)lv[((2 * (g >> 2) + h) * 8 + (r >> 2)) * 16 + (g & 3) * 4 + (r & 3)];
+            } else {
             // ---- F1 ----
             v4i s_frag4, p_frag4;
 #pragma unroll
@@ -736,14 +759,11 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
             for (int g = 0; g < 16; g++) acc[g] = 1 << (LG - 2);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(s_frag4, m_nat, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(p_frag4, m_neg, acc, 0, 0, 0);
-            int t[16];
 #pragma unroll
             for (int g = 0; g < 16; g++) t[g] = acc[g] >> (LG - 1);
 
             // ---- F2 ----
-            v4i hi, lo;
             slice16<false>(t, hi, lo);
-            v16i acc_hi, acc_lo;
 #pragma unroll
             for (int g = 0; g < 16; g++) {
                 acc_hi[g] = 0;
@@ -758,6 +778,15 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
                 const unsigned sh = 16 * (w & 1) + 8 * h;
                 const unsigned qpb = ((w < 2 ? qp_cur.x : qp_cur.y) >> sh) & 255u, flb = ((w < 2 ? fl_cur.x : fl_cur.y) >> sh) & 255u;
                 const bool mine = !MIXED || (int)((flb >> 1) & 1u) == type;
+                if (MODE == MODE_SUBDCT) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; e4++) {
+                        const int g = 4 * w + e4;
+                        const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
+                        if (mine) lv[((2 * w + h) * 8 + (r >> 2)) * 16 + e4 * 4 + (r & 3)] = (int16_t)c;
+                    }
+                    continue;
+                }
                 const int2 e = s_qtab[min(qpb, 51u)];
                 const int q = e.x & 0xffff, qbits = e.x >> 16, dscale = e.y;
                 const int qadd_pos = (85 + 86 * (int)(flb & 1u)) << (qbits - 9);
@@ -777,6 +806,8 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
                 local += __builtin_amdgcn_update_dpp(0, local, 0x112, 0xf, 0xf, true);   // row_shr:2
                 if ((r & 3) == 3 && mine) sm[b * 8 + a] = (uint32_t)local;
             }
+            if (MODE == MODE_SUBDCT) continue;
+            }   // MODE != MODE_IDCT
 
             // ---- I1 ----
             slice16<true>(t, hi, lo);
@@ -820,37 +851,42 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
 #pragma unroll
             for (int w = 0; w < 4; w++) {      // TU (a = r/4, b = 4h + w)
                 bool mine = true;
-                if (MIXED) mine = (int)((p.flags[tu_first + (4 * h + w) * 8 + (r >> 2)] >> 1) & 1) == type;
+                if (MIXED) mine = (int)((p.flags[tu_first + (4 * h + w) * 8 + (r >> 2)] >> 1) & 1) == type;   // p.flags != null when mixed
                 if (mine) *reinterpret_cast<unsigned *>(p.rec + base + pix_off(r, 16 * h + 4 * w)) = o[w];
             }
         }
         claim();
 
         // levels: LDS patch -> memory order (TU t = 8b + a at t * 16), 16 bytes = two TU rows per lane and step
+        if (MODE != MODE_IDCT) {
 #pragma unroll
         for (int c = lane; c < 128; c += 64) {
             const int tu = c >> 1, a = tu & 7, b = tu >> 3;
             const v4i d = *reinterpret_cast<const v4i *>(lv + (a * 8 + b) * 16 + (c & 1) * 8);
             *reinterpret_cast<v4i *>(p.out16 + base + c * 8) = d;
         }
-        p.sum[tu_first + lane] = sm[lane];
+        }
+        if (MODE == MODE_CHAIN) p.sum[tu_first + lane] = sm[lane];
     }
 }
 
+template <int MODE>
 int launch_mfma4(const TuParams &p, hipStream_t st)
 {
     constexpr int S = 64;
     const int tiles = p.count / S;
     if (tiles > 0) {
         const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;
-        hipLaunchKernelGGL(tu_mfma4_kernel, dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((tu_mfma4_kernel<MODE>), dim3(blocks), dim3(256), 0, st, p);
         XMI_HIP(hipGetLastError());
     }
     const int rest = p.count - tiles * S;
     if (rest > 0) {
         const size_t tu0 = (size_t)tiles * S, px0 = tu0 * 16;
-        TuParams q = { p.pix + px0, p.pred + px0, p.qp + tu0, p.flags + tu0, nullptr, p.out16 + px0, p.rec + px0, p.sum + tu0, rest };
-        hipLaunchKernelGGL((tu_kernel<4, MODE_CHAIN>), dim3((rest + Cfg<4>::TUS - 1) / Cfg<4>::TUS), dim3(256), 0, st, q);
+        auto at = [](auto *ptr, size_t off) { return ptr ? ptr + off : ptr; };
+        TuParams q = { at(p.pix, px0), at(p.pred, px0), at(p.qp, tu0), at(p.flags, tu0), at(p.coef_in, px0), at(p.out16, px0),
+                       at(p.rec, px0), at(p.sum, tu0), rest };
+        hipLaunchKernelGGL((tu_kernel<4, MODE>), dim3((rest + Cfg<4>::TUS - 1) / Cfg<4>::TUS), dim3(256), 0, st, q);
         XMI_HIP(hipGetLastError());
     }
     return XMI_OK;
@@ -926,7 +962,7 @@ int xmi_tu_chain_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t
     // (and the last partial tile of a batch) takes the VALU kernel
     if (count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_rec | (uintptr_t)d_level) & 15) == 0 &&
         (((uintptr_t)d_qp | (uintptr_t)d_flags | (uintptr_t)d_sum) & 7) == 0) {
-        if (n == 4) return launch_mfma4(p, xmi::as_stream(stream));
+        if (n == 4) return launch_mfma4<MODE_CHAIN>(p, xmi::as_stream(stream));
         return launch_mfma_n<MODE_CHAIN>(n, p, xmi::as_stream(stream));
     }
 #endif
@@ -940,8 +976,8 @@ int xmi_sub_dct_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t 
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_pix && d_pred && d_coef), "xmi_sub_dct_batch_dev: null argument");
     TuParams p = { d_pix, d_pred, nullptr, d_flags, nullptr, d_coef, nullptr, nullptr, count };
-    if (n >= 8 && count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_coef) & 15) == 0)
-        return launch_mfma_n<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
+    if (count > 0 && (((uintptr_t)d_pix | (uintptr_t)d_pred | (uintptr_t)d_coef) & 15) == 0 && ((uintptr_t)d_flags & 7) == 0)
+        return n == 4 ? launch_mfma4<MODE_SUBDCT>(p, xmi::as_stream(stream)) : launch_mfma_n<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
     return launch<MODE_SUBDCT>(n, p, xmi::as_stream(stream));
 }
 
@@ -973,8 +1009,8 @@ int xmi_idct_add_batch_dev(int n, int count, const int16_t *d_coef, const uint8_
     if (rc != XMI_OK) return rc;
     XMI_ARG(count == 0 || (d_coef && d_pred && d_rec), "xmi_idct_add_batch_dev: null argument");
     TuParams p = { nullptr, d_pred, nullptr, d_flags, d_coef, nullptr, d_rec, nullptr, count };
-    if (n >= 8 && count > 0 && (((uintptr_t)d_coef | (uintptr_t)d_pred | (uintptr_t)d_rec) & 15) == 0)
-        return launch_mfma_n<MODE_IDCT>(n, p, xmi::as_stream(stream));
+    if (count > 0 && (((uintptr_t)d_coef | (uintptr_t)d_pred | (uintptr_t)d_rec) & 15) == 0 && ((uintptr_t)d_flags & 7) == 0)
+        return n == 4 ? launch_mfma4<MODE_IDCT>(p, xmi::as_stream(stream)) : launch_mfma_n<MODE_IDCT>(n, p, xmi::as_stream(stream));
     return launch<MODE_IDCT>(n, p, xmi::as_stream(stream));
 }
 
