@@ -245,6 +245,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "interp.npz"), **out)
     if os.path.exists(LIB_ME):
         gen_me()
+        gen_intra()
     else:
         print("skipping me_search.npz: make -C oracle ref_me first")
     print("golden vectors written to", os.path.normpath(OUT))
@@ -310,6 +311,107 @@ def gen_me():
     out["lambdas"] = np.array(lambdas, np.float64)
     out["pad"] = np.array([PAD], np.int32)
     np.savez_compressed(os.path.join(OUT, "me_search.npz"), **out)
+
+
+
+def gen_intra():
+    """Intra luma prediction known answers from the reference's compiled code: xPaddingRef and xFilterRef
+    (src/encode.cpp:3843, 3873), xEncIntraPred (src/pixel.cpp:7338, the SSE4 paths the encoder uses) for all 35 modes
+    and sizes 4..32, and, for 32x32 (where the bound SATD is the reference's own C++ xCalcHADs32x32_test), the
+    35-mode decision loop of src/encode.cpp:4021-4081 replayed in Python over those reference functions."""
+    lib = C.CDLL(LIB_ME)
+    fpad = lib._Z11xPaddingRefPhhPKi
+    fpad.restype = None
+    fpad.argtypes = [C.c_void_p, C.c_uint8, C.POINTER(C.c_int32)]
+    ffil = lib._Z10xFilterRefPhS_ij
+    ffil.restype = None
+    ffil.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint]
+    fprd = lib._Z13xEncIntraPredPhS_jjjj
+    fprd.restype = None
+    fprd.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    fsatd32 = lib._Z19xCalcHADs32x32_testPhlS_l
+    fsatd32.restype = C.c_int
+    fsatd32.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+    ftype = (C.c_uint8 * (5 * 35)).in_dll(lib, "xg_aucIntraFilterType")
+    rng = np.random.default_rng(77)
+    out = {}
+    valid_sets = (0x1f, 0x1e, 0x0e, 0x0c, 0x06, 0x18, 0x02, 0x08, 0x1a, 0x0a, 0x04)
+    for li, n in enumerate((4, 8, 16, 32)):
+        ncase = {4: 14, 8: 12, 16: 10, 32: 8}[n]
+        L = 4 * n + 1
+        raw = np.zeros((ncase, L), np.uint8)
+        valids = np.zeros(ncase, np.uint8)
+        strong = np.zeros(ncase, np.uint8)
+        padded = np.zeros((ncase, L), np.uint8)
+        filt = np.zeros((ncase, L), np.uint8)
+        preds = np.zeros((ncase, 35, n, n), np.uint8)
+        src = np.zeros((ncase, n, n), np.uint8)
+        mpm = np.zeros((ncase, 3), np.uint8)
+        lam = np.zeros(ncase, np.float64)
+        satd = np.zeros((ncase, 35), np.uint32)
+        best = np.zeros((ncase, 2), np.int32)       # mode, pred_idx
+        cost = np.zeros(ncase, np.float64)
+        ref0 = aligned((4 * 64 + 1 + 64,), np.uint8)
+        ref1 = aligned((4 * 64 + 1 + 64,), np.uint8)
+        dst = aligned((32 * 32 + 64,), np.uint8)
+        pix = aligned((64, 64), np.uint8)
+        offs = (C.c_int32 * 6)(0, n, 2 * n, 2 * n + 1, 3 * n + 1, 4 * n + 1)
+        for ci in range(ncase):
+            kind = ci % 4
+            if kind == 0:
+                r = rng.integers(0, 256, L)
+            elif kind == 1:      # smooth ramp: exercises the bilinear (strong) filter decision at 32x32
+                r = np.clip(100 + np.arange(L) * (0.2 + 0.1 * ci) + rng.integers(-1, 2, L), 0, 255)
+            elif kind == 2:      # extremes
+                r = np.where(rng.random(L) < 0.5, 0, 255)
+            else:
+                r = np.clip(128 + 90 * np.sin(np.arange(L) / (3.0 + ci)) + rng.integers(-5, 6, L), 0, 255)
+            raw[ci] = r.astype(np.uint8)
+            valids[ci] = valid_sets[ci % len(valid_sets)]
+            strong[ci] = (ci >> 1) & 1
+            ref0[:L] = raw[ci]
+            fpad(ptr(ref0), int(valids[ci]), offs)
+            padded[ci] = ref0[:L]
+            ffil(ptr(ref1), ptr(ref0), n, int(strong[ci]))
+            filt[ci] = ref1[:L]
+            s = np.clip(128 + 70 * np.sin(np.add.outer(np.arange(n) * (0.3 + 0.05 * ci), np.arange(n) * 0.2)) + rng.integers(-20, 21, (n, n)), 0, 255)
+            src[ci] = s.astype(np.uint8)
+            pix[:] = 0
+            pix[:n, :n] = src[ci]
+            mpm[ci] = ((0, 1, 26), (10, 26, 0), (5, 4, 6), (34, 2, 33), (1, 1, 1))[ci % 5]
+            lam[ci] = np.sqrt(0.57 * 2 ** ((np.array((22, 27, 32, 37))[ci % 4] - 12) / 3.0))
+            bestc, bestm = np.finfo(np.float64).max, 0
+            for mode in range(35):
+                rf = ref1 if ftype[li * 35 + mode] else ref0
+                dst[:] = 0
+                fprd(ptr(dst), ptr(rf), n, mode, n, 1 if n != 32 else 0)
+                preds[ci, mode] = dst[:n * n].reshape(n, n)
+                if n == 32:
+                    sv = fsatd32(ptr(pix), 64, ptr(dst), n)
+                    satd[ci, mode] = sv
+                    c = (1.0 if mode == mpm[ci, 0] else 2.0 if mode in (mpm[ci, 1], mpm[ci, 2]) else 3.0) * lam[ci]
+                    c += float(sv)
+                    if c < bestc:
+                        bestc, bestm = c, mode
+            if n == 32:
+                m = [int(v) for v in mpm[ci]]
+                if bestm in m:
+                    idx = m.index(bestm)
+                else:
+                    sm = sorted(m)
+                    idx = bestm
+                    idx -= idx > sm[2]
+                    idx -= idx > sm[1]
+                    idx -= idx > sm[0]
+                    idx += 3
+                best[ci] = (bestm, idx)
+                cost[ci] = bestc
+        t = f"n{n}_"
+        out[t + "raw"], out[t + "valids"], out[t + "strong"], out[t + "padded"], out[t + "filtered"] = raw, valids, strong, padded, filt
+        out[t + "pred"], out[t + "src"], out[t + "mpm"], out[t + "sqrt_lambda"] = preds, src, mpm, lam
+        if n == 32:
+            out[t + "satd"], out[t + "best"], out[t + "cost"] = satd, best, cost
+    np.savez_compressed(os.path.join(OUT, "intra.npz"), **out)
 
 
 if __name__ == "__main__":

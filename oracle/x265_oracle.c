@@ -462,3 +462,152 @@ void orc_motion_search(const uint8_t *cur, const uint8_t *ref, int rs, int size,
     out->best_sad = bsad;
     out->mvp_idx = mvp_idx;
 }
+
+/* ------------------------------------------------------------------ intra mode search ---- */
+
+static const uint8_t k_intra_filter_type[4][35] = { /* src/table.cpp:32-40, sizes 4..32 */
+    { 0 },
+    { 1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1 },
+    { 1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1 },
+    { 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1 },
+};
+static const int8_t k_intra_angle[35] = { /* src/table.cpp:43-50 */
+    0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26,
+    -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int16_t k_intra_inv_angle[35] = { /* src/table.cpp:53-60 */
+    0, 0, 256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315,
+    256, 315, 390, 482, 630, 910, 1638, 4096, 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+
+void orc_padding_ref(uint8_t *ref, int size, unsigned valids)
+{
+    const int off[6] = { 0, size, 2 * size, 2 * size + 1, 3 * size + 1, 4 * size + 1 };
+    int n = 0;
+    while (n < 5 && !(valids & (1u << n))) n++;
+    uint8_t pad = ref[off[n]];
+    for (int i = 0; i < off[n]; i++) ref[i] = pad;
+    for (; n < 5; n++)
+        if (!(valids & (1u << n))) {
+            pad = ref[off[n] - 1];
+            for (int i = off[n]; i < off[n + 1]; i++) ref[i] = pad;
+        }
+}
+
+void orc_filter_ref(uint8_t *dst, const uint8_t *src, int size, int strong)
+{
+    const int bl = src[0], tl = src[2 * size], tr = src[4 * size];
+    const int bilinear_left = abs(bl + tl - 2 * src[size]) < 8;
+    const int bilinear_top = abs(tl + tr - 2 * src[3 * size]) < 8;
+    if (strong && size == 32 && bilinear_left && bilinear_top) {
+        dst[0] = src[0];
+        dst[2 * size] = src[2 * size];
+        dst[4 * size] = src[4 * size];
+        for (int i = 1; i < 2 * size; i++) {
+            dst[i] = (uint8_t)(((2 * size - i) * bl + i * tl + size) >> 6);
+            dst[2 * size + i] = (uint8_t)(((2 * size - i) * tl + i * tr + size) >> 6);
+        }
+    } else {
+        dst[0] = src[0];
+        dst[4 * size] = src[4 * size];
+        for (int i = 1; i < 4 * size; i++) dst[i] = (uint8_t)((src[i - 1] + 2 * src[i] + src[i + 1] + 2) >> 2);
+    }
+}
+
+void orc_intra_pred(uint8_t *dst, const uint8_t *ref, int stride, int mode, int size, int is_luma)
+{
+    const uint8_t *left = ref + 2 * size - 1, *top = ref + 2 * size + 1, *tl = ref + 2 * size;
+    const int lg = xlog2((unsigned)size - 1);
+    if (mode == 0) { /* planar, src/pixel.cpp:6489-6532 */
+        const int bl = left[-size], tr = top[size];
+        for (int i = 0; i < size; i++)
+            for (int j = 0; j < size; j++)
+                dst[i * stride + j] = (uint8_t)(((size - 1 - j) * left[-i] + (j + 1) * tr + (size - 1 - i) * top[j] + (i + 1) * bl + size) >> (lg + 1));
+    } else if (mode == 1) { /* DC, src/pixel.cpp:6583-6601, 6704-6730 */
+        unsigned sum = 0;
+        for (int i = 0; i < size; i++) sum += top[i] + left[-i];
+        const int dc = (int)((sum + (unsigned)size) / (unsigned)(2 * size));
+        for (int i = 0; i < size; i++) memset(dst + i * stride, dc, (size_t)size);
+        if (is_luma) {
+            dst[0] = (uint8_t)((top[0] + left[0] + 2 * dc + 2) >> 2);
+            for (int i = 1; i < size; i++) {
+                dst[i] = (uint8_t)((top[i] + 3 * dc + 2) >> 2);
+                dst[i * stride] = (uint8_t)((left[-i] + 3 * dc + 2) >> 2);
+            }
+        }
+    } else { /* angular, src/pixel.cpp:7243-7331 */
+        const int hor = mode < 18, angle = k_intra_angle[mode], inv = k_intra_inv_angle[mode];
+        uint8_t buf[2 * 64 + 1], *main_ = buf + (angle < 0 ? 64 : 0);
+        uint8_t tmp[32 * 32];
+        for (int x = 0; x < size + 1; x++) main_[x] = hor ? tl[-x] : tl[x];
+        if (angle < 0) {
+            int sum = 128;
+            for (int x = -1; x > ((size * angle) >> 5); x--) {
+                sum += inv;
+                main_[x] = tl[hor ? (sum >> 8) : -(sum >> 8)];
+            }
+        } else {
+            for (int x = size + 1; x < 2 * size + 1; x++) main_[x] = hor ? tl[-x] : tl[x];
+        }
+        int delta = 0;
+        for (int k = 0; k < size; k++) {
+            delta += angle;
+            const int idx = delta >> 5, fact = delta & 31;
+            for (int x = 0; x < size; x++)
+                tmp[k * size + x] = fact ? (uint8_t)(((32 - fact) * main_[x + idx + 1] + fact * main_[x + idx + 2] + 16) >> 5)
+                                         : main_[x + idx + 1];
+        }
+        if (is_luma && angle == 0) {
+            const int o = hor ? 1 : -1;
+            for (int x = 0; x < size; x++)
+                tmp[x * size] = (uint8_t)clip3(0, 255, tmp[x * size] + ((tl[(x + 1) * o] - tl[0]) >> 1));
+        }
+        for (int k = 0; k < size; k++)
+            for (int x = 0; x < size; x++)
+                dst[k * stride + x] = hor ? tmp[x * size + k] : tmp[k * size + x];
+    }
+}
+
+void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw, int size, unsigned valids,
+                      int strong_smoothing, const uint8_t mpm_in[3], double sqrt_lambda, orc_intra_result *out)
+{
+    uint8_t ref[2][4 * 64 + 1], pred[32 * 32];
+    const int lg = xlog2((unsigned)size - 1);
+    if (valids == 0) {
+        memset(ref, 0x80, sizeof ref);   /* src/encode.cpp:4006-4008: both sample sets */
+    } else {
+        memcpy(ref[0], ref_raw, (size_t)(4 * size + 1));
+        orc_padding_ref(ref[0], size, valids);
+        orc_filter_ref(ref[1], ref[0], size, strong_smoothing);
+    }
+    double best = 1.7976931348623157e308;
+    int best_mode = 0;
+    for (int mode = 0; mode < 35; mode++) {
+        orc_intra_pred(pred, ref[k_intra_filter_type[lg - 2][mode]], size, mode, size, size != 32);
+        double cost = (mode == mpm_in[0] ? 1.0 : (mode == mpm_in[1] || mode == mpm_in[2]) ? 2.0 : 3.0) * sqrt_lambda;
+        const uint32_t satd = orc_satd_table(lg - 2, src, src_stride, pred, size);
+        out->satd[mode] = satd;
+        cost += (double)satd;
+        if (cost < best) {
+            best = cost;
+            best_mode = mode;
+        }
+    }
+    uint8_t mpm[3] = { mpm_in[0], mpm_in[1], mpm_in[2] };
+    int idx;
+    if (best_mode == mpm[0]) idx = 0;
+    else if (best_mode == mpm[1]) idx = 1;
+    else if (best_mode == mpm[2]) idx = 2;
+    else { /* src/encode.cpp:4059-4080 */
+        uint8_t t;
+        if (mpm[0] > mpm[1]) { t = mpm[0]; mpm[0] = mpm[1]; mpm[1] = t; }
+        if (mpm[0] > mpm[2]) { t = mpm[0]; mpm[0] = mpm[2]; mpm[2] = t; }
+        if (mpm[1] > mpm[2]) { t = mpm[1]; mpm[1] = mpm[2]; mpm[2] = t; }
+        idx = best_mode;
+        idx -= idx > mpm[2];
+        idx -= idx > mpm[1];
+        idx -= idx > mpm[0];
+        idx += 3;
+    }
+    out->best_mode = best_mode;
+    out->pred_idx = idx;
+    out->best_cost = best;
+}

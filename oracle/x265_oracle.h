@@ -115,6 +115,30 @@ void orc_motion_search(const uint8_t *cur, const uint8_t *ref, int ref_stride, i
                        const orc_mv mvp[2], int zero_mv_tested, orc_mv mv_min_ipel, orc_mv mv_max_ipel,
                        double lambda, int me_range, orc_me_result *out);
 
+/* N3: intra luma mode search, src/encode.cpp:4005-4081 with its helpers.
+ * Reference sample array layout (both functions below and the search): 4*size+1 bytes,
+ * [0 .. 2*size-1] = left column bottom-up (bottom-left first), [2*size] = top-left, then the top row and top-right.
+ * orc_padding_ref : xPaddingRef, src/encode.cpp:3843 (valids: bit 0 = bottom-left, 1 = left, 2 = top-left, 3 = top,
+ *                   4 = top-right; at least one bit set).
+ * orc_filter_ref  : xFilterRef,  src/encode.cpp:3873 ([1 2 1] smoothing or, for 32x32 with strong smoothing, bilinear).
+ * orc_intra_pred  : xEncIntraPred, src/pixel.cpp:7338 -> planar (:6489), DC (:6704), angular (:7243); is_luma enables the
+ *                   DC / horizontal / vertical edge filters (the reference passes size != 32).
+ * orc_intra_search: the 35-mode loop: prediction from the unfiltered or filtered samples (xg_aucIntraFilterType,
+ *                   src/table.cpp:32), cost = satd + {1,2,3} * sqrt_lambda in double (most probable modes), strict <
+ *                   in mode order; satd = the entry the reference binds in xSatdN[log2(size)-2] (x264 SATD for 4..16,
+ *                   xCalcHADs32x32_test for 32); then the mapping of the best mode to its coded index. */
+void orc_padding_ref(uint8_t *ref, int size, unsigned valids);
+void orc_filter_ref(uint8_t *dst, const uint8_t *src, int size, int strong);
+void orc_intra_pred(uint8_t *dst, const uint8_t *ref, int stride, int mode, int size, int is_luma);
+typedef struct {
+    int best_mode;        /* nBestModeY */
+    int pred_idx;         /* iPredIdx: 0..2 = most probable mode hit, else 3 + rank among the remaining 32 */
+    double best_cost;     /* dBestSATDCost */
+    uint32_t satd[35];    /* SATD of every mode (before the mode-bit term) */
+} orc_intra_result;
+void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw, int size, unsigned valids,
+                      int strong_smoothing, const uint8_t mpm[3], double sqrt_lambda, orc_intra_result *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ class OrcMEResult(C.Structure):
                 ("mvp_idx", C.c_int), ("n_int_sads", C.c_int), ("n_sub_sads", C.c_int)]
 
 
+class OrcIntraResult(C.Structure):
+    _fields_ = [("best_mode", C.c_int), ("pred_idx", C.c_int), ("best_cost", C.c_double), ("satd", C.c_uint32 * 35)]
+
+
 def _build():
     src = os.path.join(ROOT, "oracle", "x265_oracle.c")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -56,6 +60,14 @@ def load():
     lib.orc_motion_search.restype = None
     lib.orc_motion_search.argtypes = [vp, vp, i, i, C.POINTER(OrcMV), i, OrcMV, OrcMV, C.c_double, i,
                                       C.POINTER(OrcMEResult)]
+    lib.orc_padding_ref.restype = None
+    lib.orc_padding_ref.argtypes = [vp, i, u]
+    lib.orc_filter_ref.restype = None
+    lib.orc_filter_ref.argtypes = [vp, vp, i, i]
+    lib.orc_intra_pred.restype = None
+    lib.orc_intra_pred.argtypes = [vp, vp, i, i, i, i]
+    lib.orc_intra_search.restype = None
+    lib.orc_intra_search.argtypes = [vp, i, vp, i, u, i, vp, C.c_double, C.POINTER(OrcIntraResult)]
     return lib
 
 

@@ -153,3 +153,39 @@ def test_motion_search_matches_reference(lib, golden_dir, tag):
         walked += out.n_int_sads > 6
     if tag != "c":
         assert walked > 10
+
+
+FILTER_TYPE = {8: {0, 2, 18, 34}, 16: set(range(35)) - {1, 9, 10, 11, 25, 26, 27}, 32: set(range(35)) - {1, 10, 26}, 4: set()}
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_prediction_matches_reference(lib, golden_dir, n):
+    """xPaddingRef, xFilterRef and all 35 xEncIntraPred modes against the reference's compiled code; for 32x32 also
+    the SATD of every mode and the decision (best mode, coded index, cost) of the reference's mode loop."""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "intra.npz"))
+    t = f"n{n}_"
+    raw, valids, strong = g[t + "raw"], g[t + "valids"], g[t + "strong"]
+    for ci in range(len(raw)):
+        ref0 = raw[ci].copy()
+        lib.orc_padding_ref(O.p(ref0), n, int(valids[ci]))
+        np.testing.assert_array_equal(ref0, g[t + "padded"][ci], err_msg=f"padding case {ci}")
+        ref1 = np.zeros_like(ref0)
+        lib.orc_filter_ref(O.p(ref1), O.p(ref0), n, int(strong[ci]))
+        np.testing.assert_array_equal(ref1, g[t + "filtered"][ci], err_msg=f"filter case {ci}")
+        for mode in range(35):
+            rf = ref1 if mode in FILTER_TYPE[n] else ref0
+            dst = np.zeros((n, n), np.uint8)
+            lib.orc_intra_pred(O.p(dst), O.p(rf), n, mode, n, int(n != 32))
+            np.testing.assert_array_equal(dst, g[t + "pred"][ci, mode], err_msg=f"case {ci} mode {mode}")
+        out = O.OrcIntraResult()
+        src = np.ascontiguousarray(g[t + "src"][ci])
+        mpm = np.ascontiguousarray(g[t + "mpm"][ci])
+        lib.orc_intra_search(O.p(src), n, O.p(np.ascontiguousarray(raw[ci])), n, int(valids[ci]), int(strong[ci]), O.p(mpm),
+                             float(g[t + "sqrt_lambda"][ci]), C.byref(out))
+        if n == 32:
+            np.testing.assert_array_equal(np.array(out.satd[:], np.uint32), g[t + "satd"][ci], err_msg=f"satd case {ci}")
+            assert (out.best_mode, out.pred_idx) == tuple(int(v) for v in g[t + "best"][ci]), f"decision case {ci}"
+            assert out.best_cost == float(g[t + "cost"][ci])
+        else:
+            assert 0 <= out.best_mode < 35 and 0 <= out.pred_idx < 35
