@@ -113,6 +113,35 @@ typedef struct xmi_me_result {
 int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows, int pad,
                             const xmi_me_request *d_req, int n, int me_range, xmi_me_result *d_res, void *stream);
 
+/* ---- intra luma mode search ---------------------------------------------------------------------
+ * The 35-mode SATD search of xEncDecideCU_Intra (src/encode.cpp:4005-4081) for a batch of PUs, one request per
+ * PU, with what the reference has at that point of its CTU loop: the PU's source pixels (taken from the
+ * source frame at x0,y0), the 4*size+1 neighbouring reconstruction samples as the reference gathers them
+ * (src/encode.cpp:4010-4015: left column bottom-up, top-left, top row, top-right; 132 bytes per request), the
+ * neighbour availability bits, the three most probable modes and sqrt(lambda). The kernel restates xPaddingRef
+ * (:3843), xFilterRef (:3873), xEncIntraPred (src/pixel.cpp:7338) and the SATD entry the reference binds in
+ * xSatdN[log2(size)-2]; the cost is satd + {1,2,3}*sqrt_lambda in double, first minimum in mode order.
+ * No counterpart call exists in the reference: the loop is inline in xEncDecideCU_Intra. */
+#define XMI_INTRA_REF_PITCH 132
+typedef struct xmi_intra_request {
+    int32_t x0, y0;               /* PU origin in the source frame, multiples of 4 */
+    uint8_t size;                 /* 4, 8, 16 or 32 */
+    uint8_t valids;               /* ucValids: bit 0 bottom-left, 1 left, 2 top-left, 3 top, 4 top-right */
+    uint8_t strong_smoothing;     /* bStrongIntraSmoothing */
+    uint8_t mpm[3];               /* aucMostModeY */
+    uint8_t reserved[2];
+    double sqrt_lambda;           /* dSqrtLambda */
+} xmi_intra_request;
+typedef struct xmi_intra_result {
+    int32_t best_mode;            /* nBestModeY */
+    int32_t pred_idx;             /* iPredIdx */
+    double best_cost;             /* dBestSATDCost */
+    uint32_t satd[35];            /* SATD of every mode */
+    uint32_t reserved;
+} xmi_intra_result;
+int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
+                               const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

@@ -1,0 +1,113 @@
+"""GPU: batched intra luma mode search (xmi_intra_search_batch_dev) against the stored outputs of the reference's
+compiled prediction code (tests/golden/intra.npz, 32x32 incl. the decision) and against the oracle's restatement
+of src/encode.cpp:4005-4081 on seeded requests of every size. Every output must match exactly (SATD per mode,
+best mode, coded index, cost as a double)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from x265_amd import capi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = capi.load()
+    capi.check(lib.xmi_init(0))
+    return lib
+
+
+def run_gpu(L, frame, reqs, refs):
+    n = len(reqs)
+    d_src = torch.from_numpy(frame).cuda()
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_ref = torch.from_numpy(refs).cuda()
+    d_res = torch.zeros(n * C.sizeof(capi.IntraResult), dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_intra_search_batch_dev(d_src.data_ptr(), frame.strides[0], d_ref.data_ptr(), d_req.data_ptr(), n,
+                                            d_res.data_ptr(), None))
+    torch.cuda.synchronize()
+    return (capi.IntraResult * n).from_buffer_copy(d_res.cpu().numpy().tobytes())
+
+
+def test_intra_search_matches_reference_golden(L):
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intra.npz"))
+    orc = O.load()
+    for n in (4, 8, 16, 32):
+        t = f"n{n}_"
+        raw, src = g[t + "raw"], g[t + "src"]
+        nc = len(raw)
+        frame = np.zeros((32, 32 * nc), np.uint8)
+        reqs = (capi.IntraRequest * nc)()
+        refs = np.zeros((nc, capi.INTRA_REF_PITCH), np.uint8)
+        for ci in range(nc):
+            frame[:n, 32 * ci:32 * ci + n] = src[ci]
+            rq = reqs[ci]
+            rq.x0, rq.y0, rq.size = 32 * ci, 0, n
+            rq.valids, rq.strong_smoothing = int(g[t + "valids"][ci]), int(g[t + "strong"][ci])
+            rq.mpm[0], rq.mpm[1], rq.mpm[2] = [int(v) for v in g[t + "mpm"][ci]]
+            rq.sqrt_lambda = float(g[t + "sqrt_lambda"][ci])
+            refs[ci, :4 * n + 1] = raw[ci]
+        res = run_gpu(L, frame, reqs, refs)
+        for ci in range(nc):
+            if n == 32:      # SATD and decision from the reference's own functions
+                np.testing.assert_array_equal(np.array(res[ci].satd[:], np.uint32), g[t + "satd"][ci], err_msg=f"satd case {ci}")
+                assert (res[ci].best_mode, res[ci].pred_idx) == tuple(int(v) for v in g[t + "best"][ci])
+                assert res[ci].best_cost == float(g[t + "cost"][ci])
+            else:            # SATD of the reference's predictions (x264 form, restated) per mode
+                s = np.ascontiguousarray(src[ci])
+                for mode in range(35):
+                    pr = np.ascontiguousarray(g[t + "pred"][ci, mode])
+                    want = orc.orc_satd_x264(n, O.p(s), n, O.p(pr), n)
+                    assert res[ci].satd[mode] == want, f"size {n} case {ci} mode {mode}"
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_intra_search_matches_oracle(L, seed):
+    orc = O.load()
+    rng = np.random.default_rng(seed)
+    H, W, nreq = 128, 256, 400
+    yy, xx = np.mgrid[0:H, 0:W]
+    frame = np.clip(128 + 60 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 30 * np.sin((xx + 3 * yy) / 4.0) + rng.integers(-12, 13, (H, W)), 0, 255).astype(np.uint8)
+    reqs = (capi.IntraRequest * nreq)()
+    refs = np.zeros((nreq, capi.INTRA_REF_PITCH), np.uint8)
+    for i in range(nreq):
+        n = int(rng.choice([4, 8, 16, 32]))
+        rq = reqs[i]
+        rq.size = n
+        rq.x0 = int(rng.integers(0, (W - n) // 4 + 1)) * 4
+        rq.y0 = int(rng.integers(0, (H - n) // 4 + 1)) * 4
+        rq.valids = int(rng.choice([0, 0x1f, 0x1e, 0x0e, 0x0c, 0x06, 0x02, 0x08, 0x1a, 0x04, 0x10, 0x01, 0x11]))
+        rq.strong_smoothing = int(rng.integers(0, 2))
+        m = rng.choice(35, 3, replace=bool(i % 9 == 0))
+        rq.mpm[0], rq.mpm[1], rq.mpm[2] = int(m[0]), int(m[1]), int(m[2])
+        rq.sqrt_lambda = float(rng.choice([0.0, 2.1, 4.7, 13.25, 40.0, 1e3]))
+        style = i % 3
+        L4 = 4 * n + 1
+        if style == 0:       # neighbours that continue the picture content
+            base = frame[rq.y0:rq.y0 + 1, rq.x0:rq.x0 + n].mean()
+            r = np.clip(base + rng.integers(-25, 26, L4), 0, 255)
+        elif style == 1:     # smooth: strong-filter candidates
+            r = np.clip(90 + np.arange(L4) * rng.uniform(0, 0.5) + rng.integers(-1, 2, L4), 0, 255)
+        else:
+            r = rng.integers(0, 256, L4)
+        refs[i, :L4] = r.astype(np.uint8)
+    res = run_gpu(L, frame, reqs, refs)
+    for i in range(nreq):
+        rq = reqs[i]
+        out = O.OrcIntraResult()
+        mpm = np.array([rq.mpm[0], rq.mpm[1], rq.mpm[2]], np.uint8)
+        orc.orc_intra_search(O.at(frame, rq.y0, rq.x0), frame.strides[0], O.p(np.ascontiguousarray(refs[i])), rq.size, rq.valids,
+                             rq.strong_smoothing, O.p(mpm), rq.sqrt_lambda, C.byref(out))
+        assert list(res[i].satd) == list(out.satd), f"request {i} size {rq.size} valids {rq.valids:#x}"
+        assert (res[i].best_mode, res[i].pred_idx, res[i].best_cost) == (out.best_mode, out.pred_idx, out.best_cost), f"request {i}"
+
+
+def test_intra_search_empty_and_errors(L):
+    assert L.xmi_intra_search_batch_dev(None, 0, None, None, 0, None, None) == 0
+    a = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    assert L.xmi_intra_search_batch_dev(a.data_ptr(), 6, a.data_ptr(), a.data_ptr(), 1, a.data_ptr(), None) == -1

@@ -119,3 +119,22 @@ for size, nreq in ((8, 28000), (16, 9500), (32, 2400), (64, 600), (0, 39000)):
     print(json.dumps({"kernel": f"me_search {'mixed' if not size else str(size) + 'x' + str(size)}", "requests": nreq, "ms": round(t * 1e3, 3),
                       "Msearch_per_s": round(nreq / t / 1e6, 2), "sads_per_search": round(sads / nreq, 1),
                       "Msad_per_s": round(sads / t / 1e6, 1)}))
+
+# ---- intra mode search: every PU of a 1080p frame at each depth (35 modes, prediction + SATD) ----
+frame = torch.from_numpy(f1).cuda()
+for n in (4, 8, 16, 32):
+    nx, ny = W // n, H // n
+    nreq = nx * ny
+    reqs = (capi.IntraRequest * nreq)()
+    for i in range(nreq):
+        rq = reqs[i]
+        rq.x0, rq.y0, rq.size, rq.valids, rq.strong_smoothing = (i % nx) * n, (i // nx) * n, n, 0x1f, 1
+        rq.mpm[0], rq.mpm[1], rq.mpm[2] = 0, 1, 26
+        rq.sqrt_lambda = 4.7
+    refs = torch.randint(0, 256, (nreq, capi.INTRA_REF_PITCH), dtype=torch.uint8, device="cuda", generator=g)
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_res = torch.zeros(nreq * C.sizeof(capi.IntraResult), dtype=torch.uint8, device="cuda")
+    t = timeit(lambda: capi.check(L.xmi_intra_search_batch_dev(frame.data_ptr(), W, refs.data_ptr(), d_req.data_ptr(), nreq,
+                                                               d_res.data_ptr(), s)), iters=5)
+    print(json.dumps({"kernel": f"intra_search {n}x{n}", "requests": nreq, "ms": round(t * 1e3, 3),
+                      "Msearch_per_s": round(nreq / t / 1e6, 2), "Gpixel_modes_per_s": round(nreq * n * n * 35 / t / 1e9, 1)}))

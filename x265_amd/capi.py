@@ -31,6 +31,18 @@ class MeResult(C.Structure):
                 ("n_int_sads", C.c_int32), ("n_sub_sads", C.c_int32)]
 
 
+class IntraRequest(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_uint8), ("valids", C.c_uint8),
+                ("strong_smoothing", C.c_uint8), ("mpm", C.c_uint8 * 3), ("reserved", C.c_uint8 * 2),
+                ("sqrt_lambda", C.c_double)]
+
+
+class IntraResult(C.Structure):
+    _fields_ = [("best_mode", C.c_int32), ("pred_idx", C.c_int32), ("best_cost", C.c_double),
+                ("satd", C.c_uint32 * 35), ("reserved", C.c_uint32)]
+
+
+INTRA_REF_PITCH = 132
 _lib = None
 
 
@@ -61,6 +73,9 @@ def load():
     if hasattr(L, "xmi_interp_planes_dev"):
         L.xmi_interp_planes_dev.restype = i
         L.xmi_interp_planes_dev.argtypes = [vp, i, i, i, vp, vp]
+    if hasattr(L, "xmi_intra_search_batch_dev"):
+        L.xmi_intra_search_batch_dev.restype = i
+        L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
     if hasattr(L, "xmi_me_search_batch_dev"):
         L.xmi_me_search_batch_dev.restype = i
         L.xmi_me_search_batch_dev.argtypes = [vp, i, vp, i, i, i, vp, i, i, vp, vp]
