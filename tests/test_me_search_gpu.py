@@ -129,6 +129,40 @@ def test_me_search_matches_reference_golden(L, tag):
         assert got == tuple(int(v) for v in want[i]), f"clip {tag} request {i}: gpu {got} reference {tuple(want[i])}"
 
 
+def test_me_search_replays_encoder_trace(L):
+    """The kernel on the requests the reference's encoder issued while coding three P pictures (inputs and
+    outputs recorded from a bit-identical encode, tests/golden/me_trace.npz): one batch per picture."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "me_trace.npz"))
+    pad = int(g["pad"][0])
+    for poc in g["pocs"]:
+        cur, ref = np.ascontiguousarray(g[f"p{poc}_cur"]), np.ascontiguousarray(g[f"p{poc}_ref"])
+        req, lam, want = g[f"p{poc}_req"], g[f"p{poc}_lambda"], g[f"p{poc}_res"]
+        rows, stride = ref.shape
+        d_ref = torch.from_numpy(ref).cuda()
+        planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+        capi.check(L.xmi_interp_planes_dev(d_ref.data_ptr(), stride, rows, stride, planes.data_ptr(), None))
+        d_cur = torch.from_numpy(cur).cuda()
+        nreq = len(req)
+        reqs = (capi.MeRequest * nreq)()
+        for i, r in enumerate(req):
+            rq = reqs[i]
+            rq.x0, rq.y0, rq.size = int(r[0]), int(r[1]), int(r[2])
+            rq.mvp[0][0], rq.mvp[0][1], rq.mvp[1][0], rq.mvp[1][1] = int(r[3]), int(r[4]), int(r[5]), int(r[6])
+            rq.zero_mv_tested = int(r[7])
+            rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = int(r[8]), int(r[9]), int(r[10]), int(r[11])
+            rq.sqrt_lambda = int(math.sqrt(float(lam[i])))
+        d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+        d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+        capi.check(L.xmi_me_search_batch_dev(d_cur.data_ptr(), cur.strides[0], planes.data_ptr(), stride, rows, pad,
+                                             d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
+        torch.cuda.synchronize()
+        res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
+        for i in range(nreq):
+            got = (res[i].mv[0], res[i].mv[1], res[i].best_cost, res[i].best_sad, res[i].mvp_idx)
+            assert got == tuple(int(v) for v in want[i]), f"picture {poc} request {i}: gpu {got} encoder {tuple(want[i])}"
+
+
 def test_me_search_empty_and_errors(L):
     assert L.xmi_me_search_batch_dev(None, 0, None, 0, 0, 0, None, 0, 32, None, None) == 0
     a = torch.zeros(64, dtype=torch.uint8, device="cuda")

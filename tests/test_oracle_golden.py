@@ -189,3 +189,28 @@ def test_intra_prediction_matches_reference(lib, golden_dir, n):
             assert out.best_cost == float(g[t + "cost"][ci])
         else:
             assert 0 <= out.best_mode < 35 and 0 <= out.pred_idx < 35
+
+
+def test_motion_search_replays_encoder_trace(lib, golden_dir):
+    """Every xMotionSearch call the reference's encoder made on three P pictures of the 416x240 QP32 clip
+    (recorded by oracle/gen_me_trace.py from a bit-identical encode): the oracle returns the same MV, cost,
+    SAD and MVP index from the same inputs."""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "me_trace.npz"))
+    pad = int(g["pad"][0])
+    blk = np.zeros((64, 64), np.uint8)
+    n = 0
+    for poc in g["pocs"]:
+        cur, ref = g[f"p{poc}_cur"], np.ascontiguousarray(g[f"p{poc}_ref"])
+        for r, lam, want in zip(g[f"p{poc}_req"], g[f"p{poc}_lambda"], g[f"p{poc}_res"]):
+            x, y, size = int(r[0]), int(r[1]), int(r[2])
+            blk[:] = 0
+            blk[:size, :size] = cur[y:y + size, x:x + size]
+            mvp = (O.OrcMV * 2)(O.OrcMV(int(r[3]), int(r[4])), O.OrcMV(int(r[5]), int(r[6])))
+            out = O.OrcMEResult()
+            lib.orc_motion_search(O.p(blk), O.at(ref, pad + y, pad + x), ref.strides[0], size, mvp, int(r[7]),
+                                  O.OrcMV(int(r[8]), int(r[9])), O.OrcMV(int(r[10]), int(r[11])), float(lam), 32, C.byref(out))
+            got = (out.mv.x, out.mv.y, out.best_cost, out.best_sad, out.mvp_idx)
+            assert got == tuple(int(v) for v in want), f"picture {poc} PU ({x},{y}) size {size}: oracle {got} encoder {tuple(want)}"
+            n += 1
+    assert n > 500
