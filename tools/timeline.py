@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of sad_surface_kernel<64> on the bench workload. Needs a library built with
+-DXMI_EXP_TIMELINE (tools/build_variant.sh timeline -DXMI_EXP_TIMELINE; X265_AMD_LIB=build/variants/...).
+s_memtime ticks are core-clock cycles (calibrated with tools/microbench/memtime_rate.hip), s_memrealtime is 100 MHz."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+from x265_amd import capi, layout  # noqa: E402
+
+L = capi.load()
+capi.check(L.xmi_init(0))
+W, H, R, PAD = 1920, 1088, 64, 80
+f0, f1 = B.synth_frame(W, H, 0, 7), B.synth_frame(W, H, 1, 7)
+ref = torch.from_numpy(B.pad_frame(f0, PAD)).cuda()
+cur = torch.from_numpy(f1).cuda()
+nctu = (W // 64) * (H // 64)
+planes = [torch.empty(layout.plane_elems(nctu, R, lv), dtype=torch.int16 if lv < 2 else torch.int32, device="cuda") for lv in range(4)]
+geom = capi.SadGeom(W, H, W, W + 2 * PAD, R)
+s = torch.cuda.current_stream().cuda_stream
+for it in range(30):     # sustained load, the last launch is analysed
+    capi.check(L.xmi_sad_surface_dev(C.byref(geom), cur.data_ptr(), ref.data_ptr() + PAD * (W + 2 * PAD) + PAD, planes[0].data_ptr(),
+                                     planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), 0, nctu, s))
+torch.cuda.synchronize()
+buf = (C.c_uint64 * (6 * nctu))()
+L.xmi_debug_timeline.argtypes = [C.c_void_p, C.c_int]
+assert L.xmi_debug_timeline(buf, nctu) == 0
+t = np.frombuffer(buf, np.uint64).reshape(nctu, 6).astype(np.int64)
+dur, stg, loop, tail = t[:, 3] - t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+r0 = t[:, 4].min()
+rs, re_ = t[:, 4] - r0, t[:, 5] - r0
+first = dur < np.median(dur)
+qsad_cycles = 8 * 136 * 64 * 16 // 4     # per SIMD for one workgroup: 8 wavefronts x 136 steps x 64 qsad x 16 cycles, over 4 SIMDs
+print(f"kernel span {re_.max() / 100:.1f} us; workgroups start within {rs.max() / 100:.2f} us")
+for name, m in (("first workgroup of a CU", first), ("second workgroup of a CU", ~first)):
+    print(f"{name}: n {m.sum()}  ends at {re_[m].mean() / 100:.1f} us  core cycles: total {int(dur[m].mean())}  staging {int(stg[m].mean())}  "
+          f"main loop {int(loop[m].mean())}  dx=+R pass {int(tail[m].mean())}  core clock {float((dur[m] / ((t[m, 5] - t[m, 4]) * 10.0)).mean()):.3f} GHz")
+print(f"v_qsad_pk_u16_u8 issue bound of one workgroup's main loop: {qsad_cycles} cycles -> the first workgroup runs at "
+      f"{qsad_cycles / loop[first].mean():.1%} of it; both workgroups of a CU together need {int(dur[~first].mean())} cycles "
+      f"for 2 x {qsad_cycles} cycles of qsad issue ({2 * qsad_cycles / dur[~first].mean():.1%})")

@@ -75,6 +75,10 @@ __device__ __forceinline__ u32 quad_reduce_scatter(u32 lo, u32 hi, int b)
     return keep2 + dpp_mov<kQuadXor1>(send2);
 }
 
+#ifdef XMI_EXP_TIMELINE
+__device__ unsigned long long g_timeline[4096 * 6];   // per workgroup: s_memtime at start / staged / main loop done / end, s_memrealtime at start / end
+#endif
+
 // Workgroup = one CTU x one band of dy rows; R/8 wavefronts.
 // lane = q*16 + gl*4 + b: q = 32x32 quadrant (raster), b = 16x16 block inside it (raster), gl = dx group of the wavefront.
 template <int R>
@@ -85,6 +89,9 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
     unsigned char *ref_lds = lds + kCurLdsBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef XMI_EXP_TIMELINE
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
+#endif
     constexpr int nwaves = R / 8;
     const int ctu = p.ctu_begin + blockIdx.x;
     const int cx0 = (ctu % p.wc) * 64, cy0 = (ctu / p.wc) * 64;
@@ -153,6 +160,9 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
     for (int c = 0; c < 4; c++)
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[c][j] = 0;
+#ifdef XMI_EXP_TIMELINE
+    const unsigned long long t_staged = __builtin_amdgcn_s_memtime();
+#endif
 
     // One 8-step group (the accumulator ring period). PHASE 0 / 2 are the first / last group of a full-range
     // band (ndy = 1 mod 8): there the row pairs whose dy falls outside the band are skipped at compile time
@@ -239,6 +249,9 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
     }
 #endif
 
+#ifdef XMI_EXP_TIMELINE
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     // ---- the dx = +R column: one more than a multiple of 4, so it gets a plain v_sad_u8 pass of its own.
     // lane (z, gl) of wavefront w takes the band rows d = (4w + gl), +4*nwaves, ...; the reference bytes of
     // dx = +R start at window dword R/2 + 4*bx16, already staged.
@@ -281,6 +294,17 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
             }
         }
     }
+#ifdef XMI_EXP_TIMELINE
+    if (tid == 0 && blockIdx.x < 4096) {
+        unsigned long long *t = g_timeline + blockIdx.x * 6;
+        t[0] = t_start;
+        t[1] = t_staged;
+        t[2] = t_loop;
+        t[3] = __builtin_amdgcn_s_memtime();
+        t[4] = r_start;
+        t[5] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 size_t lds_bytes(int R, int seg_len)
@@ -316,6 +340,13 @@ size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level)
     const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
     return nctu * (size_t)(2 * g->range + 1) * (size_t)(row_elems(g->range, level) + level_blocks(level));
 }
+
+#ifdef XMI_EXP_TIMELINE
+int xmi_debug_timeline(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), (size_t)n * 48) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk, int dy, int dx)
 {
