@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# torch ships its own copy of the HIP runtime: it has to be the first one loaded into the process, otherwise a
+# test file that loads libx265_amd.so before touching torch ends up with two runtimes and torch sees no device
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

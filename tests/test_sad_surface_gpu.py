@@ -111,3 +111,78 @@ def test_surface_rejects_bad_arguments(L):
     good = capi.SadGeom(w, h, cur.strides[0], ref.strides[0], rng)
     assert L.xmi_sad_surface(C.byref(good), O.p(cur), O.at(ref, pad, pad), 8, O.p(s), O.p(s), O.p(s), O.p(s)) == -1
     assert b"pad" in L.xmi_last_error()
+
+
+def _pyramid_checks(torch, planes, nctu, rng, ctu_lo, ctu_hi):
+    """levels must sum exactly, checked on the device in the tiled layout: slot c*16+z of sad8 -> slot z of sad16,
+    z = 4q+b -> quadrant q of sad32 -> sad64; main part [ctu][dy][tile][slot][16] and the dx = +R part [ctu][dy][slot]"""
+    nmv, t = 2 * rng + 1, rng // 8
+    main = [nctu * nmv * t * nb * 16 for nb in layout.NBLK]
+    for lo in range(ctu_lo, ctu_hi, 32):          # chunks of CTUs bound the int32 temporaries
+        hi = min(lo + 32, ctu_hi)
+        n = hi - lo
+
+        def part(lvl, edge):
+            nb = layout.NBLK[lvl]
+            if edge:
+                return planes[lvl][main[lvl] + lo * nmv * nb:main[lvl] + hi * nmv * nb].view(n, nmv, 1, nb, 1).to(torch.int32)
+            return planes[lvl][lo * nmv * t * nb * 16:hi * nmv * t * nb * 16].view(n, nmv, t, nb, 16).to(torch.int32)
+
+        for edge in (False, True):
+            s8, s16, s32, s64 = (part(lvl, edge) for lvl in range(4))
+            w = s8.shape[-1]
+            tt = s8.shape[2]
+            assert torch.equal(s8.view(n, nmv, tt, 4, 16, w).sum(3), s16), "sad16 != sum of its 8x8 blocks"
+            assert torch.equal(s16.view(n, nmv, tt, 4, 4, w).sum(4), s32), "sad32 != sum of its 16x16 blocks"
+            assert torch.equal(s32.sum(3, keepdim=True), s64), "sad64 != sum of its 32x32 blocks"
+
+
+def _spot_checks(L, planes_host_lookup, g, cur, ref, pad, rng, ctus):
+    wc = cur.shape[1] // 64
+    for ctu in ctus:
+        cy, cx = (ctu // wc) * 64, (ctu % wc) * 64
+        for dy, dx in ((0, 0), (-rng, -rng), (rng, rng), (-rng, rng), (rng, -rng), (3, -2), (-17, 41)):
+            d = np.abs(cur[cy:cy + 64, cx:cx + 64].astype(int)
+                       - ref[pad + cy + dy:pad + cy + dy + 64, pad + cx + dx:pad + cx + dx + 64].astype(int))
+            assert planes_host_lookup(3, L.xmi_sad_surface_index(C.byref(g), 3, ctu, 0, dy, dx)) == d.sum()
+            assert planes_host_lookup(2, L.xmi_sad_surface_index(C.byref(g), 2, ctu, 3, dy, dx)) == d[32:, 32:].sum()
+            assert planes_host_lookup(1, L.xmi_sad_surface_index(C.byref(g), 1, ctu, 6, dy, dx)) == d[16:32, 32:48].sum()
+            assert planes_host_lookup(0, L.xmi_sad_surface_index(C.byref(g), 0, ctu, 8 * 5 + 2, dy, dx)) == d[40:48, 16:24].sum()
+
+
+def test_surface_full_size_1080p_properties(L):
+    """BASELINE configuration 2 at full size (1920x1088, R = 64: 510 CTUs x 16 641 MVs x 85 PUs, 1.5 GB of output), device
+    resident: the whole pyramid must be consistent, and direct SADs at the window corners and a few other MVs must match."""
+    torch = pytest.importorskip("torch")
+    rng, pad, w, h = 64, 80, 1920, 1088
+    cur, ref = make_frames(w, h, pad, seed=7, kind="smooth")
+    nctu = (w // 64) * (h // 64)
+    g = capi.SadGeom(w, h, w, w + 2 * pad, rng)
+    d_cur, d_ref = torch.from_numpy(cur).cuda(), torch.from_numpy(ref).cuda()
+    dts = (torch.int16, torch.int16, torch.int32, torch.int32)
+    planes = [torch.full((layout.plane_elems(nctu, rng, lvl),), -21846, dtype=dts[lvl], device="cuda") for lvl in range(4)]
+    capi.check(L.xmi_sad_surface_dev(C.byref(g), d_cur.data_ptr(), d_ref.data_ptr() + pad * (w + 2 * pad) + pad,
+                                     *[p.data_ptr() for p in planes], 0, nctu, None))
+    torch.cuda.synchronize()
+    upl = [planes[0].view(torch.uint16), planes[1].view(torch.uint16), planes[2], planes[3]]
+    _pyramid_checks(torch, upl, nctu, rng, 0, nctu)
+    _spot_checks(L, lambda lvl, idx: int(upl[lvl][idx].item()), g, cur, ref, pad, rng, (0, 29, 255, 480, 509))
+
+
+def test_surface_2160p_range128_ctu_band(L):
+    """BASELINE configuration 4 geometry (3840x2176, R = 128, 66 049 MVs per CTU): a band of CTUs of the 24 GB surface."""
+    torch = pytest.importorskip("torch")
+    rng, pad, w, h = 128, 144, 3840, 2176
+    cur, ref = make_frames(w, h, pad, seed=9, kind="smooth")
+    nctu = (w // 64) * (h // 64)
+    g = capi.SadGeom(w, h, w, w + 2 * pad, rng)
+    d_cur, d_ref = torch.from_numpy(cur).cuda(), torch.from_numpy(ref).cuda()
+    dts = (torch.int16, torch.int16, torch.int32, torch.int32)
+    planes = [torch.empty((layout.plane_elems(nctu, rng, lvl),), dtype=dts[lvl], device="cuda") for lvl in range(4)]
+    lo, hi = 1000, 1048
+    capi.check(L.xmi_sad_surface_dev(C.byref(g), d_cur.data_ptr(), d_ref.data_ptr() + pad * (w + 2 * pad) + pad,
+                                     *[p.data_ptr() for p in planes], lo, hi, None))
+    torch.cuda.synchronize()
+    upl = [planes[0].view(torch.uint16), planes[1].view(torch.uint16), planes[2], planes[3]]
+    _pyramid_checks(torch, upl, nctu, rng, lo, hi)
+    _spot_checks(L, lambda lvl, idx: int(upl[lvl][idx].item()), g, cur, ref, pad, rng, (lo, lo + 17, hi - 1))
