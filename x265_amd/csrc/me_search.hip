@@ -8,9 +8,13 @@
 // sub-pel points at half and quarter step. Cost = SAD + floor(sqrt(lambda)) * (bits(mvp.x - x) + bits(mvp.y - y)),
 // bits() = xGetComponentBits (src/encode.cpp:194-205). Ties keep the earlier candidate (strict <).
 // Every SAD is computed by the 64 lanes together (v_sad_u8 on dwords, unaligned reference dwords assembled
-// with v_alignbyte_b32, wavefront reduction); sub-pel predictions are lookups in the interpolation planes
-// (interp_planes.hip), which hold exactly what xPredInterLumaBlk would compute.
+// with v_alignbyte_b32, DPP wavefront reduction); sub-pel predictions are lookups in the interpolation planes
+// (interp_planes.hip), which hold exactly what xPredInterLumaBlk would compute. The SADs of one stage (the two
+// predictors + (0,0) + both possible start points; the 4 diamond points; the 9 sub-pel points) are independent
+// and are evaluated together, so a search is about 8 dependent memory round trips instead of 28.
 #include "xmi_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -30,64 +34,89 @@ __device__ __forceinline__ u32 mv_bits(int v)
     return 1u + 2u * (31u - (u32)__clz((int)t));
 }
 
-// SAD of an n x n block: cur is 4-byte aligned, ref has any byte alignment. All 64 lanes return the sum.
-__device__ __forceinline__ u32 wave_sad(const uint8_t *cur, int cs, const uint8_t *ref, int rs, int n, int lane)
-{
-    const int dw_per_row = n >> 2, total = n * dw_per_row;
-    u32 s = 0;
-    for (int d = lane; d < total; d += 64) {
-        const int row = d / dw_per_row, c4 = d - row * dw_per_row;
-        const u32 c = *reinterpret_cast<const u32 *>(cur + (size_t)row * cs + c4 * 4);
-        const uintptr_t a = reinterpret_cast<uintptr_t>(ref + (ptrdiff_t)row * rs + c4 * 4);
-        const u32 *al = reinterpret_cast<const u32 *>(a & ~(uintptr_t)3);
-        const u32 sh = (u32)(a & 3);
-        const u32 lo = al[0];
-        const u32 hi = sh ? al[1] : 0u;
-        s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, sh), c, s);
-    }
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) s += (u32)__shfl_xor((int)s, k);
-    return s;
-}
-
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 
-__global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
+// wavefront sum, returned as a uniform value
+__device__ __forceinline__ u32 wave_sum(u32 x)
 {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (idx >= p.n) return;
-    const xmi_me_request rq = p.req[idx];
-    const int n = rq.size;
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31
+    return (u32)__builtin_amdgcn_readlane(v, 63);
+}
+
+// One search. The reference evaluates its candidates one after the other, but inside each stage they do not
+// depend on each other (only the comparisons do), so a stage's SADs are computed together - all loads of a
+// stage are in flight at once - and the comparisons are then applied in the reference's order.
+template <int N>
+__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int lane)
+{
+    constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
+    constexpr int J = DW < 64 ? 1 : DW / 64;         // block dwords per lane
+    constexpr int KC = J == 1 ? 9 : J == 4 ? 4 : 1;  // candidates evaluated together (bounds the registers)
+    const bool live = DW >= 64 || lane < DW;
     const size_t plane_bytes = (size_t)p.rows * p.stride;
-    const uint8_t *cur = p.cur + (size_t)rq.y0 * p.cur_stride + rq.x0;
     const uint8_t *ref0 = p.planes + (size_t)(p.pad + rq.y0) * p.stride + p.pad + rq.x0;   // integer plane at the PU origin
+    u32 cur[J];
+    // the lane's dwords: d = lane + 64 j -> row lane / DPR + j * (64 / DPR), column dword lane % DPR
+    const int row0 = live ? lane / DPR : 0, c40 = live ? lane % DPR : 0;
+    const int off0 = row0 * p.stride + c40 * 4, joff = (64 / DPR) * p.stride;    // byte offsets inside a reference block
+#pragma unroll
+    for (int j = 0; j < J; j++)
+        cur[j] = live ? *reinterpret_cast<const u32 *>(p.cur + (size_t)(rq.y0 + row0 + j * (64 / DPR)) * p.cur_stride + rq.x0 + c40 * 4) : 0u;
+    // SADs of COUNT candidate blocks (top-left pointers, any byte alignment) against the current block
+    auto eval = [&](auto count_tag, const uint8_t *const *cand, u32 *out) {
+        constexpr int COUNT = decltype(count_tag)::value;
+#pragma unroll
+        for (int k0 = 0; k0 < COUNT; k0 += KC) {
+            u32 lo[KC][J], hi[KC][J], sh[KC];
+#pragma unroll
+            for (int k = 0; k < KC; k++) {
+                if (k0 + k >= COUNT) continue;
+                const uintptr_t a = reinterpret_cast<uintptr_t>(cand[k0 + k]);
+                sh[k] = (u32)(a & 3);
+                const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3) + off0;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    lo[k][j] = live ? *reinterpret_cast<const u32 *>(al + (ptrdiff_t)j * joff) : 0u;
+                    hi[k][j] = (live && sh[k]) ? *reinterpret_cast<const u32 *>(al + (ptrdiff_t)j * joff + 4) : 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KC; k++) {
+                if (k0 + k >= COUNT) continue;
+                u32 s = 0;
+#pragma unroll
+                for (int j = 0; j < J; j++) s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi[k][j], lo[k][j], sh[k]), cur[j], s);
+                out[k0 + k] = wave_sum(s);
+            }
+        }
+    };
+    auto qpel = [&](int mx, int my) { return ref0 + ((my & 3) * 4 + (mx & 3)) * plane_bytes + (ptrdiff_t)(my >> 2) * p.stride + (mx >> 2); };
+    auto ipel = [&](int x, int y) { return ref0 + (ptrdiff_t)y * p.stride + x; };
     const u32 lam = rq.sqrt_lambda;
 
-    // SAD of the block predicted by quarter-pel MV (mx,my): what xPredInterLumaBlk + xSad_AMP would give
-    auto sad_qpel = [&](int mx, int my) {
-        const uint8_t *r = ref0 + ((my & 3) * 4 + (mx & 3)) * plane_bytes + (ptrdiff_t)(my >> 2) * p.stride + (mx >> 2);
-        return wave_sad(cur, p.cur_stride, r, p.stride, n, lane);
-    };
-    auto sad_ipel = [&](int x, int y) { return wave_sad(cur, p.cur_stride, ref0 + (ptrdiff_t)y * p.stride + x, p.stride, n, lane); };
-
-    int n_int = 0, n_sub = 0;
-    int mvp_idx = -1;
-    u32 bsad = 0x7fffffffu, bcost = 0x7fffffffu;
+    // ---- predictor choice, (0,0) and the integer start point ----
     const int passes = ((abs(rq.mvp[0][0] - rq.mvp[1][0]) >> 2) + (abs(rq.mvp[0][1] - rq.mvp[1][1]) >> 2) > 4) ? 2 : 1;
-    for (int i = 0; i < passes; i++) {
-        const u32 s = sad_qpel(rq.mvp[i][0], rq.mvp[i][1]);
-        n_sub++;
-        if (s < bsad) {
-            bsad = s;
-            mvp_idx = i;
-        }
+    u32 s5[5];
+    {
+        const uint8_t *c[5] = { qpel(rq.mvp[0][0], rq.mvp[0][1]), qpel(rq.mvp[1][0], rq.mvp[1][1]), ipel(0, 0),
+                                ipel(rq.mvp[0][0] >> 2, rq.mvp[0][1] >> 2), ipel(rq.mvp[1][0] >> 2, rq.mvp[1][1] >> 2) };
+        eval(std::integral_constant<int, 5>{}, c, s5);
     }
-    const int px = rq.mvp[mvp_idx][0], py = rq.mvp[mvp_idx][1];
+    int n_int = 0, n_sub = passes;
+    const int mvp_idx = (passes == 2 && s5[1] < s5[0]) ? 1 : 0;
+    const u32 bsad = mvp_idx ? s5[1] : s5[0];
+    const int px = mvp_idx ? rq.mvp[1][0] : rq.mvp[0][0], py = mvp_idx ? rq.mvp[1][1] : rq.mvp[0][1];
     auto mvcost = [&](int x, int y) { return lam * (mv_bits(px - x) + mv_bits(py - y)); };
+    u32 bcost = 0x7fffffffu;
     int bmx = 0, bmy = 0, best_k = -1;
     if (!rq.zero_mv_tested) {
-        const u32 c = sad_ipel(0, 0) + mvcost(0, 0);
+        const u32 c = s5[2] + mvcost(0, 0);
         n_int++;
         if (c < bcost) {
             bcost = c;
@@ -96,7 +125,7 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     }
     int omx = px >> 2, omy = py >> 2;
     {
-        const u32 c = sad_ipel(omx, omy) + mvcost(omx * 4, omy * 4);
+        const u32 c = (mvp_idx ? s5[4] : s5[3]) + mvcost(omx * 4, omy * 4);
         n_int++;
         if (c < bcost) {
             bcost = c;
@@ -104,21 +133,30 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
             bmy = omy * 4;
         }
     }
+    // ---- small diamond ----
     const int dia4x[4] = { 0, 0, -1, 1 }, dia4y[4] = { -1, 1, 0, 0 };
     for (int i = 0; i < p.me_range; i++) {
+        int tx[4], ty[4];
+        const uint8_t *c[4];
+        u32 s4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            tx[k] = clip3(rq.mv_min_ipel[0], rq.mv_max_ipel[0], omx + dia4x[k]);
+            ty[k] = clip3(rq.mv_min_ipel[1], rq.mv_max_ipel[1], omy + dia4y[k]);
+            c[k] = ipel(tx[k], ty[k]);
+        }
+        eval(std::integral_constant<int, 4>{}, c, s4);
         bool changed = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int tx = clip3(rq.mv_min_ipel[0], rq.mv_max_ipel[0], omx + dia4x[k]);
-            const int ty = clip3(rq.mv_min_ipel[1], rq.mv_max_ipel[1], omy + dia4y[k]);
-            const u32 c = sad_ipel(tx, ty) + mvcost(tx * 4, ty * 4);
+            const u32 cst = s4[k] + mvcost(tx[k] * 4, ty[k] * 4);
             n_int++;
-            if (c < bcost) {
+            if (cst < bcost) {
                 changed = true;
-                bcost = c;
+                bcost = cst;
                 best_k = k;
-                bmx = tx * 4;
-                bmy = ty * 4;
+                bmx = tx[k] * 4;
+                bmy = ty[k] * 4;
             }
         }
         if (!changed) break;
@@ -131,26 +169,35 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
         bmx = clip3(mnx, mxy, bmx);
         bmy = clip3(mny, mxy, bmy);
     }
+    // ---- half- and quarter-pel rounds ----
     bcost = 0x7fffffffu;
     const int dia9x[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 }, dia9y[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 };
     int step = 2;
     for (int i = 0; i < 2; i++) {
-        bool changed = false;
+        int tx[9], ty[9];
+        const uint8_t *c[9];
+        u32 s9[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const int tx = (int16_t)(bmx + dia9x[k] * step), ty = (int16_t)(bmy + dia9y[k] * step);
-            const u32 c = sad_qpel(tx, ty) + mvcost(tx, ty);
+            tx[k] = (int16_t)(bmx + dia9x[k] * step);
+            ty[k] = (int16_t)(bmy + dia9y[k] * step);
+            c[k] = qpel(tx[k], ty[k]);
+        }
+        eval(std::integral_constant<int, 9>{}, c, s9);
+        int bdx = 0, bdy = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const u32 cst = s9[k] + mvcost(tx[k], ty[k]);
             n_sub++;
-            if (c < bcost) {
-                changed = true;
-                bcost = c;
+            if (cst < bcost) {
+                bcost = cst;
                 best_k = k;
+                bdx = dia9x[k] * step;
+                bdy = dia9y[k] * step;
             }
         }
-        if (changed) {
-            bmx += dia9x[best_k] * step;
-            bmy += dia9y[best_k] * step;
-        }
+        bmx += bdx;       // nothing improved: the offsets stay 0
+        bmy += bdy;
         step >>= 1;
     }
     if (lane == 0) {
@@ -163,6 +210,20 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
         out.n_int_sads = n_int;
         out.n_sub_sads = n_sub;
         p.res[idx] = out;
+    }
+}
+
+__global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (idx >= p.n) return;
+    const xmi_me_request rq = p.req[idx];
+    switch (rq.size) {
+    case 8: search<8>(p, rq, idx, lane); break;
+    case 16: search<16>(p, rq, idx, lane); break;
+    case 32: search<32>(p, rq, idx, lane); break;
+    default: search<64>(p, rq, idx, lane); break;
     }
 }
 
