@@ -8,9 +8,10 @@
 //   SATD (x264) x265_pixel_satd_{4x4,8x8,16x16}_sse4 = (sum over 4x4 tiles of sum|H4 D H4|) / 2
 //                                                        src/x86/pixel-a.asm:1645, 3455, 1787
 //
-// One lane owns one tile (4x4 or 8x8) of one block, keeps the whole residual tile in registers, runs the
+// SATD: one lane owns one tile (4x4 or 8x8) of one block, keeps the whole residual tile in registers, runs the
 // 2-D Hadamard there, and the tiles of a block (consecutive lanes) are summed with a segmented
-// wavefront reduction. HBM traffic is the algorithmic 2*n*n + 4 bytes per pair.
+// wavefront reduction. SAD / SSD of 16-byte aligned arrays: streaming kernel (sum_metric_kernel below).
+// HBM traffic is the algorithmic 2*n*n + 4 bytes per pair.
 #include "xmi_common.h"
 
 namespace {
@@ -93,6 +94,80 @@ __global__ void __launch_bounds__(256) metric_kernel(const uint8_t *a, const uin
     if (blk < count && tile == 0) out[blk] = METRIC == M_SATD_X264 ? v >> 1 : v;
 }
 
+// SAD and SSD are plain sums over the block, so any assignment of bytes to lanes will do: a lane takes 16
+// consecutive bytes of both operands per step (fully coalesced 16-byte loads, 1 KB per wavefront instruction)
+// and the n*n/16 lanes of a block meet in a segmented DPP reduction; a 64x64 block is four steps of one
+// wavefront. SSD of four byte pairs = a.a + b.b - 2 a.b with three v_dot4_u32_u8.
+template <int W>
+__device__ __forceinline__ int group_sum_to_last_lane(int v)
+{
+    if (W >= 2) v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);     // row_shr:1
+    if (W >= 4) v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);     // row_shr:2
+    if (W >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);     // row_shr:4
+    if (W >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    if (W >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1 and 3
+    if (W >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <int N, int METRIC>
+__global__ void __launch_bounds__(256) sum_metric_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int count)
+{
+    constexpr int LPB = N * N / 16 < 64 ? N * N / 16 : 64;     // lanes per block within one step
+    constexpr int STEPS = N * N / 16 / LPB;                    // steps per block (64x64: 4)
+    const int lane = threadIdx.x & 63;
+    const size_t total = (size_t)count * N * N;                // bytes per operand, a multiple of 16
+    const size_t nchunk = (total + 1023) / 1024;               // one chunk = one wavefront step = 1 KB per operand
+    const size_t wave0 = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t c0 = wave0 * STEPS; c0 < nchunk; c0 += nwaves * STEPS) {
+        u32 acc = 0;
+#pragma unroll
+        for (int st = 0; st < STEPS; st++) {
+            const size_t e = (c0 + st) * 1024 + (size_t)lane * 16;
+            if (e < total) {
+                const uint4 va = *reinterpret_cast<const uint4 *>(a + e), vb = *reinterpret_cast<const uint4 *>(b + e);
+                const u32 wa[4] = { va.x, va.y, va.z, va.w }, wb[4] = { vb.x, vb.y, vb.z, vb.w };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (METRIC == M_SAD) {
+                        acc = __builtin_amdgcn_sad_u8(wa[k], wb[k], acc);
+                    } else {
+                        acc = __builtin_amdgcn_udot4(wa[k], wa[k], acc, false);
+                        acc = __builtin_amdgcn_udot4(wb[k], wb[k], acc, false);
+                        acc -= 2u * __builtin_amdgcn_udot4(wa[k], wb[k], 0u, false);
+                    }
+                }
+            }
+        }
+        const u32 v = (u32)group_sum_to_last_lane<LPB>((int)acc);
+        const size_t blk = (c0 * 1024 + (size_t)lane * 16) / ((size_t)N * N);
+        if ((lane & (LPB - 1)) == LPB - 1 && blk < (size_t)count) out[blk] = v;
+    }
+}
+
+template <int N, int METRIC>
+int launch_sum(const uint8_t *a, const uint8_t *b, u32 *out, int count, hipStream_t st)
+{
+    constexpr int STEPS = N * N / 16 < 64 ? 1 : N * N / 16 / 64;
+    const size_t nchunk = ((size_t)count * N * N + 1023) / 1024, work = (nchunk + STEPS - 1) / STEPS;
+    const unsigned blocks = (unsigned)((work + 3) / 4 < 16384 ? (work + 3) / 4 : 16384);
+    hipLaunchKernelGGL((sum_metric_kernel<N, METRIC>), dim3(blocks), dim3(256), 0, st, a, b, out, count);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+template <int METRIC>
+int launch_sum_n(int n, const uint8_t *a, const uint8_t *b, u32 *out, int count, hipStream_t st)
+{
+    switch (n) {
+    case 4: return launch_sum<4, METRIC>(a, b, out, count, st);
+    case 8: return launch_sum<8, METRIC>(a, b, out, count, st);
+    case 16: return launch_sum<16, METRIC>(a, b, out, count, st);
+    case 32: return launch_sum<32, METRIC>(a, b, out, count, st);
+    default: return launch_sum<64, METRIC>(a, b, out, count, st);
+    }
+}
+
 template <int T, int METRIC>
 int launch(const uint8_t *a, const uint8_t *b, u32 *out, int n, int count, hipStream_t st)
 {
@@ -121,6 +196,8 @@ extern "C" int xmi_block_metric_batch_dev(int metric, int n, int count, const ui
         XMI_ARG(n <= 32, "xmi_block_metric_batch_dev: xSatdN has no %dx%d entry", n, n);
         metric = n == 32 ? XMI_METRIC_SATD_HM : XMI_METRIC_SATD_X264;
     }
+    if ((metric == XMI_METRIC_SAD || metric == XMI_METRIC_SSD) && (((uintptr_t)d_a | (uintptr_t)d_b) & 15) == 0)
+        return metric == XMI_METRIC_SAD ? launch_sum_n<M_SAD>(n, d_a, d_b, d_out, count, st) : launch_sum_n<M_SSD>(n, d_a, d_b, d_out, count, st);
     switch (metric) {
     case XMI_METRIC_SAD: return n == 4 ? launch<4, M_SAD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SAD>(d_a, d_b, d_out, n, count, st);
     case XMI_METRIC_SSD: return n == 4 ? launch<4, M_SSD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SSD>(d_a, d_b, d_out, n, count, st);
