@@ -78,6 +78,78 @@ __device__ __forceinline__ u32 tile_value(const uint8_t *a, const uint8_t *b, in
     return s;                                                            // x264 form: halved after the block sum
 }
 
+// SATD of one T x T tile with packed 16-bit arithmetic (|coefficient| <= 255 T^2 <= 16 320): the residual is held
+// as pairs of neighbouring columns, the column transform and the outer stages of the row transform are packed
+// adds/subtracts, and the last row stage, which would combine the two halves of a pair, is folded into the sum:
+// |u + v| + |u - v| = 2 max(|u|, |v|). Returns the same value as tile_value<T, M_SATD_*>.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int T, int METRIC>
+__device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t *b, int n)
+{
+    constexpr int P = T / 2;                  // column pairs per row
+    s16x2 d[T][P];
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+        u32 wa[T / 4], wb[T / 4];
+        if (T == 8) {
+            const uint2 va = *reinterpret_cast<const uint2 *>(a + r * n), vb = *reinterpret_cast<const uint2 *>(b + r * n);
+            wa[0] = va.x;
+            wa[T / 4 - 1] = va.y;
+            wb[0] = vb.x;
+            wb[T / 4 - 1] = vb.y;
+        } else {
+            wa[0] = *reinterpret_cast<const u32 *>(a + r * n);
+            wb[0] = *reinterpret_cast<const u32 *>(b + r * n);
+        }
+#pragma unroll
+        for (int w = 0; w < T / 4; w++) {
+            const s16x2 a01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wa[w], 0x0c010c00u));
+            const s16x2 a23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wa[w], 0x0c030c02u));
+            const s16x2 b01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wb[w], 0x0c010c00u));
+            const s16x2 b23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, wb[w], 0x0c030c02u));
+            d[r][2 * w] = a01 - b01;
+            d[r][2 * w + 1] = a23 - b23;
+        }
+    }
+    // columns: Hadamard over the rows, two columns per operation
+#pragma unroll
+    for (int p = 0; p < P; p++)
+#pragma unroll
+        for (int len = 1; len < T; len <<= 1)
+#pragma unroll
+            for (int i = 0; i < T; i += 2 * len)
+#pragma unroll
+                for (int j = i; j < i + len; j++) {
+                    const s16x2 x = d[j][p], y = d[j + len][p];
+                    d[j][p] = x + y;
+                    d[j + len][p] = x - y;
+                }
+    // rows: the stages that combine different pairs
+    u32 s = 0;
+#pragma unroll
+    for (int r = 0; r < T; r++) {
+#pragma unroll
+        for (int len = 1; len < P; len <<= 1)
+#pragma unroll
+            for (int i = 0; i < P; i += 2 * len)
+#pragma unroll
+                for (int j = i; j < i + len; j++) {
+                    const s16x2 x = d[r][j], y = d[r][j + len];
+                    d[r][j] = x + y;
+                    d[r][j + len] = x - y;
+                }
+        // last stage inside each pair, folded into the magnitude sum
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const s16x2 m = __builtin_elementwise_max(d[r][p], -d[r][p]);
+            s += 2u * (u32)(unsigned short)max(m.x, m.y);
+        }
+    }
+    if (METRIC == M_SATD_HM) return T == 4 ? (s + 1) >> 1 : (s + 2) >> 2;
+    return s;
+}
+
 template <int T, int METRIC>
 __global__ void __launch_bounds__(256) metric_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int n, int count)
 {
@@ -88,7 +160,7 @@ __global__ void __launch_bounds__(256) metric_kernel(const uint8_t *a, const uin
     u32 v = 0;
     if (blk < count) {
         const size_t off = (size_t)blk * n * n + (size_t)(tile / tiles_per_row) * T * n + (size_t)(tile % tiles_per_row) * T;
-        v = tile_value<T, METRIC>(a + off, b + off, n);
+        v = (METRIC == M_SATD_HM || METRIC == M_SATD_X264) ? tile_satd_packed<T, METRIC>(a + off, b + off, n) : tile_value<T, METRIC>(a + off, b + off, n);
     }
     for (int sh = 1; sh < tiles; sh <<= 1) v += (u32)__shfl_xor((int)v, sh);  // tiles of a block sit in consecutive lanes
     if (blk < count && tile == 0) out[blk] = METRIC == M_SATD_X264 ? v >> 1 : v;
@@ -168,6 +240,83 @@ int launch_sum_n(int n, const uint8_t *a, const uint8_t *b, u32 *out, int count,
     }
 }
 
+// SATD with coalesced loads: a wavefront takes 64 transform tiles (whole blocks) per step. Each lane loads 16
+// consecutive bytes of both operands per KB of the chunk and scatters them into a tile-major LDS patch (tile t at
+// t * PITCH bytes, rows of T bytes; the pitch leaves every row read and write free of bank conflicts); then
+// lane t reads tile t back and transforms it in registers as metric_kernel does.
+template <int T, int METRIC, int N>
+__global__ void __launch_bounds__(256) satd_staged_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int count)
+{
+    constexpr int PITCH = T == 8 ? 72 : 20;
+    constexpr int TPR = N / T, TILES = TPR * TPR;              // tiles per block row / per block
+    constexpr int CHUNK = 64 * T * T;                          // bytes per operand and step
+    constexpr int PIECES = CHUNK / 1024;                       // 16-byte pieces per lane and step
+    __shared__ __align__(16) uint8_t s_patch[4][2][64 * PITCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *pa = s_patch[wave][0], *pb = s_patch[wave][1];
+    const size_t total = (size_t)count * N * N;
+    const size_t nchunk = (total + CHUNK - 1) / CHUNK;
+    for (size_t c = (size_t)blockIdx.x * 4 + wave; c < nchunk; c += (size_t)gridDim.x * 4) {
+        const size_t base = c * CHUNK;
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            const int o = k * 1024 + lane * 16;                // byte offset inside the chunk
+            if (base + o >= total) continue;
+            const uint4 va = *reinterpret_cast<const uint4 *>(a + base + o), vb = *reinterpret_cast<const uint4 *>(b + base + o);
+            const int bi = o / (N * N), ob = o % (N * N), row = ob / N, col = ob % N;
+            if (T == 8 && N == 8) {                            // two rows of one tile
+                const int at = bi * PITCH + row * 8;
+                *reinterpret_cast<uint2 *>(pa + at) = make_uint2(va.x, va.y);
+                *reinterpret_cast<uint2 *>(pa + at + 8) = make_uint2(va.z, va.w);
+                *reinterpret_cast<uint2 *>(pb + at) = make_uint2(vb.x, vb.y);
+                *reinterpret_cast<uint2 *>(pb + at + 8) = make_uint2(vb.z, vb.w);
+            } else if (T == 8) {                               // one row piece of two neighbouring tiles
+                const int at = (bi * TILES + (row / 8) * TPR + col / 8) * PITCH + (row % 8) * 8;
+                *reinterpret_cast<uint2 *>(pa + at) = make_uint2(va.x, va.y);
+                *reinterpret_cast<uint2 *>(pa + at + PITCH) = make_uint2(va.z, va.w);
+                *reinterpret_cast<uint2 *>(pb + at) = make_uint2(vb.x, vb.y);
+                *reinterpret_cast<uint2 *>(pb + at + PITCH) = make_uint2(vb.z, vb.w);
+            } else if (N == 8) {                               // 4x4 tiles of an 8x8 block: two rows x two tiles
+                const int at = (bi * TILES + (row / 4) * TPR) * PITCH + (row % 4) * 4;
+                *reinterpret_cast<u32 *>(pa + at) = va.x;
+                *reinterpret_cast<u32 *>(pa + at + PITCH) = va.y;
+                *reinterpret_cast<u32 *>(pa + at + 4) = va.z;
+                *reinterpret_cast<u32 *>(pa + at + PITCH + 4) = va.w;
+                *reinterpret_cast<u32 *>(pb + at) = vb.x;
+                *reinterpret_cast<u32 *>(pb + at + PITCH) = vb.y;
+                *reinterpret_cast<u32 *>(pb + at + 4) = vb.z;
+                *reinterpret_cast<u32 *>(pb + at + PITCH + 4) = vb.w;
+            } else {                                           // 4x4 tiles of a 16x16 block: one row x four tiles
+                const int at = (bi * TILES + (row / 4) * TPR) * PITCH + (row % 4) * 4;
+                *reinterpret_cast<u32 *>(pa + at) = va.x;
+                *reinterpret_cast<u32 *>(pa + at + PITCH) = va.y;
+                *reinterpret_cast<u32 *>(pa + at + 2 * PITCH) = va.z;
+                *reinterpret_cast<u32 *>(pa + at + 3 * PITCH) = va.w;
+                *reinterpret_cast<u32 *>(pb + at) = vb.x;
+                *reinterpret_cast<u32 *>(pb + at + PITCH) = vb.y;
+                *reinterpret_cast<u32 *>(pb + at + 2 * PITCH) = vb.z;
+                *reinterpret_cast<u32 *>(pb + at + 3 * PITCH) = vb.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32 v = tile_satd_packed<T, METRIC>(pa + lane * PITCH, pb + lane * PITCH, T);
+        __builtin_amdgcn_wave_barrier();
+        v = (u32)group_sum_to_last_lane<TILES>((int)v);
+        const size_t blk = (base + (size_t)lane * T * T) / ((size_t)N * N);
+        if ((lane & (TILES - 1)) == TILES - 1 && blk < (size_t)count) out[blk] = METRIC == M_SATD_X264 ? v >> 1 : v;
+    }
+}
+
+template <int T, int METRIC, int N>
+int launch_staged(const uint8_t *a, const uint8_t *b, u32 *out, int count, hipStream_t st)
+{
+    const size_t nchunk = ((size_t)count * N * N + 64 * T * T - 1) / (64 * T * T);
+    const unsigned blocks = (unsigned)((nchunk + 3) / 4 < 8192 ? (nchunk + 3) / 4 : 8192);
+    hipLaunchKernelGGL((satd_staged_kernel<T, METRIC, N>), dim3(blocks), dim3(256), 0, st, a, b, out, count);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
 template <int T, int METRIC>
 int launch(const uint8_t *a, const uint8_t *b, u32 *out, int n, int count, hipStream_t st)
 {
@@ -198,6 +347,14 @@ extern "C" int xmi_block_metric_batch_dev(int metric, int n, int count, const ui
     }
     if ((metric == XMI_METRIC_SAD || metric == XMI_METRIC_SSD) && (((uintptr_t)d_a | (uintptr_t)d_b) & 15) == 0)
         return metric == XMI_METRIC_SAD ? launch_sum_n<M_SAD>(n, d_a, d_b, d_out, count, st) : launch_sum_n<M_SSD>(n, d_a, d_b, d_out, count, st);
+    if ((((uintptr_t)d_a | (uintptr_t)d_b) & 15) == 0) {
+        if (metric == XMI_METRIC_SATD_HM && n == 8) return launch_staged<8, M_SATD_HM, 8>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_HM && n == 16) return launch_staged<8, M_SATD_HM, 16>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_HM && n == 32) return launch_staged<8, M_SATD_HM, 32>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_HM && n == 64) return launch_staged<8, M_SATD_HM, 64>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_X264 && n == 8) return launch_staged<4, M_SATD_X264, 8>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_X264 && n == 16) return launch_staged<4, M_SATD_X264, 16>(d_a, d_b, d_out, count, st);
+    }
     switch (metric) {
     case XMI_METRIC_SAD: return n == 4 ? launch<4, M_SAD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SAD>(d_a, d_b, d_out, n, count, st);
     case XMI_METRIC_SSD: return n == 4 ? launch<4, M_SSD>(d_a, d_b, d_out, n, count, st) : launch<8, M_SSD>(d_a, d_b, d_out, n, count, st);
