@@ -78,11 +78,9 @@ __device__ __forceinline__ u32 tile_value(const uint8_t *a, const uint8_t *b, in
     return s;                                                            // x264 form: halved after the block sum
 }
 
-// SATD of one T x T tile with packed 16-bit arithmetic (|coefficient| <= 255 T^2 <= 16 320): the residual is held
-// as pairs of neighbouring columns, the column transform and the outer stages of the row transform are packed
-// adds/subtracts, and the last row stage, which would combine the two halves of a pair, is folded into the sum:
-// |u + v| + |u - v| = 2 max(|u|, |v|). Returns the same value as tile_value<T, M_SATD_*>.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
+// SATD of one T x T tile with packed 16-bit arithmetic: the residual is unpacked into pairs of neighbouring
+// columns and handed to xmi::hadamard_abs_sum_packed. Returns the same value as tile_value<T, M_SATD_*>.
+using xmi::s16x2;
 
 template <int T, int METRIC>
 __device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t *b, int n)
@@ -112,40 +110,7 @@ __device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t 
             d[r][2 * w + 1] = a23 - b23;
         }
     }
-    // columns: Hadamard over the rows, two columns per operation
-#pragma unroll
-    for (int p = 0; p < P; p++)
-#pragma unroll
-        for (int len = 1; len < T; len <<= 1)
-#pragma unroll
-            for (int i = 0; i < T; i += 2 * len)
-#pragma unroll
-                for (int j = i; j < i + len; j++) {
-                    const s16x2 x = d[j][p], y = d[j + len][p];
-                    d[j][p] = x + y;
-                    d[j + len][p] = x - y;
-                }
-    // rows: the stages that combine different pairs
-    u32 s = 0;
-#pragma unroll
-    for (int r = 0; r < T; r++) {
-#pragma unroll
-        for (int len = 1; len < P; len <<= 1)
-#pragma unroll
-            for (int i = 0; i < P; i += 2 * len)
-#pragma unroll
-                for (int j = i; j < i + len; j++) {
-                    const s16x2 x = d[r][j], y = d[r][j + len];
-                    d[r][j] = x + y;
-                    d[r][j + len] = x - y;
-                }
-        // last stage inside each pair, folded into the magnitude sum
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            const s16x2 m = __builtin_elementwise_max(d[r][p], -d[r][p]);
-            s += 2u * (u32)(unsigned short)max(m.x, m.y);
-        }
-    }
+    const u32 s = xmi::hadamard_abs_sum_packed<T>(d);
     if (METRIC == M_SATD_HM) return T == 4 ? (s + 1) >> 1 : (s + 2) >> 2;
     return s;
 }

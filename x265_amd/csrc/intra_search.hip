@@ -74,8 +74,11 @@ __device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int y, 
     return v;
 }
 
-template <int N>
-__device__ void search(const IntraParams &p, const xmi_intra_request &rq, int idx, uint8_t *s_ref, uint8_t *s_src, int lane)
+// WPR wavefronts work on one request: each prepares the samples for itself and takes every WPR-th pass of modes;
+// s_best (WPR entries of cost, mode) joins them at the end.
+template <int N, int WPR>
+__device__ void search(const IntraParams &p, const xmi_intra_request &rq, int idx, uint8_t *s_ref, uint8_t *s_src, int lane, int sub,
+                       double *s_best_cost, int *s_best_mode)
 {
     constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     constexpr int L = 4 * N + 1;
@@ -142,46 +145,20 @@ __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int id
     double best_cost = 1.7976931348623157e308;
     int best_mode = 64;
     xmi_intra_result *out = p.res + idx;
-    for (int m0 = 0; m0 < 35; m0 += MP) {
+    for (int m0 = sub * MP; m0 < 35; m0 += MP * WPR) {
         const int mode = m0 + lane / T;
         int sum = 0;
         if (mode < 35) {
             const uint8_t *ref = ((fbits >> mode) & 1) ? ref1 : ref0;
-            int d[TS][TS];
+            xmi::s16x2 d[TS][TS / 2];       // residual as pairs of neighbouring columns
 #pragma unroll
             for (int y = 0; y < TS; y++)
 #pragma unroll
-                for (int x = 0; x < TS; x++)
-                    d[y][x] = (int)s_src[(ty + y) * N + tx + x] - pred_sample<N>(ref, mode, ty + y, tx + x, dc, is_luma);
-            // 2-D Hadamard (natural order; the sum of magnitudes does not depend on the row order)
-#pragma unroll
-            for (int y = 0; y < TS; y++)
-#pragma unroll
-                for (int len = 1; len < TS; len <<= 1)
-#pragma unroll
-                    for (int i = 0; i < TS; i += 2 * len)
-#pragma unroll
-                        for (int j = i; j < i + len; j++) {
-                            const int a = d[y][j], b = d[y][j + len];
-                            d[y][j] = a + b;
-                            d[y][j + len] = a - b;
-                        }
-#pragma unroll
-            for (int x = 0; x < TS; x++)
-#pragma unroll
-                for (int len = 1; len < TS; len <<= 1)
-#pragma unroll
-                    for (int i = 0; i < TS; i += 2 * len)
-#pragma unroll
-                        for (int j = i; j < i + len; j++) {
-                            const int a = d[j][x], b = d[j + len][x];
-                            d[j][x] = a + b;
-                            d[j + len][x] = a - b;
-                        }
-#pragma unroll
-            for (int y = 0; y < TS; y++)
-#pragma unroll
-                for (int x = 0; x < TS; x++) sum += abs(d[y][x]);
+                for (int x = 0; x < TS; x += 2) {
+                    d[y][x / 2].x = (short)((int)s_src[(ty + y) * N + tx + x] - pred_sample<N>(ref, mode, ty + y, tx + x, dc, is_luma));
+                    d[y][x / 2].y = (short)((int)s_src[(ty + y) * N + tx + x + 1] - pred_sample<N>(ref, mode, ty + y, tx + x + 1, dc, is_luma));
+                }
+            sum = (int)xmi::hadamard_abs_sum_packed<TS>(d);
             if (TS == 8) sum = (sum + 2) >> 2;          // xCalcHADs8x8 rounding, per tile
         }
         sum = group_sum_to_last_lane<T>(sum);
@@ -204,6 +181,23 @@ __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int id
         if (oc < best_cost || (oc == best_cost && om < best_mode)) {
             best_cost = oc;
             best_mode = om;
+        }
+    }
+    if (WPR > 1) {
+        if (lane == 0) {
+            s_best_cost[sub] = best_cost;
+            s_best_mode[sub] = best_mode;
+        }
+        __syncthreads();
+        if (sub != 0) return;
+#pragma unroll
+        for (int w = 1; w < WPR; w++) {
+            const double oc = s_best_cost[w];
+            const int om = s_best_mode[w];
+            if (oc < best_cost || (oc == best_cost && om < best_mode)) {
+                best_cost = oc;
+                best_mode = om;
+            }
         }
     }
     if (lane == 0) {
@@ -230,20 +224,24 @@ __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int id
     }
 }
 
+// One kernel per PU size, each over the whole request array (wavefronts of other sizes leave at once): the
+// register budget - and with it the number of resident wavefronts that hide the LDS and memory latency of this
+// serial per-PU work - is then set by the size's own needs instead of by the 32x32 instance.
+template <int N>
 __global__ void __launch_bounds__(256) intra_search_kernel(const IntraParams p)
 {
+    constexpr int WPR = 1;       // wavefronts per request (4 was tried for 32x32 and lost: the unrolled code streams through the instruction cache either way)
     __shared__ __align__(16) uint8_t s_ref[4][272];
-    __shared__ __align__(16) uint8_t s_src[4][1024];
+    __shared__ __align__(16) uint8_t s_src[4][N * N];
+    __shared__ double s_best_cost[4];
+    __shared__ int s_best_mode[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 4 + wave;
+    const int idx = WPR == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (idx >= p.n) return;
     const xmi_intra_request rq = p.req[idx];
-    switch (rq.size) {
-    case 4: search<4>(p, rq, idx, s_ref[wave], s_src[wave], lane); break;
-    case 8: search<8>(p, rq, idx, s_ref[wave], s_src[wave], lane); break;
-    case 16: search<16>(p, rq, idx, s_ref[wave], s_src[wave], lane); break;
-    default: search<32>(p, rq, idx, s_ref[wave], s_src[wave], lane); break;
-    }
+    const int size = rq.size == 4 || rq.size == 8 || rq.size == 16 ? rq.size : 32;
+    if (size != N) return;                      // uniform per workgroup when WPR == 4
+    search<N, WPR>(p, rq, idx, s_ref[wave], s_src[wave], lane, WPR == 4 ? wave : 0, s_best_cost, s_best_mode);
 }
 
 }  // namespace
@@ -258,7 +256,11 @@ extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, 
     XMI_ARG(d_src && d_ref_samples && d_req && d_res, "xmi_intra_search_batch_dev: null argument");
     XMI_ARG(src_stride % 4 == 0 && ((uintptr_t)d_src & 3) == 0, "xmi_intra_search_batch_dev: source frame must be 4-byte aligned");
     IntraParams p = { d_src, d_ref_samples, d_req, d_res, src_stride, n };
-    hipLaunchKernelGGL(intra_search_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    const dim3 grid((n + 3) / 4), block(256);
+    hipLaunchKernelGGL(intra_search_kernel<4>, grid, block, 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(intra_search_kernel<8>, grid, block, 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(intra_search_kernel<16>, grid, block, 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(intra_search_kernel<32>, grid, block, 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
