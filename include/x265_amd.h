@@ -142,6 +142,23 @@ typedef struct xmi_intra_result {
 int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
 
+/* ---- frame session: host-pointer batch interface --------------------------------------------------
+ * For a host CTU loop without device pointers of its own. The session holds one picture pair on the device (source
+ * luma, padded previous reconstruction, its 16 quarter-pel planes) and stages request / result tables.
+ * xmi_frame_begin replaces, per P picture, every later xPredInterLumaBlk (src/pixel.cpp:8745) of the motion search;
+ * xmi_frame_me_search a batch of xMotionSearch calls (src/encode.cpp:2815); xmi_frame_intra_search a batch of
+ * the 35-mode loops (src/encode.cpp:4005-4081); xmi_frame_tu_chain a batch of xSubDctQuantRec (src/encode.cpp:3005)
+ * with packed n x n blocks in host memory. All calls are synchronous; one thread per session.
+ * ref_padded points at the first byte of the padded reconstruction ((height + 2 pad) rows of width + 2 pad). */
+typedef struct xmi_frame xmi_frame;
+int xmi_frame_create(int width, int height, int pad, xmi_frame **out);
+int xmi_frame_destroy(xmi_frame *f);
+int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint8_t *ref_padded, int ref_stride);
+int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_range, xmi_me_result *res);
+int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_intra_request *req, int n, xmi_intra_result *res);
+int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const uint8_t *pred, const uint8_t *qp,
+                       const uint8_t *flags, int16_t *level, uint8_t *rec, uint32_t *sum);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

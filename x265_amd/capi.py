@@ -73,6 +73,19 @@ def load():
     if hasattr(L, "xmi_interp_planes_dev"):
         L.xmi_interp_planes_dev.restype = i
         L.xmi_interp_planes_dev.argtypes = [vp, i, i, i, vp, vp]
+    if hasattr(L, "xmi_frame_create"):
+        L.xmi_frame_create.restype = i
+        L.xmi_frame_create.argtypes = [i, i, i, C.POINTER(vp)]
+        L.xmi_frame_destroy.restype = i
+        L.xmi_frame_destroy.argtypes = [vp]
+        L.xmi_frame_begin.restype = i
+        L.xmi_frame_begin.argtypes = [vp, vp, i, vp, i]
+        L.xmi_frame_me_search.restype = i
+        L.xmi_frame_me_search.argtypes = [vp, vp, i, i, vp]
+        L.xmi_frame_intra_search.restype = i
+        L.xmi_frame_intra_search.argtypes = [vp, vp, vp, i, vp]
+        L.xmi_frame_tu_chain.restype = i
+        L.xmi_frame_tu_chain.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "xmi_intra_search_batch_dev"):
         L.xmi_intra_search_batch_dev.restype = i
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
