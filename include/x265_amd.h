@@ -154,6 +154,8 @@ typedef struct xmi_frame xmi_frame;
 int xmi_frame_create(int width, int height, int pad, xmi_frame **out);
 int xmi_frame_destroy(xmi_frame *f);
 int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint8_t *ref_padded, int ref_stride);
+/* copies the 16 quarter-pel planes (plane yFrac*4 + xFrac, each (height + 2 pad) x (width + 2 pad) bytes) to host memory */
+int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes);
 int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_range, xmi_me_result *res);
 int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_intra_request *req, int n, xmi_intra_result *res);
 int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const uint8_t *pred, const uint8_t *qp,

@@ -39,3 +39,30 @@ def test_bitstream_identical_with_gpu_primitives(tmp_path, qp, frames):
     got_g = encode("gpu", yuv, str(tmp_path / "g.265"), w, h, frames, qp)
     assert got_o == (want["md5"], want["bytes"])
     assert got_g == (want["md5"], want["bytes"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-ME encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (27, 8), (37, 8)])
+def test_bitstream_identical_with_gpu_motion_search(tmp_path, qp, frames):
+    """The reference's encoder with every xMotionSearch call served by the GPU library through the frame session
+    (oracle/me_gpu_hook.cpp interposed; one xmi_frame_begin per picture, one request per call): the bitstream, which
+    carries the MD5 of every reconstructed picture, must be the recorded one."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_me", yuv, str(tmp_path / "m.265"), w, h, frames, qp)
+    assert got == (want["md5"], want["bytes"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_planes")), reason="GPU-planes encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_interpolation_planes(tmp_path, qp, frames):
+    """The reference's encoder with xPredInterLumaBlk replaced by copies out of the GPU-built quarter-pel planes
+    (oracle/planes_gpu_hook.cpp interposed; motion search, merge candidates and motion compensation all read them)."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_planes", yuv, str(tmp_path / "p.265"), w, h, frames, qp)
+    assert got == (want["md5"], want["bytes"])

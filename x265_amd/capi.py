@@ -80,6 +80,8 @@ def load():
         L.xmi_frame_destroy.argtypes = [vp]
         L.xmi_frame_begin.restype = i
         L.xmi_frame_begin.argtypes = [vp, vp, i, vp, i]
+        L.xmi_frame_planes_host.restype = i
+        L.xmi_frame_planes_host.argtypes = [vp, vp]
         L.xmi_frame_me_search.restype = i
         L.xmi_frame_me_search.argtypes = [vp, vp, i, i, vp]
         L.xmi_frame_intra_search.restype = i

@@ -3,6 +3,7 @@
 // previous reconstruction and its 16 quarter-pel planes - and staging buffers for request and result tables.
 //   xmi_frame_begin          once per P picture: upload source + padded reconstruction, build the planes
 //                            (what xPredInterLumaBlk, src/pixel.cpp:8745, would compute per candidate)
+//   xmi_frame_planes_host    the 16 planes back to host memory (a CPU search can then read predictions instead of filtering)
 //   xmi_frame_me_search      a batch of xMotionSearch calls (src/encode.cpp:2815), host request/result tables
 //   xmi_frame_intra_search   a batch of 35-mode intra searches (src/encode.cpp:4005-4081)
 //   xmi_frame_tu_chain       a batch of xSubDctQuantRec chains (src/encode.cpp:3005), host arrays
@@ -92,6 +93,14 @@ int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint
     if (rc != XMI_OK) return rc;
     XMI_HIP(hipStreamSynchronize(f->stream));
     f->has_picture = true;
+    return XMI_OK;
+}
+
+int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes)
+{
+    XMI_ARG(f && f->has_picture && planes, "xmi_frame_planes_host: no picture or null destination");
+    XMI_HIP(hipMemcpyAsync(planes, f->d_planes, 16 * (size_t)f->rows * f->stride, hipMemcpyDeviceToHost, f->stream));
+    XMI_HIP(hipStreamSynchronize(f->stream));
     return XMI_OK;
 }
 
