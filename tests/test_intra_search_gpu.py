@@ -107,6 +107,34 @@ def test_intra_search_matches_oracle(L, seed):
         assert (res[i].best_mode, res[i].pred_idx, res[i].best_cost) == (out.best_mode, out.pred_idx, out.best_cost), f"request {i}"
 
 
+def test_intra_search_replays_encoder_trace(L):
+    """The kernel on the searches the reference's encoder ran (tests/golden/intra_trace.npz, recorded from a
+    bit-identical encode): the 35 SATDs of every stored PU, and the decision that follows from them."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intra_trace.npz"))
+    for n in (4, 8, 16, 32):
+        t = f"n{n}_"
+        src, raw, want = g[t + "src"], g[t + "raw"], g[t + "satd"]
+        nc = len(src)
+        per_row = 64
+        frame = np.zeros((((nc + per_row - 1) // per_row) * 32, per_row * 32), np.uint8)
+        reqs = (capi.IntraRequest * nc)()
+        refs = np.zeros((nc, capi.INTRA_REF_PITCH), np.uint8)
+        for i in range(nc):
+            y0, x0 = (i // per_row) * 32, (i % per_row) * 32
+            frame[y0:y0 + n, x0:x0 + n] = src[i]
+            rq = reqs[i]
+            rq.x0, rq.y0, rq.size = x0, y0, n
+            rq.valids, rq.strong_smoothing = int(g[t + "valids"][i]), int(g[t + "strong"][i])
+            rq.mpm[0], rq.mpm[1], rq.mpm[2] = 0, 1, 26
+            rq.sqrt_lambda = 4.7
+            refs[i, :4 * n + 1] = raw[i]
+        res = run_gpu(L, frame, reqs, refs)
+        for i in range(nc):
+            np.testing.assert_array_equal(np.array(res[i].satd[:], np.uint32), want[i], err_msg=f"{n}x{n} search {i}")
+            cost = want[i].astype(np.float64) + np.where(np.arange(35) == 0, 1.0, np.where(np.isin(np.arange(35), (1, 26)), 2.0, 3.0)) * 4.7
+            assert res[i].best_mode == int(np.argmin(cost)) and res[i].best_cost == cost.min()
+
+
 def test_intra_search_empty_and_errors(L):
     assert L.xmi_intra_search_batch_dev(None, 0, None, None, 0, None, None) == 0
     a = torch.zeros(256, dtype=torch.uint8, device="cuda")

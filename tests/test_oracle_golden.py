@@ -214,3 +214,19 @@ def test_motion_search_replays_encoder_trace(lib, golden_dir):
             assert got == tuple(int(v) for v in want), f"picture {poc} PU ({x},{y}) size {size}: oracle {got} encoder {tuple(want)}"
             n += 1
     assert n > 500
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_search_replays_encoder_trace(lib, golden_dir, n):
+    """The intra mode searches the reference's encoder ran on the 416x240 clip (oracle/gen_intra_trace.py: samples before
+    padding, availability bits, source block, SATD per mode from a bit-identical encode): the oracle obtains the same
+    35 SATDs from the same inputs - padding, smoothing, prediction and SATD on real picture content."""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "intra_trace.npz"))
+    t = f"n{n}_"
+    mpm = np.array([0, 1, 26], np.uint8)
+    for i in range(len(g[t + "valids"])):
+        out = O.OrcIntraResult()
+        src, raw = np.ascontiguousarray(g[t + "src"][i]), np.ascontiguousarray(g[t + "raw"][i])
+        lib.orc_intra_search(O.p(src), n, O.p(raw), n, int(g[t + "valids"][i]), int(g[t + "strong"][i]), O.p(mpm), 4.7, C.byref(out))
+        np.testing.assert_array_equal(np.array(out.satd[:], np.uint32), g[t + "satd"][i], err_msg=f"{n}x{n} search {i}")
