@@ -4,7 +4,7 @@
 A step = one P-frame: the full 85-PU SAD pyramid of every CTU over the [-R,R]^2 integer search window
 (current frame vs. the padded previous frame), computed by libx265_amd.so from frames that are
 already resident in HBM. Workload at N=1: 1920x1080 (coded 1920x1088, 510 CTUs), R=64, synthetic
-IPPP video - BASELINE.json configs[1]. With --gpus N every rank runs the same number of steps on its
+IPPP video (the 1080p configuration the headline metric is quoted on). With --gpus N every rank runs the same number of steps on its
 own GOP segment (weak scaling, no data-path collective); the only exchange is the final gather of
 per-rank statistics.
 

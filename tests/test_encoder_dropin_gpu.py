@@ -3,7 +3,7 @@ oracle/_ref by `make -C oracle enc`) run with three sets of pixel primitives mus
   x265_refsse  reference C++/SSE4 primitives (+ oracle for the NASM-only SATD/SSD entries)
   x265_oracle  all primitives from the CPU oracle
   x265_gpu     all primitives from libx265_amd through the drop-in table (per-call GPU kernels)
-Config 0 of the baseline: 416x240, 8 frames, IPPP, CPU-sized. The md5s in tests/golden/encoder_md5.json were
+The CPU-sized configuration: 416x240, 8 frames, IPPP, CPU-sized. The md5s in tests/golden/encoder_md5.json were
 written in the development container by the refsse build (tools/enc_parity.py --write)."""
 import hashlib
 import json

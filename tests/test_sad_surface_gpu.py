@@ -151,7 +151,7 @@ def _spot_checks(L, planes_host_lookup, g, cur, ref, pad, rng, ctus):
 
 
 def test_surface_full_size_1080p_properties(L):
-    """BASELINE configuration 2 at full size (1920x1088, R = 64: 510 CTUs x 16 641 MVs x 85 PUs, 1.5 GB of output), device
+    """The 1080p benchmark configuration at full size (1920x1088, R = 64: 510 CTUs x 16 641 MVs x 85 PUs, 1.5 GB of output), device
     resident: the whole pyramid must be consistent, and direct SADs at the window corners and a few other MVs must match."""
     torch = pytest.importorskip("torch")
     rng, pad, w, h = 64, 80, 1920, 1088
@@ -170,7 +170,7 @@ def test_surface_full_size_1080p_properties(L):
 
 
 def test_surface_2160p_range128_ctu_band(L):
-    """BASELINE configuration 4 geometry (3840x2176, R = 128, 66 049 MVs per CTU): a band of CTUs of the 24 GB surface."""
+    """The 2160p configuration (3840x2176, R = 128, 66 049 MVs per CTU): a band of CTUs of the 24 GB surface."""
     torch = pytest.importorskip("torch")
     rng, pad, w, h = 128, 144, 3840, 2176
     cur, ref = make_frames(w, h, pad, seed=9, kind="smooth")
