@@ -78,11 +78,27 @@ def cpu_baseline(cur, refp, rng, budget_s=12.0):
         kind, cands, sec = run(2)                      # calibrate
         n = max(2, min((w // 64) * (h // 64), int(2 * budget_s / max(sec, 1e-6))))
         kind, cands, sec = run(n)
-        return {"value": round(cands / sec / 1e9, 5), "unit": "Gcand/s", "cores": 1, "kind": kind,
-                "sample": f"{n} of {(w // 64) * (h // 64)} CTUs x {(2 * rng + 1) ** 2} MVs x 85 PUs, one xSad call per "
-                          f"candidate, {sec:.1f} s single thread"}
+        out = {"value": round(cands / sec / 1e9, 5), "unit": "Gcand/s", "cores": 1, "kind": kind,
+               "sample": f"{n} of {(w // 64) * (h // 64)} CTUs x {(2 * rng + 1) ** 2} MVs x 85 PUs, one xSad call per "
+                         f"candidate, {sec:.1f} s single thread"}
+        prims = cpu_primitives(ref_lib)
+        if prims:
+            out["primitives"] = prims
+        return out
     finally:
         os.unlink(path)
+
+
+def cpu_primitives(ref_lib, seconds_per_case=0.25):
+    """Per-block primitives on one host core (same thread budget as above): the reference's compiled functions
+    where they exist, the restatement where the reference binds NASM. Mblk/s per primitive and size."""
+    exe = os.path.join(ROOT, "oracle", "cpu_primitives")
+    if not os.path.exists(exe):
+        return None
+    args = [exe, ref_lib if os.path.exists(ref_lib) else "", str(seconds_per_case)]
+    lines = subprocess.run(args, capture_output=True, text=True, timeout=120).stdout.splitlines()
+    rows = [json.loads(x) for x in lines if x.startswith("{")]
+    return {r["cpu"]: {"Mblk_per_s": r["Mblk_per_s"], "GBps": r["GBps"], "kind": r["kind"]} for r in rows}
 
 
 def main():
