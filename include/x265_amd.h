@@ -112,6 +112,15 @@ typedef struct xmi_me_result {
 } xmi_me_result;
 int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows, int pad,
                             const xmi_me_request *d_req, int n, int me_range, xmi_me_result *d_res, void *stream);
+/* Same search, same results, but the integer candidates (the SAD calls of src/encode.cpp:2885-2931) are read
+ * from the resident SAD surface that xmi_sad_surface_dev produced for this picture pair (g: its width, height
+ * and range; strides unused) instead of being computed. Applies per request when the PU lies on the CTU
+ * quad-tree (x0, y0 multiples of size) and per stage when its candidates are inside [-range, range]^2; anything
+ * else is computed as above. d_cur / plane 0 must be the frames the surface was made from. */
+int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows, int pad,
+                                    const xmi_sad_geom *g, const uint16_t *d_sad8, const uint16_t *d_sad16,
+                                    const uint32_t *d_sad32, const uint32_t *d_sad64, const xmi_me_request *d_req, int n,
+                                    int me_range, xmi_me_result *d_res, void *stream);
 
 /* ---- intra luma mode search ---------------------------------------------------------------------
  * The 35-mode SATD search of xEncDecideCU_Intra (src/encode.cpp:4005-4081) for a batch of PUs, one request per
@@ -154,6 +163,10 @@ typedef struct xmi_frame xmi_frame;
 int xmi_frame_create(int width, int height, int pad, xmi_frame **out);
 int xmi_frame_destroy(xmi_frame *f);
 int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint8_t *ref_padded, int ref_stride);
+/* Optional, after xmi_frame_begin: build the SAD surface of the picture pair (xmi_sad_surface_dev, integer MVs in
+ * [-range, range]^2; width and height must be multiples of 64 and pad >= range + 4). Later xmi_frame_me_search
+ * calls for this picture then read their integer candidates from it. The next xmi_frame_begin drops it. */
+int xmi_frame_sad_surface(xmi_frame *f, int range);
 /* copies the 16 quarter-pel planes (plane yFrac*4 + xFrac, each (height + 2 pad) x (width + 2 pad) bytes) to host memory */
 int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes);
 int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_range, xmi_me_result *res);

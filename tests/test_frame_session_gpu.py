@@ -49,6 +49,12 @@ def test_session_replays_encoder_motion_searches(L, golden_dir):
             for i in range(n):
                 got = (res[i].mv[0], res[i].mv[1], res[i].best_cost, res[i].best_sad, res[i].mvp_idx)
                 assert got == tuple(int(v) for v in want[i]), f"picture {poc} request {i}"
+            # the same batch with the picture's SAD surface resident: integer candidates become lookups
+            assert L.xmi_frame_sad_surface(sess, 128) == -1 and b"pad" in L.xmi_last_error()
+            capi.check(L.xmi_frame_sad_surface(sess, 64))
+            res2 = (capi.MeResult * n)()
+            capi.check(L.xmi_frame_me_search(sess, reqs, n, 32, res2))
+            assert bytes(res2) == bytes(res), f"picture {poc}: surface-backed search differs"
         # a request outside the picture is refused, not executed
         bad = (capi.MeRequest * 1)()
         bad[0].x0, bad[0].y0, bad[0].size = w - 4, 0, 8

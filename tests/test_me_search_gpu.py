@@ -31,13 +31,37 @@ def make_video(w, h, seed, motion=(3, 2), noise=6):
     return np.ascontiguousarray(cur), np.ascontiguousarray(ref)
 
 
-def run_case(L, orc, w, h, seed, nreq, motion, lambdas, noise=6):
+def make_surface(L, d_cur, d_ref, w, h, stride, pad, rng_):
+    """SAD surface of the pair (xmi_sad_surface_dev) -> (geom, planes)."""
+    from x265_amd import layout
+    nctu = (w // 64) * (h // 64)
+    geom = capi.SadGeom(w, h, w, stride, rng_)
+    planes = [torch.zeros(layout.plane_elems(nctu, rng_, lv), dtype=torch.int16 if lv < 2 else torch.int32, device="cuda") for lv in range(4)]
+    capi.check(L.xmi_sad_surface_dev(C.byref(geom), d_cur.data_ptr(), d_ref.data_ptr() + pad * stride + pad, planes[0].data_ptr(),
+                                     planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), 0, nctu, None))
+    return geom, planes
+
+
+def search(L, d_cur, cur_stride, planes, stride, rows, pad, d_req, nreq, d_res, surface=None):
+    if surface is None:
+        capi.check(L.xmi_me_search_batch_dev(d_cur.data_ptr(), cur_stride, planes.data_ptr(), stride, rows, pad,
+                                             d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
+    else:
+        geom, sp = surface
+        capi.check(L.xmi_me_search_surface_batch_dev(d_cur.data_ptr(), cur_stride, planes.data_ptr(), stride, rows, pad, C.byref(geom),
+                                                     sp[0].data_ptr(), sp[1].data_ptr(), sp[2].data_ptr(), sp[3].data_ptr(),
+                                                     d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
+    torch.cuda.synchronize()
+
+
+def run_case(L, orc, w, h, seed, nreq, motion, lambdas, noise=6, surface_range=None):
     cur, ref = make_video(w, h, seed, motion, noise)
     rows, stride = ref.shape
     d_ref = torch.from_numpy(ref).cuda()
     planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
     capi.check(L.xmi_interp_planes_dev(d_ref.data_ptr(), stride, rows, stride, planes.data_ptr(), None))
     d_cur = torch.from_numpy(cur).cuda()
+    surface = make_surface(L, d_cur, d_ref, w, h, stride, PAD, surface_range) if surface_range else None
     rng = np.random.default_rng(seed + 1)
     reqs = (capi.MeRequest * nreq)()
     for i in range(nreq):
@@ -64,9 +88,7 @@ def run_case(L, orc, w, h, seed, nreq, motion, lambdas, noise=6):
         rq.sqrt_lambda = int(math.sqrt(lambdas[i % len(lambdas)]))
     d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
     d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
-    capi.check(L.xmi_me_search_batch_dev(d_cur.data_ptr(), cur.strides[0], planes.data_ptr(), stride, rows, PAD,
-                                         d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
-    torch.cuda.synchronize()
+    search(L, d_cur, cur.strides[0], planes, stride, rows, PAD, d_req, nreq, d_res, surface)
     res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
     blk = np.zeros((64, 64), np.uint8)
     moved = 0
@@ -95,6 +117,18 @@ def test_me_search_matches_oracle(L):
     assert moved > 20       # the diamond walk is exercised, not only the early exits
     run_case(L, orc, 192, 128, seed=9, nreq=120, motion=(-7, 5), lambdas=lambdas, noise=2)
     run_case(L, orc, 128, 128, seed=2, nreq=60, motion=(0, 0), lambdas=[1.0, 50.0], noise=0)   # exact match: cost < 800 exits
+
+
+@pytest.mark.parametrize("surface_range", [16, 32, 64])
+def test_me_search_on_sad_surface_matches_oracle(L, surface_range):
+    """Integer candidates looked up in the resident SAD surface instead of computed: same results. Small ranges put many
+    candidates outside the surface window, unaligned PUs are off the CTU quad-tree: both fall back to computing."""
+    orc = O.load()
+    lambdas = [0.578 * 2 ** ((qp - 12) / 3.0) for qp in (22, 27, 32, 37)] + [400.0, 2500.0]
+    moved = run_case(L, orc, 256, 192, seed=5, nreq=240, motion=(3, 2), lambdas=lambdas, surface_range=surface_range)
+    assert moved > 20
+    run_case(L, orc, 192, 128, seed=9, nreq=120, motion=(-7, 5), lambdas=lambdas, noise=2, surface_range=surface_range)
+    run_case(L, orc, 128, 128, seed=2, nreq=60, motion=(0, 0), lambdas=[1.0, 50.0], noise=0, surface_range=surface_range)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -129,9 +163,11 @@ def test_me_search_matches_reference_golden(L, tag):
         assert got == tuple(int(v) for v in want[i]), f"clip {tag} request {i}: gpu {got} reference {tuple(want[i])}"
 
 
-def test_me_search_replays_encoder_trace(L):
+@pytest.mark.parametrize("use_surface", [False, True])
+def test_me_search_replays_encoder_trace(L, use_surface):
     """The kernel on the requests the reference's encoder issued while coding three P pictures (inputs and
-    outputs recorded from a bit-identical encode, tests/golden/me_trace.npz): one batch per picture."""
+    outputs recorded from a bit-identical encode, tests/golden/me_trace.npz): one batch per picture; computed
+    integer candidates, and integer candidates read from the picture pair's SAD surface (range 64)."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "me_trace.npz"))
     pad = int(g["pad"][0])
@@ -154,9 +190,9 @@ def test_me_search_replays_encoder_trace(L):
             rq.sqrt_lambda = int(math.sqrt(float(lam[i])))
         d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
         d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
-        capi.check(L.xmi_me_search_batch_dev(d_cur.data_ptr(), cur.strides[0], planes.data_ptr(), stride, rows, pad,
-                                             d_req.data_ptr(), nreq, 32, d_res.data_ptr(), None))
-        torch.cuda.synchronize()
+        h, w = cur.shape
+        surface = make_surface(L, d_cur, d_ref, w, h, stride, pad, 64) if use_surface else None
+        search(L, d_cur, cur.strides[0], planes, stride, rows, pad, d_req, nreq, d_res, surface)
         res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
         for i in range(nreq):
             got = (res[i].mv[0], res[i].mv[1], res[i].best_cost, res[i].best_sad, res[i].mvp_idx)
@@ -167,3 +203,6 @@ def test_me_search_empty_and_errors(L):
     assert L.xmi_me_search_batch_dev(None, 0, None, 0, 0, 0, None, 0, 32, None, None) == 0
     a = torch.zeros(64, dtype=torch.uint8, device="cuda")
     assert L.xmi_me_search_batch_dev(a.data_ptr(), 6, a.data_ptr(), 8, 8, 0, a.data_ptr(), 1, 32, a.data_ptr(), None) == -1
+    bad = capi.SadGeom(100, 64, 100, 200, 64)      # not a CTU multiple
+    assert L.xmi_me_search_surface_batch_dev(a.data_ptr(), 8, a.data_ptr(), 8, 8, 0, C.byref(bad), a.data_ptr(), a.data_ptr(), a.data_ptr(),
+                                             a.data_ptr(), a.data_ptr(), 1, 32, a.data_ptr(), None) == -1

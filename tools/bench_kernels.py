@@ -120,6 +120,41 @@ for size, nreq in ((8, 28000), (16, 9500), (32, 2400), (64, 600), (0, 39000)):
                       "Msearch_per_s": round(nreq / t / 1e6, 2), "sads_per_search": round(sads / nreq, 1),
                       "Msad_per_s": round(sads / t / 1e6, 1)}))
 
+# ---- the same searches on quad-tree positions: integer candidates computed vs looked up in the resident SAD surface ----
+from x265_amd import layout  # noqa: E402
+
+R = 64
+nctu = (W // 64) * (H // 64)
+geom = capi.SadGeom(W, H, W, stride, R)
+sp = [torch.zeros(layout.plane_elems(nctu, R, lv), dtype=torch.int16 if lv < 2 else torch.int32, device="cuda") for lv in range(4)]
+capi.check(L.xmi_sad_surface_dev(C.byref(geom), cur.data_ptr(), ref.data_ptr() + PAD * stride + PAD, sp[0].data_ptr(), sp[1].data_ptr(),
+                                 sp[2].data_ptr(), sp[3].data_ptr(), 0, nctu, s))
+nreq = 39000
+reqs = (capi.MeRequest * nreq)()
+for i in range(nreq):
+    n = int(rng.choice([8, 8, 8, 8, 8, 8, 16, 16, 32, 64]))
+    rq = reqs[i]
+    rq.size = n
+    rq.x0 = int(rng.integers(0, W // n)) * n
+    rq.y0 = int(rng.integers(0, H // n)) * n
+    rq.mvp[0][0], rq.mvp[0][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+    rq.mvp[1][0], rq.mvp[1][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+    rq.zero_mv_tested = 0
+    rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+    rq.sqrt_lambda = int(math.sqrt(0.578 * 2 ** ((22 - 12) / 3.0)))
+d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+d_res2 = torch.zeros_like(d_res)
+t0 = timeit(lambda: capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD,
+                                                         d_req.data_ptr(), nreq, 32, d_res.data_ptr(), s)), iters=5)
+t1 = timeit(lambda: capi.check(L.xmi_me_search_surface_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, C.byref(geom),
+                                                                 sp[0].data_ptr(), sp[1].data_ptr(), sp[2].data_ptr(), sp[3].data_ptr(),
+                                                                 d_req.data_ptr(), nreq, 32, d_res2.data_ptr(), s)), iters=5)
+assert torch.equal(d_res, d_res2)
+print(json.dumps({"kernel": "me_search mixed, quad-tree positions", "requests": nreq, "ms_computed": round(t0 * 1e3, 3),
+                  "ms_surface_lookup": round(t1 * 1e3, 3)}))
+del sp
+
 # ---- intra mode search: every PU of a 1080p frame at each depth (35 modes, prediction + SATD) ----
 frame = torch.from_numpy(f1).cuda()
 for n in (4, 8, 16, 32):

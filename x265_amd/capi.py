@@ -80,6 +80,8 @@ def load():
         L.xmi_frame_destroy.argtypes = [vp]
         L.xmi_frame_begin.restype = i
         L.xmi_frame_begin.argtypes = [vp, vp, i, vp, i]
+        L.xmi_frame_sad_surface.restype = i
+        L.xmi_frame_sad_surface.argtypes = [vp, i]
         L.xmi_frame_planes_host.restype = i
         L.xmi_frame_planes_host.argtypes = [vp, vp]
         L.xmi_frame_me_search.restype = i
@@ -94,6 +96,8 @@ def load():
     if hasattr(L, "xmi_me_search_batch_dev"):
         L.xmi_me_search_batch_dev.restype = i
         L.xmi_me_search_batch_dev.argtypes = [vp, i, vp, i, i, i, vp, i, i, vp, vp]
+        L.xmi_me_search_surface_batch_dev.restype = i
+        L.xmi_me_search_surface_batch_dev.argtypes = [vp, i, vp, i, i, i, C.POINTER(SadGeom), vp, vp, vp, vp, vp, i, i, vp, vp]
     if hasattr(L, "xmi_block_metric_batch_dev"):
         L.xmi_block_metric_batch_dev.restype = i
         L.xmi_block_metric_batch_dev.argtypes = [i, i, i, vp, vp, vp, vp]

@@ -3,6 +3,7 @@
 // previous reconstruction and its 16 quarter-pel planes - and staging buffers for request and result tables.
 //   xmi_frame_begin          once per P picture: upload source + padded reconstruction, build the planes
 //                            (what xPredInterLumaBlk, src/pixel.cpp:8745, would compute per candidate)
+//   xmi_frame_sad_surface    optional: the SAD surface of the pair; motion searches then look integer SADs up
 //   xmi_frame_planes_host    the 16 planes back to host memory (a CPU search can then read predictions instead of filtering)
 //   xmi_frame_me_search      a batch of xMotionSearch calls (src/encode.cpp:2815), host request/result tables
 //   xmi_frame_intra_search   a batch of 35-mode intra searches (src/encode.cpp:4005-4081)
@@ -15,6 +16,9 @@
 struct xmi_frame {
     int width, height, pad, stride, rows;
     uint8_t *d_cur = nullptr, *d_ref = nullptr, *d_planes = nullptr;
+    void *d_surf[4] = { nullptr, nullptr, nullptr, nullptr };   // SAD surface planes (8x8, 16x16, 32x32, 64x64), allocated on first use
+    int surf_alloc_range = 0;         // range the planes were sized for
+    int surf_range = 0;               // range of the surface computed for the current picture; 0 = none
     uint8_t *d_stage = nullptr;       // request / result / block staging, grown on demand
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
@@ -76,6 +80,8 @@ int xmi_frame_destroy(xmi_frame *f)
     if (f->d_ref) (void)hipFree(f->d_ref);
     if (f->d_planes) (void)hipFree(f->d_planes);
     if (f->d_stage) (void)hipFree(f->d_stage);
+    for (void *q : f->d_surf)
+        if (q) (void)hipFree(q);
     delete f;
     return XMI_OK;
 }
@@ -89,10 +95,38 @@ int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint
                              hipMemcpyHostToDevice, f->stream));
     XMI_HIP(hipMemcpy2DAsync(f->d_ref, (size_t)f->stride, ref_padded, (size_t)ref_stride, (size_t)f->stride, (size_t)f->rows,
                              hipMemcpyHostToDevice, f->stream));
+    f->surf_range = 0;
     int rc = xmi_interp_planes_dev(f->d_ref, f->stride, f->rows, f->stride, f->d_planes, f->stream);
     if (rc != XMI_OK) return rc;
     XMI_HIP(hipStreamSynchronize(f->stream));
     f->has_picture = true;
+    return XMI_OK;
+}
+
+int xmi_frame_sad_surface(xmi_frame *f, int range)
+{
+    XMI_ARG(f && f->has_picture, "xmi_frame_sad_surface: no picture (call xmi_frame_begin first)");
+    XMI_ARG(f->width % 64 == 0 && f->height % 64 == 0, "xmi_frame_sad_surface: %dx%d is not a multiple of the 64x64 CTU", f->width, f->height);
+    XMI_ARG(range == 16 || range == 32 || range == 64 || range == 128, "xmi_frame_sad_surface: range %d not in {16,32,64,128}", range);
+    XMI_ARG(f->pad >= range + 4, "xmi_frame_sad_surface: pad %d is smaller than range + 4 = %d", f->pad, range + 4);
+    const xmi_sad_geom g = { f->width, f->height, f->width, f->stride, range };
+    if (f->surf_alloc_range != range) {
+        for (void *&q : f->d_surf) {
+            if (q) (void)hipFree(q);
+            q = nullptr;
+        }
+        f->surf_alloc_range = 0;
+        for (int level = 0; level < 4; level++)
+            XMI_HIP(hipMalloc(&f->d_surf[level], xmi_sad_surface_elems(&g, level) * (level < 2 ? 2 : 4)));
+        f->surf_alloc_range = range;
+    }
+    f->surf_range = 0;
+    int rc = xmi_sad_surface_dev(&g, f->d_cur, f->d_ref + (size_t)f->pad * f->stride + f->pad, static_cast<uint16_t *>(f->d_surf[0]),
+                                 static_cast<uint16_t *>(f->d_surf[1]), static_cast<uint32_t *>(f->d_surf[2]),
+                                 static_cast<uint32_t *>(f->d_surf[3]), 0, (f->width / 64) * (f->height / 64), f->stream);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipStreamSynchronize(f->stream));
+    f->surf_range = range;
     return XMI_OK;
 }
 
@@ -119,7 +153,15 @@ int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_r
     xmi_me_request *d_req = reinterpret_cast<xmi_me_request *>(f->d_stage);
     xmi_me_result *d_res = reinterpret_cast<xmi_me_result *>(f->d_stage + rq_bytes);
     XMI_HIP(hipMemcpyAsync(d_req, req, (size_t)n * sizeof(xmi_me_request), hipMemcpyHostToDevice, f->stream));
-    rc = xmi_me_search_batch_dev(f->d_cur, f->width, f->d_planes, f->stride, f->rows, f->pad, d_req, n, me_range, d_res, f->stream);
+    if (f->surf_range) {
+        const xmi_sad_geom g = { f->width, f->height, f->width, f->stride, f->surf_range };
+        rc = xmi_me_search_surface_batch_dev(f->d_cur, f->width, f->d_planes, f->stride, f->rows, f->pad, &g,
+                                             static_cast<const uint16_t *>(f->d_surf[0]), static_cast<const uint16_t *>(f->d_surf[1]),
+                                             static_cast<const uint32_t *>(f->d_surf[2]), static_cast<const uint32_t *>(f->d_surf[3]), d_req, n,
+                                             me_range, d_res, f->stream);
+    } else {
+        rc = xmi_me_search_batch_dev(f->d_cur, f->width, f->d_planes, f->stride, f->rows, f->pad, d_req, n, me_range, d_res, f->stream);
+    }
     if (rc != XMI_OK) return rc;
     XMI_HIP(hipMemcpyAsync(res, d_res, rs_bytes, hipMemcpyDeviceToHost, f->stream));
     XMI_HIP(hipStreamSynchronize(f->stream));

@@ -12,6 +12,11 @@
 // (interp_planes.hip), which hold exactly what xPredInterLumaBlk would compute. The SADs of one stage (the two
 // predictors + (0,0) + both possible start points; the 4 diamond points; the 9 sub-pel points) are independent
 // and are evaluated together, so a search is about 8 dependent memory round trips instead of 28.
+//
+// With a resident SAD surface of the picture pair (sad_surface.hip) the integer candidates are not computed at
+// all: SAD(PU, integer MV) is element [ctu][blk][dy][dx] of the surface, because the surface's windows are
+// relative to each block's own position exactly like the MVs of a search. A request takes that path when its PU
+// sits on the CTU quad-tree and the stage's candidates are inside [-R, R]^2; otherwise the stage is computed.
 #include "xmi_common.h"
 
 #include <type_traits>
@@ -26,6 +31,10 @@ struct MeParams {
     const xmi_me_request *req;
     xmi_me_result *res;
     int cur_stride, stride, rows, pad, n, me_range;
+    // resident SAD surface of the same picture pair (SURF kernels only)
+    const uint16_t *sad8, *sad16;
+    const u32 *sad32, *sad64;
+    int surf_range, surf_wc, surf_nctu;
 };
 
 __device__ __forceinline__ u32 mv_bits(int v)
@@ -52,7 +61,7 @@ __device__ __forceinline__ u32 wave_sum(u32 x)
 // One search. The reference evaluates its candidates one after the other, but inside each stage they do not
 // depend on each other (only the comparisons do), so a stage's SADs are computed together - all loads of a
 // stage are in flight at once - and the comparisons are then applied in the reference's order.
-template <int N>
+template <int N, bool SURF>
 __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int lane)
 {
     constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
@@ -99,14 +108,31 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     auto qpel = [&](int mx, int my) { return ref0 + ((my & 3) * 4 + (mx & 3)) * plane_bytes + (ptrdiff_t)(my >> 2) * p.stride + (mx >> 2); };
     auto ipel = [&](int x, int y) { return ref0 + (ptrdiff_t)y * p.stride + x; };
     const u32 lam = rq.sqrt_lambda;
+    // surface coordinates of this PU (wave-uniform)
+    constexpr int LEVEL = N == 8 ? 0 : N == 16 ? 1 : N == 32 ? 2 : 3;
+    const int R = p.surf_range;
+    const bool on_tree = SURF && (rq.x0 & (N - 1)) == 0 && (rq.y0 & (N - 1)) == 0;
+    const int s_ctu = (rq.y0 >> 6) * p.surf_wc + (rq.x0 >> 6), s_blk = ((rq.y0 & 63) / N) * (64 / N) + (rq.x0 & 63) / N;
+    auto in_window = [&](int x, int y) { return x >= -R && x <= R && y >= -R && y <= R; };
+    auto surf = [&](int x, int y) -> u32 {
+        const size_t e = xmi::surface_index(R, (size_t)p.surf_nctu, LEVEL, s_ctu, s_blk, y, x);
+        return LEVEL == 0 ? (u32)p.sad8[e] : LEVEL == 1 ? (u32)p.sad16[e] : LEVEL == 2 ? p.sad32[e] : p.sad64[e];
+    };
 
     // ---- predictor choice, (0,0) and the integer start point ----
     const int passes = ((abs(rq.mvp[0][0] - rq.mvp[1][0]) >> 2) + (abs(rq.mvp[0][1] - rq.mvp[1][1]) >> 2) > 4) ? 2 : 1;
     u32 s5[5];
     {
-        const uint8_t *c[5] = { qpel(rq.mvp[0][0], rq.mvp[0][1]), qpel(rq.mvp[1][0], rq.mvp[1][1]), ipel(0, 0),
-                                ipel(rq.mvp[0][0] >> 2, rq.mvp[0][1] >> 2), ipel(rq.mvp[1][0] >> 2, rq.mvp[1][1] >> 2) };
-        eval(std::integral_constant<int, 5>{}, c, s5);
+        const int ax = rq.mvp[0][0] >> 2, ay = rq.mvp[0][1] >> 2, bx = rq.mvp[1][0] >> 2, by = rq.mvp[1][1] >> 2;
+        const uint8_t *c[5] = { qpel(rq.mvp[0][0], rq.mvp[0][1]), qpel(rq.mvp[1][0], rq.mvp[1][1]), ipel(0, 0), ipel(ax, ay), ipel(bx, by) };
+        if (on_tree && in_window(ax, ay) && in_window(bx, by)) {
+            eval(std::integral_constant<int, 2>{}, c, s5);
+            s5[2] = surf(0, 0);
+            s5[3] = surf(ax, ay);
+            s5[4] = surf(bx, by);
+        } else {
+            eval(std::integral_constant<int, 5>{}, c, s5);
+        }
     }
     int n_int = 0, n_sub = passes;
     const int mvp_idx = (passes == 2 && s5[1] < s5[0]) ? 1 : 0;
@@ -145,7 +171,12 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
             ty[k] = clip3(rq.mv_min_ipel[1], rq.mv_max_ipel[1], omy + dia4y[k]);
             c[k] = ipel(tx[k], ty[k]);
         }
-        eval(std::integral_constant<int, 4>{}, c, s4);
+        if (on_tree && in_window(tx[0], ty[0]) && in_window(tx[1], ty[1]) && in_window(tx[2], ty[2]) && in_window(tx[3], ty[3])) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) s4[k] = surf(tx[k], ty[k]);
+        } else {
+            eval(std::integral_constant<int, 4>{}, c, s4);
+        }
         bool changed = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -213,6 +244,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     }
 }
 
+template <bool SURF>
 __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
 {
     const int lane = threadIdx.x & 63;
@@ -220,11 +252,21 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     if (idx >= p.n) return;
     const xmi_me_request rq = p.req[idx];
     switch (rq.size) {
-    case 8: search<8>(p, rq, idx, lane); break;
-    case 16: search<16>(p, rq, idx, lane); break;
-    case 32: search<32>(p, rq, idx, lane); break;
-    default: search<64>(p, rq, idx, lane); break;
+    case 8: search<8, SURF>(p, rq, idx, lane); break;
+    case 16: search<16, SURF>(p, rq, idx, lane); break;
+    case 32: search<32, SURF>(p, rq, idx, lane); break;
+    default: search<64, SURF>(p, rq, idx, lane); break;
     }
+}
+
+int check_common(const char *who, const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int pad,
+                 const xmi_me_request *d_req, int me_range, xmi_me_result *d_res)
+{
+    XMI_ARG(d_cur && d_planes && d_req && d_res, "%s: null argument", who);
+    XMI_ARG(cur_stride % 4 == 0 && ((uintptr_t)d_cur & 3) == 0, "%s: current frame must be 4-byte aligned", who);
+    XMI_ARG(stride % 4 == 0 && ((uintptr_t)d_planes & 3) == 0 && pad % 4 == 0, "%s: planes, stride and pad must be multiples of 4", who);
+    XMI_ARG(me_range >= 0 && me_range <= 1024, "%s: me_range %d out of range", who, me_range);
+    return XMI_OK;
 }
 
 }  // namespace
@@ -237,12 +279,33 @@ extern "C" int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, con
     if (rc != XMI_OK) return rc;
     XMI_ARG(n >= 0, "xmi_me_search_batch_dev: negative request count");
     if (n == 0) return XMI_OK;
-    XMI_ARG(d_cur && d_planes && d_req && d_res, "xmi_me_search_batch_dev: null argument");
-    XMI_ARG(cur_stride % 4 == 0 && ((uintptr_t)d_cur & 3) == 0, "xmi_me_search_batch_dev: current frame must be 4-byte aligned");
-    XMI_ARG(stride % 4 == 0 && ((uintptr_t)d_planes & 3) == 0 && pad % 4 == 0, "xmi_me_search_batch_dev: planes, stride and pad must be multiples of 4");
-    XMI_ARG(me_range >= 0 && me_range <= 1024, "xmi_me_search_batch_dev: me_range %d out of range", me_range);
-    MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range };
-    hipLaunchKernelGGL(me_search_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, pad, d_req, me_range, d_res);
+    if (rc != XMI_OK) return rc;
+    MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+    hipLaunchKernelGGL(me_search_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+extern "C" int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows,
+                                               int pad, const xmi_sad_geom *g, const uint16_t *d_sad8, const uint16_t *d_sad16,
+                                               const uint32_t *d_sad32, const uint32_t *d_sad64, const xmi_me_request *d_req, int n,
+                                               int me_range, xmi_me_result *d_res, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_me_search_surface_batch_dev: negative request count");
+    if (n == 0) return XMI_OK;
+    rc = check_common("xmi_me_search_surface_batch_dev", d_cur, cur_stride, d_planes, stride, pad, d_req, me_range, d_res);
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(g && d_sad8 && d_sad16 && d_sad32 && d_sad64, "xmi_me_search_surface_batch_dev: null surface");
+    XMI_ARG(g->width > 0 && g->height > 0 && g->width % 64 == 0 && g->height % 64 == 0 &&
+                (g->range == 16 || g->range == 32 || g->range == 64 || g->range == 128),
+            "xmi_me_search_surface_batch_dev: surface geometry %dx%d range %d is not one xmi_sad_surface_dev produces", g->width,
+            g->height, g->range);
+    MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, d_sad8, d_sad16, d_sad32, d_sad64,
+                   g->range, g->width / 64, (g->width / 64) * (g->height / 64) };
+    hipLaunchKernelGGL(me_search_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }

@@ -50,8 +50,8 @@ struct SadParams {
 constexpr int kCurLdsBytes = 16 * 16 * 16;  // [row in 16x16 block][z][16 bytes]
 
 // blocks per level, and elements per (ctu, dy) row of the main part of each level's plane
-__host__ __device__ constexpr int level_blocks(int level) { return level == 0 ? 64 : level == 1 ? 16 : level == 2 ? 4 : 1; }
-__host__ __device__ constexpr int row_elems(int R, int level) { return (R / 8) * level_blocks(level) * 16; }
+constexpr int level_blocks(int level) { return xmi::surface_level_blocks(level); }
+constexpr int row_elems(int R, int level) { return xmi::surface_row_elems(R, level); }
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
@@ -350,24 +350,8 @@ int xmi_debug_timeline(unsigned long long *out, int n)
 
 size_t xmi_sad_surface_index(const xmi_sad_geom *g, int level, int ctu, int blk, int dy, int dx)
 {
-    const int R = g->range;
-    const int dxi = dx + R, dyi = dy + R;
-    int slot;  // position of the block inside a tile
-    if (level == 0) {
-        const int by = blk >> 3, bx = blk & 7, by16 = by >> 1, bx16 = bx >> 1;
-        const int z = (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
-        slot = ((by & 1) * 2 + (bx & 1)) * 16 + z;
-    } else if (level == 1) {
-        const int by16 = blk >> 2, bx16 = blk & 3;
-        slot = (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
-    } else {
-        slot = level == 2 ? blk : 0;
-    }
-    const size_t nmv = (size_t)(2 * R + 1), nb = (size_t)level_blocks(level);
     const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
-    const size_t row = (size_t)ctu * nmv + (size_t)dyi;
-    if (dxi == 2 * R) return nctu * nmv * (size_t)row_elems(R, level) + row * nb + (size_t)slot;
-    return row * (size_t)row_elems(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
+    return xmi::surface_index(g->range, nctu, level, ctu, blk, dy, dx);
 }
 
 int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8_t *d_ref_origin,

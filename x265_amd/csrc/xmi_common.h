@@ -34,6 +34,35 @@ void *scratch(int slot, size_t bytes);
         }                                   \
     } while (0)
 
+// ---- layout of the SAD surface planes (sad_surface.hip writes it, me_search.hip reads it) ----
+// level 0..3 = 8x8 / 16x16 / 32x32 / 64x64 blocks of a CTU; blk = raster index of the block at that level.
+// Main part, dx in [-R, R-1]: [ctu][dy][dx / 16][slot][dx % 16]; edge part, dx = +R: after the main part, [ctu][dy][slot].
+__host__ __device__ constexpr int surface_level_blocks(int level) { return level == 0 ? 64 : level == 1 ? 16 : level == 2 ? 4 : 1; }
+__host__ __device__ constexpr int surface_row_elems(int R, int level) { return (R / 8) * surface_level_blocks(level) * 16; }
+
+__host__ __device__ inline int surface_slot(int level, int blk)
+{
+    if (level == 0) {
+        const int by = blk >> 3, bx = blk & 7, by16 = by >> 1, bx16 = bx >> 1;
+        const int z = (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
+        return ((by & 1) * 2 + (bx & 1)) * 16 + z;
+    }
+    if (level == 1) {
+        const int by16 = blk >> 2, bx16 = blk & 3;
+        return (((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1));
+    }
+    return level == 2 ? blk : 0;
+}
+
+__host__ __device__ inline size_t surface_index(int R, size_t nctu, int level, int ctu, int blk, int dy, int dx)
+{
+    const int dxi = dx + R, dyi = dy + R, slot = surface_slot(level, blk);
+    const size_t nmv = (size_t)(2 * R + 1), nb = (size_t)surface_level_blocks(level);
+    const size_t row = (size_t)ctu * nmv + (size_t)dyi;
+    if (dxi == 2 * R) return nctu * nmv * (size_t)surface_row_elems(R, level) + row * nb + (size_t)slot;
+    return row * (size_t)surface_row_elems(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
+}
+
 }  // namespace xmi
 
 #ifdef __HIPCC__
