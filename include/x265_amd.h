@@ -151,6 +151,30 @@ typedef struct xmi_intra_result {
 int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
 
+/* ---- prediction blocks -------------------------------------------------------------------------------
+ * Inter: what xPredInterLumaBlk (src/pixel.cpp:8745-8795, 8-tap, quarter-pel) and xPredInterChromaBlk
+ * (src/pixel.cpp:9657-9703, 4-tap, the same MV numbers read as eighth-pel) write for one PU, for a batch of PUs
+ * straight from the padded reconstruction on the device (d_ref_* = pixel (0,0) of each plane). Blocks are written
+ * packed (rows `size` resp. `size`/2 bytes apart) at the byte offsets the request names, ready to be the `pred`
+ * input of xmi_tu_chain_batch_dev. A null d_pred_y skips luma, null d_pred_u / d_pred_v skip that chroma plane. */
+typedef struct xmi_inter_pred_request {
+    int32_t x0, y0, size;         /* luma PU origin and size (8/16/32/64); chroma blocks are size/2 at (x0/2, y0/2) */
+    int16_t mv[2];                /* quarter-pel luma MV */
+    uint32_t out_y, out_c;        /* byte offsets of the luma block in d_pred_y and of the chroma blocks in d_pred_u / d_pred_v */
+} xmi_inter_pred_request;
+int xmi_pred_inter_batch_dev(const uint8_t *d_ref_y, int stride_y, const uint8_t *d_ref_u, const uint8_t *d_ref_v, int stride_c,
+                             const xmi_inter_pred_request *d_req, int n, uint8_t *d_pred_y, uint8_t *d_pred_u, uint8_t *d_pred_v,
+                             void *stream);
+/* Intra: xEncIntraPred (src/pixel.cpp:7338) for a batch: request i predicts a size x size block in `mode` (0 planar,
+ * 1 DC, 2..34 angular; is_luma switches the DC / horizontal / vertical edge filters) from its 4*size+1 neighbouring
+ * samples at d_ref_samples + i * XMI_INTRA_REF_PITCH (bottom-left first, as the reference's aucRef rows; already padded
+ * and, where the caller wants the smoothed set, filtered) and writes it packed at d_pred + out. */
+typedef struct xmi_intra_pred_request {
+    uint8_t size, mode, is_luma, reserved;
+    uint32_t out;
+} xmi_intra_pred_request;
+int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream);
+
 /* ---- frame session: host-pointer batch interface --------------------------------------------------
  * For a host CTU loop without device pointers of its own. The session holds one picture pair on the device (source
  * luma, padded previous reconstruction, its 16 quarter-pel planes) and stages request / result tables.
@@ -229,6 +253,13 @@ int xmi_dequant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, 
 /* xIDctAdd, src/pixel.cpp:5938 (pred is read with `stride`, like the reference) */
 int xmi_idct_add(uint8_t *dst, uint32_t stride_dst, const int16_t *src, uint32_t stride, const uint8_t *pred,
                  int width, uint32_t mode);
+/* xPredInterLumaBlk (src/pixel.cpp:8745) / xPredInterChromaBlk (:9657) / xEncIntraPred (:7338) with host pointers and
+ * the reference's argument meaning: ref points at the block's integer origin inside the caller's padded plane, pred rows
+ * are MAX_CU_SIZE = 64 (luma) or 32 (chroma) bytes apart, the psTmp argument is not needed. Square blocks only (the
+ * reference never asks for others): luma 8..64, chroma 4..32. Only the samples the reference's filters read are touched. */
+int xmi_pred_inter_luma(const uint8_t *ref, uint8_t *pred, uint32_t ref_stride, uint32_t size_x, uint32_t size_y, int mvx, int mvy);
+int xmi_pred_inter_chroma(const uint8_t *ref, uint8_t *pred, uint32_t ref_stride, uint32_t size_x, uint32_t size_y, int mvx, int mvy);
+int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t stride, uint32_t mode, uint32_t size, uint32_t is_luma);
 /* xSubDctQuantRec, src/encode.cpp:3005 */
 int64_t xmi_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef, int size,
                      int stride, int stride_rec, uint32_t qp, uint32_t mode, int slice_type);

@@ -11,6 +11,7 @@ Functions called (mangled C++ names; signatures from inc/x265.h:650-670 and src/
   xCalcHADs4x4/8x8/16x16/32x32/64x64, xCalcHADs32x32_test   src/pixel.cpp:63-527
   xSubDct / xQuant / xDeQuant / xIDctAdd                      src/pixel.cpp:3446, 1054, 1244, 5938
   xPredInterLumaBlk                                           src/pixel.cpp:8745
+  xPredInterChromaBlk                                         src/pixel.cpp:9657
   xMotionSearch (from oracle/_ref/libx265ref_me.so, `make -C oracle ref_me`)   src/encode.cpp:2815
 """
 import ctypes as C
@@ -414,5 +415,85 @@ def gen_intra():
     np.savez_compressed(os.path.join(OUT, "intra.npz"), **out)
 
 
+def gen_chroma():
+    """Chroma prediction known answers: the reference's compiled xPredInterChromaBlk (src/pixel.cpp:9657, SSE4 paths)
+    for block sizes 4..32, all 64 eighth-pel phases, on random and on 0/255 checkerboard-noise frames."""
+    lib = C.CDLL(LIB)
+
+    class XMV(C.Structure):
+        _fields_ = [("x", C.c_int16), ("y", C.c_int16)]
+
+    f = lib._Z19xPredInterChromaBlkPKhPhjjj3xMVPs
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, XMV, C.c_void_p]
+    rng = np.random.default_rng(20240611)
+    RS = 80
+    refbuf = aligned((64, RS), np.uint8)
+    dst = aligned((32, 32), np.uint8)
+    tmp = aligned(((64 + 16) * 64,), np.int16)
+    out = {}
+    for n in (4, 8, 16, 32):
+        frames = rng.integers(0, 256, (2, 64, RS), dtype=np.uint8)
+        frames[1] = np.where(rng.random((64, RS)) < 0.5, 0, 255).astype(np.uint8)
+        res = np.zeros((2, 64, n, n), np.uint8)
+        mvs = np.zeros((64, 2), np.int16)
+        for fi in range(2):
+            refbuf[:] = frames[fi]
+            for ph in range(64):
+                mv = XMV(int(8 * (ph % 3 - 1) + (ph & 7)), int(8 * ((ph // 7) % 3 - 1) + (ph >> 3)))
+                mvs[ph] = (mv.x, mv.y)
+                dst[:] = 0
+                origin = C.c_void_p(refbuf.ctypes.data + 12 * RS + 12)
+                f(origin, ptr(dst), RS, n, n, mv, ptr(tmp))
+                res[fi, ph] = dst[:n, :n]
+        out[f"ref{n}"], out[f"mv{n}"], out[f"pred{n}"] = frames, mvs, res
+    out["origin"] = np.array([12, 12], np.int32)
+    np.savez_compressed(os.path.join(OUT, "interp_chroma.npz"), **out)
+    print("wrote interp_chroma.npz")
+
+
+def gen_intra_chroma():
+    """xEncIntraPred (src/pixel.cpp:7338) called the way the chroma path calls it (bIsLuma = 0: no DC / horizontal /
+    vertical edge filters) for sizes 4..32 and all 35 modes, next to the bIsLuma = 1 output for sizes 4..16."""
+    lib = C.CDLL(LIB)
+    fprd = lib._Z13xEncIntraPredPhS_jjjj
+    fprd.restype = None
+    fprd.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    rng = np.random.default_rng(4242)
+    out = {}
+    ref = aligned((4 * 64 + 1 + 64,), np.uint8)
+    dst = aligned((32 * 32 + 64,), np.uint8)
+    for n in (4, 8, 16, 32):
+        L = 4 * n + 1
+        ncase = 6
+        refs = np.zeros((ncase, L), np.uint8)
+        preds = np.zeros((ncase, 2, 35, n, n), np.uint8)
+        for ci in range(ncase):
+            if ci % 3 == 0:
+                r = rng.integers(0, 256, L)
+            elif ci % 3 == 1:
+                r = np.where(rng.random(L) < 0.5, 0, 255)
+            else:
+                r = np.clip(128 + 100 * np.sin(np.arange(L) / (2.0 + ci)) + rng.integers(-4, 5, L), 0, 255)
+            refs[ci] = r.astype(np.uint8)
+            ref[:L] = refs[ci]
+            for luma in (0, 1):
+                if luma and n == 32:
+                    continue          # the encoder never asks for it (src/encode.cpp:4038 passes nSize != 32)
+                for mode in range(35):
+                    dst[:] = 0
+                    fprd(ptr(dst), ptr(ref), n, mode, n, luma)
+                    preds[ci, luma, mode] = dst[:n * n].reshape(n, n)
+        out[f"n{n}_ref"], out[f"n{n}_pred"] = refs, preds
+    np.savez_compressed(os.path.join(OUT, "intra_pred_flags.npz"), **out)
+    print("wrote intra_pred_flags.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "chroma":
+        gen_chroma()
+        gen_intra_chroma()
+    else:
+        main()
+        gen_chroma()
+        gen_intra_chroma()

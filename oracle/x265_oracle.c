@@ -358,6 +358,53 @@ void orc_pred_inter_luma(const uint8_t *ref, uint8_t *dst, int rs, int w, int h,
     }
 }
 
+static const int k_chroma_filter[8][4] = { /* xg_chromaFilter, src/table.cpp:532-541 */
+    { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+    { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 }
+};
+
+void orc_pred_inter_chroma(const uint8_t *ref, uint8_t *dst, int rs, int w, int h, int mvx, int mvy)
+{
+    const int dx = mvx >> 3, dy = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
+    ref += (ptrdiff_t)dy * rs + dx;
+    if (!xf && !yf) {
+        for (int i = 0; i < h; i++)
+            memcpy(dst + i * 32, ref + (ptrdiff_t)i * rs, (size_t)w);
+    } else if (!yf) { /* src/pixel.cpp:8982-9007 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 4; t++)
+                    s += ref[(ptrdiff_t)i * rs + j + t - 1] * k_chroma_filter[xf][t];
+                dst[i * 32 + j] = (uint8_t)clip3(0, 255, (s + 32) >> 6);
+            }
+    } else if (!xf) { /* src/pixel.cpp:9257-9282 */
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 4; t++)
+                    s += ref[(ptrdiff_t)(i + t - 1) * rs + j] * k_chroma_filter[yf][t];
+                dst[i * 32 + j] = (uint8_t)clip3(0, 255, (s + 32) >> 6);
+            }
+    } else { /* src/pixel.cpp:9611-9654 */
+        int16_t tmp[(32 + 3) * 32];
+        for (int i = 0; i < h + 3; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 4; t++)
+                    s += ref[(ptrdiff_t)(i - 1) * rs + j + t - 1] * k_chroma_filter[xf][t];
+                tmp[i * 32 + j] = (int16_t)(s - 8192);
+            }
+        for (int i = 0; i < h; i++)
+            for (int j = 0; j < w; j++) {
+                int s = 0;
+                for (int t = 0; t < 4; t++)
+                    s += tmp[(i + t) * 32 + j] * k_chroma_filter[yf][t];
+                dst[i * 32 + j] = (uint8_t)clip3(0, 255, (s + 8192 * 64 + 2048) >> 12);
+            }
+    }
+}
+
 void orc_motion_search(const uint8_t *cur, const uint8_t *ref, int rs, int size,
                        const orc_mv mvp[2], int zero_mv_tested, orc_mv mv_min_ipel, orc_mv mv_max_ipel,
                        double lambda, int me_range, orc_me_result *out)

@@ -99,6 +99,12 @@ unsigned orc_mv_component_bits(int val);
  * at quarter-pel MV (mvx,mvy) from ref (pointer at the block's integer origin). dst stride 64. */
 void orc_pred_inter_luma(const uint8_t *ref, uint8_t *dst, int ref_stride, int w, int h, int mvx, int mvy);
 
+/* xPredInterChromaBlk, src/pixel.cpp:9657-9703: 4-tap chroma prediction of one block; (mvx, mvy) are the luma
+ * quarter-pel MV numbers read as eighth-pel chroma units (src/encode.cpp:3721-3723). dst rows are 32 bytes apart
+ * (MAX_CU_SIZE/2). H and V: (sum + 32) >> 6; HV: first stage sum - 8192 in 16 bits, second stage
+ * (sum + 8192*64 + 2048) >> 12 (C spec :8982, :9257, :9611; filters src/table.cpp:532-541). */
+void orc_pred_inter_chroma(const uint8_t *ref, uint8_t *dst, int ref_stride, int w, int h, int mvx, int mvy);
+
 /* A2: xMotionSearch, src/encode.cpp:2815-3003 (MV_CLIP=1, MVD_COST_BY_TABLE=0, SATD_FOR_FRAC_ME=0).
  * cur: stride 64. ref: pointer at the PU origin in the padded reference. mvp[2]: quarter-pel
  * predictors {x,y}. Outputs mirror the reference's out-parameters. Returns packed mv: x | y<<16. */

@@ -57,6 +57,8 @@ def load():
     lib.orc_mv_component_bits.argtypes = [i]
     lib.orc_pred_inter_luma.restype = None
     lib.orc_pred_inter_luma.argtypes = [vp, vp, i, i, i, i, i]
+    lib.orc_pred_inter_chroma.restype = None
+    lib.orc_pred_inter_chroma.argtypes = [vp, vp, i, i, i, i, i]
     lib.orc_motion_search.restype = None
     lib.orc_motion_search.argtypes = [vp, vp, i, i, C.POINTER(OrcMV), i, OrcMV, OrcMV, C.c_double, i,
                                       C.POINTER(OrcMEResult)]

@@ -45,7 +45,8 @@ def test_library_loads_and_reports_without_gpu():
 def test_dropin_exports_the_reference_primitive_interface():
     # mangled names are the ones an object compiled from the reference's encode.cpp imports
     want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "xSatd_AMP", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType",
-            "_Z8xDeQuantPsS_jjii", "_Z8xIDctAddPhjPsjS_S0_S0_ij", "xmi_install_primitives"}
+            "_Z8xDeQuantPsS_jjii", "_Z8xIDctAddPhjPsjS_S0_S0_ij", "xmi_install_primitives",
+            "_Z17xPredInterLumaBlkPKhPhjjj3xMVPs", "_Z19xPredInterChromaBlkPKhPhjjj3xMVPs", "_Z13xEncIntraPredPhS_jjjj"}
     assert want <= exported(DROPIN)
 
 
@@ -65,3 +66,25 @@ def test_no_cpu_fallback_when_no_gpu():
     lib.xmi_sad.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     assert lib.xmi_sad(8, a.ctypes.data, 8, a.ctypes.data, 8) == -3
     assert b"no CPU fallback" in lib.xmi_last_error()
+
+
+GPU_ALL = os.path.join(ROOT, "oracle", "_ref", "x265_gpu_all")
+
+
+@pytest.mark.skipif(not (os.path.exists(GPU_ALL) and os.path.exists(DROPIN)), reason="all-GPU encoder not built (make -C oracle trace)")
+def test_reference_library_binds_to_the_dropin():
+    """In the all-GPU encoder the reference's own shared library must take every pixel primitive and prediction
+    function from libx265_amd_dropin.so (symbol interposition by link order): read the dynamic linker's binding log."""
+    env = dict(os.environ, LD_BIND_NOW="1", LD_DEBUG="bindings")
+    log = subprocess.run([GPU_ALL], env=env, capture_output=True, text=True, timeout=60).stderr
+    want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType", "_Z8xDeQuantPsS_jjii",
+            "_Z8xIDctAddPhjPsjS_S0_S0_ij", "_Z17xPredInterLumaBlkPKhPhjjj3xMVPs", "_Z19xPredInterChromaBlkPKhPhjjj3xMVPs",
+            "_Z13xEncIntraPredPhS_jjjj"}
+    bound = {}
+    for line in log.splitlines():
+        m = re.search(r"binding file \S*libx265ref_me\.so \[0\] to (\S+) \[0\]: normal symbol `([^']+)'", line)
+        if m and m.group(2) in want:
+            bound[m.group(2)] = os.path.basename(m.group(1))
+    assert set(bound) == want, f"no binding seen for {sorted(want - set(bound))}"
+    wrong = {k: v for k, v in bound.items() if v != "libx265_amd_dropin.so"}
+    assert not wrong, f"bound to the reference's own definitions: {wrong}"

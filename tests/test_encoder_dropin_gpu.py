@@ -71,7 +71,7 @@ def test_bitstream_identical_with_gpu_interpolation_planes(tmp_path, qp, frames)
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_all")), reason="all-GPU encoder not built (make -C oracle trace)")
 def test_bitstream_identical_with_every_gpu_service(tmp_path):
     """Motion search from the frame session AND every pixel primitive (SAD / SATD / SSD tables, xSubDct, xQuant,
-    xDeQuant, xIDctAdd) from libx265_amd_dropin.so, which sits ahead of the reference's library in the link order and
+    xDeQuant, xIDctAdd, xPredInterLumaBlk, xPredInterChromaBlk, xEncIntraPred) from libx265_amd_dropin.so, which sits ahead of the reference's library in the link order and
     so replaces its definitions: the reference's control flow with no CPU pixel arithmetic left in the luma/transform path."""
     w, h, frames, qp = 416, 240, 8, 32
     yuv = str(tmp_path / "in.yuv")

@@ -110,6 +110,21 @@ def test_luma_interpolation(lib, golden_dir, n):
             np.testing.assert_array_equal(dst[:n, :n], want[fi, k])
 
 
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_chroma_interpolation(lib, golden_dir, n):
+    """orc_pred_inter_chroma against the reference's compiled xPredInterChromaBlk: all 64 eighth-pel phases."""
+    g = np.load(os.path.join(golden_dir, "interp_chroma.npz"))
+    oy, ox = g["origin"]
+    frames, mvs, want = g[f"ref{n}"], g[f"mv{n}"], g[f"pred{n}"]
+    assert len({(int(a) & 7, int(b) & 7) for a, b in mvs}) == 64
+    for fi in range(frames.shape[0]):
+        ref = np.ascontiguousarray(frames[fi])
+        for k in range(len(mvs)):
+            dst = np.zeros((32, 32), np.uint8)
+            lib.orc_pred_inter_chroma(O.at(ref, oy, ox), O.p(dst), ref.strides[0], n, n, int(mvs[k, 0]), int(mvs[k, 1]))
+            np.testing.assert_array_equal(dst[:n, :n], want[fi, k])
+
+
 def test_satd_x264_properties(lib):
     """No compiled reference exists for the NASM SATD (parity unpinned): check its definition only."""
     rng = np.random.default_rng(5)
@@ -189,6 +204,22 @@ def test_intra_prediction_matches_reference(lib, golden_dir, n):
             assert out.best_cost == float(g[t + "cost"][ci])
         else:
             assert 0 <= out.best_mode < 35 and 0 <= out.pred_idx < 35
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_prediction_both_edge_filter_settings(lib, golden_dir, n):
+    """orc_intra_pred with bIsLuma = 0 (the chroma call) and 1 against the reference's compiled xEncIntraPred."""
+    g = np.load(os.path.join(golden_dir, "intra_pred_flags.npz"))
+    refs, want = g[f"n{n}_ref"], g[f"n{n}_pred"]
+    for ci in range(len(refs)):
+        rf = np.ascontiguousarray(refs[ci])
+        for luma in (0, 1):
+            if luma and n == 32:
+                continue
+            for mode in range(35):
+                dst = np.zeros((n, n), np.uint8)
+                lib.orc_intra_pred(O.p(dst), O.p(rf), n, mode, n, luma)
+                np.testing.assert_array_equal(dst, want[ci, luma, mode], err_msg=f"case {ci} luma {luma} mode {mode}")
 
 
 def test_motion_search_replays_encoder_trace(lib, golden_dir):

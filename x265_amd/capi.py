@@ -42,6 +42,15 @@ class IntraResult(C.Structure):
                 ("satd", C.c_uint32 * 35), ("reserved", C.c_uint32)]
 
 
+class InterPredRequest(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_int32), ("mv", C.c_int16 * 2),
+                ("out_y", C.c_uint32), ("out_c", C.c_uint32)]
+
+
+class IntraPredRequest(C.Structure):
+    _fields_ = [("size", C.c_uint8), ("mode", C.c_uint8), ("is_luma", C.c_uint8), ("reserved", C.c_uint8), ("out", C.c_uint32)]
+
+
 INTRA_REF_PITCH = 132
 _lib = None
 
@@ -93,6 +102,17 @@ def load():
     if hasattr(L, "xmi_intra_search_batch_dev"):
         L.xmi_intra_search_batch_dev.restype = i
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
+    if hasattr(L, "xmi_pred_inter_batch_dev"):
+        L.xmi_pred_inter_batch_dev.restype = i
+        L.xmi_pred_inter_batch_dev.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp]
+        L.xmi_intra_pred_batch_dev.restype = i
+        L.xmi_intra_pred_batch_dev.argtypes = [vp, vp, i, vp, vp]
+        L.xmi_pred_inter_luma.restype = i
+        L.xmi_pred_inter_luma.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, i, i]
+        L.xmi_pred_inter_chroma.restype = i
+        L.xmi_pred_inter_chroma.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, i, i]
+        L.xmi_enc_intra_pred.restype = i
+        L.xmi_enc_intra_pred.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
     if hasattr(L, "xmi_me_search_batch_dev"):
         L.xmi_me_search_batch_dev.restype = i
         L.xmi_me_search_batch_dev.argtypes = [vp, i, vp, i, i, i, vp, i, i, vp, vp]

@@ -2,8 +2,10 @@
 // signatures) implemented on libx265_amd.so.
 //
 // The reference has no registration API: its "plugin table" is a set of writable global arrays of
-// function pointers plus four free functions (inc/x265.h:650-670, defined in src/pixel.cpp:529-542,
-// 711-717, 810-816, 833-857, 1054, 1244, 3446, 5938). This file defines exactly those symbols, so that
+// function pointers plus free functions: xSubDct, xQuant, xDeQuant, xIDctAdd (inc/x265.h:650-670, defined in
+// src/pixel.cpp:529-542, 711-717, 810-816, 833-857, 1054, 1244, 3446, 5938) and the prediction functions
+// xPredInterLumaBlk, xPredInterChromaBlk, xEncIntraPred (declared in src/encode.cpp:38, 60-79, defined in
+// src/pixel.cpp:8745, 9657, 7338). This file defines exactly those symbols, so that
 //   (a) an encoder build that links this object INSTEAD of its own definitions uses the GPU, or
 //   (b) an unmodified encoder calls xmi_install_primitives() once to overwrite the entries of its own
 //       tables (they are non-const globals) and wraps the four free functions at link time.
@@ -100,6 +102,24 @@ UInt32 xQuant(Int16 *pDst, Int16 *pSrc, UInt nStride, UInt nQP, Int iWidth, Int 
 void xDeQuant(Int16 *pDst, Int16 *pSrc, UInt nStride, UInt nQP, Int iWidth, Int iHeight)
 {
     must(xmi_dequant(pDst, pSrc, nStride, nQP, iWidth, iHeight), "xDeQuant");
+}
+
+// ---- the prediction functions (src/encode.cpp:38, 60-79) ----
+struct xMV { Int16 x, y; };   // inc/x265.h:156-159
+
+void xPredInterLumaBlk(CUInt8 *pucRef, UInt8 *pucPred, CUInt32 nRefStride, CUInt nSizeX, CUInt nSizeY, xMV bmv, Int16 *)
+{
+    must(xmi_pred_inter_luma(pucRef, pucPred, nRefStride, nSizeX, nSizeY, bmv.x, bmv.y), "xPredInterLumaBlk");
+}
+
+void xPredInterChromaBlk(CUInt8 *pucRefC, UInt8 *pucPredC, CUInt32 nRefStrideC, CUInt nSizeCX, CUInt nSizeCY, xMV bmv, Int16 *)
+{
+    must(xmi_pred_inter_chroma(pucRefC, pucPredC, nRefStrideC, nSizeCX, nSizeCY, bmv.x, bmv.y), "xPredInterChromaBlk");
+}
+
+void xEncIntraPred(UInt8 *pucDstY, UInt8 *pucRefY, UInt nStride, UInt nMode, UInt nSize, UInt bIsLuma)
+{
+    must(xmi_enc_intra_pred(pucDstY, pucRefY, nStride, nMode, nSize, bIsLuma), "xEncIntraPred");
 }
 
 // ---- hook for an unmodified encoder: overwrite the entries of ITS tables (passed by address) ----

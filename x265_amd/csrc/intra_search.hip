@@ -8,7 +8,14 @@
 // by pixel for that tile straight from the LDS samples, and runs the Hadamard transform of the residual in
 // registers. 64 / tiles-per-block modes are evaluated at once; tile sums meet through a segmented DPP reduction.
 // Cost = satd + {1,2,3} * sqrt_lambda in double, strict < in mode order, as the reference's loop does.
+//
+// xmi_intra_pred_batch_dev / xmi_enc_intra_pred write the prediction block itself (xEncIntraPred, one mode) with the
+// same per-sample code: one wavefront per request.
 #include "xmi_common.h"
+
+#include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -244,7 +251,91 @@ __global__ void __launch_bounds__(256) intra_search_kernel(const IntraParams p)
     search<N, WPR>(p, rq, idx, s_ref[wave], s_src[wave], lane, WPR == 4 ? wave : 0, s_best_cost, s_best_mode);
 }
 
+// ---- prediction blocks: one wavefront per request ----
+struct IntraPredParams {
+    const uint8_t *refs;
+    const xmi_intra_pred_request *req;
+    uint8_t *pred;
+    int n;
+};
+
+template <int N>
+__device__ __forceinline__ void predict(const uint8_t *s_ref, uint8_t *dst, int mode, bool is_luma, int lane)
+{
+    constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    int dc;
+    {
+        int s = 0;
+        for (int i = lane; i < 2 * N; i += 64) s += i < N ? s_ref[2 * N - 1 - i] : s_ref[2 * N + 1 + (i - N)];
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) s += __shfl_xor(s, k);
+        dc = (s + N) >> (LG + 1);
+    }
+    for (int e = lane; e < N * N; e += 64) dst[e] = (uint8_t)pred_sample<N>(s_ref, mode, e / N, e % N, dc, is_luma);
+}
+
+__global__ void __launch_bounds__(256) intra_pred_kernel(const IntraPredParams p)
+{
+    __shared__ __align__(16) uint8_t s_ref[4][136];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = (int)blockIdx.x * 4 + wave;
+    if (idx >= p.n) return;
+    const xmi_intra_pred_request rq = p.req[idx];
+    const uint8_t *raw = p.refs + (size_t)idx * XMI_INTRA_REF_PITCH;
+    for (int i = lane; i < 4 * rq.size + 1; i += 64) s_ref[wave][i] = raw[i];
+    __builtin_amdgcn_wave_barrier();
+    uint8_t *dst = p.pred + rq.out;
+    const bool is_luma = rq.is_luma != 0;
+    switch (rq.size) {
+    case 4: predict<4>(s_ref[wave], dst, rq.mode, is_luma, lane); break;
+    case 8: predict<8>(s_ref[wave], dst, rq.mode, is_luma, lane); break;
+    case 16: predict<16>(s_ref[wave], dst, rq.mode, is_luma, lane); break;
+    default: predict<32>(s_ref[wave], dst, rq.mode, is_luma, lane); break;
+    }
+}
+
+std::mutex g_pred_mu;   // the per-call form shares one staging area
+
 }  // namespace
+
+extern "C" int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_intra_pred_batch_dev: negative request count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(d_ref_samples && d_req && d_pred, "xmi_intra_pred_batch_dev: null argument");
+    IntraPredParams p = { d_ref_samples, d_req, d_pred, n };
+    hipLaunchKernelGGL(intra_pred_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+extern "C" int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t stride, uint32_t mode, uint32_t size, uint32_t is_luma)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(dst && ref, "xmi_enc_intra_pred: null argument");
+    XMI_ARG(size == 4 || size == 8 || size == 16 || size == 32, "xmi_enc_intra_pred: size %u not in {4,8,16,32}", size);
+    XMI_ARG(mode < 35, "xmi_enc_intra_pred: mode %u > 34", mode);
+    std::lock_guard<std::mutex> lk(g_pred_mu);
+    const size_t rq_off = 144, out_off = 160, blk = (size_t)size * size;
+    uint8_t *dev = static_cast<uint8_t *>(xmi::scratch(9, out_off + 1024));
+    if (!dev) return XMI_ERR_HIP;
+    uint8_t host[160];
+    memset(host, 0, sizeof host);
+    memcpy(host, ref, 4 * size + 1);
+    xmi_intra_pred_request rq = { (uint8_t)size, (uint8_t)mode, (uint8_t)(is_luma ? 1 : 0), 0, 0 };
+    memcpy(host + rq_off, &rq, sizeof rq);
+    XMI_HIP(hipMemcpy(dev, host, sizeof host, hipMemcpyHostToDevice));
+    IntraPredParams p = { dev, reinterpret_cast<const xmi_intra_pred_request *>(dev + rq_off), dev + out_off, 1 };
+    hipLaunchKernelGGL(intra_pred_kernel, dim3(1), dim3(256), 0, nullptr, p);
+    XMI_HIP(hipGetLastError());
+    uint8_t out[1024];
+    XMI_HIP(hipMemcpy(out, dev + out_off, blk, hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < size; y++) memcpy(dst + (size_t)y * stride, out + (size_t)y * size, size);
+    return XMI_OK;
+}
 
 extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                           const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream)
