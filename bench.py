@@ -84,6 +84,9 @@ def cpu_baseline(cur, refp, rng, budget_s=12.0):
         prims = cpu_primitives(ref_lib)
         if prims:
             out["primitives"] = prims
+        enc = cpu_encoder_fps()
+        if enc:
+            out["encoder"] = enc
         return out
     finally:
         os.unlink(path)
@@ -99,6 +102,27 @@ def cpu_primitives(ref_lib, seconds_per_case=0.25):
     lines = subprocess.run(args, capture_output=True, text=True, timeout=120).stdout.splitlines()
     rows = [json.loads(x) for x in lines if x.startswith("{")]
     return {r["cpu"]: {"Mblk_per_s": r["Mblk_per_s"], "GBps": r["GBps"], "kind": r["kind"]} for r in rows}
+
+
+def cpu_encoder_fps(frames=6, qp=32):
+    """The reference's encoder (its own sources compiled into oracle/_ref/x265_refsse; the 7 NASM-only SATD/SSD entries
+    come from the restatement) on a short 1080p IPPP clip, one thread, wall clock of the whole run."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265_refsse")
+    gen = os.path.join(ROOT, "tools", "gen_yuv.py")
+    if not (os.path.exists(exe) and os.path.exists(gen)):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        yuv, out = os.path.join(d, "in.yuv"), os.path.join(d, "out.265")
+        subprocess.run([sys.executable, gen, "1920", "1080", str(frames), "7", yuv], check=True, timeout=300)
+        cmd = [exe, "-i", yuv, "-o", out, "-w", "1920", "-h", "1080", "-f", str(frames), "-q", str(qp), "-ip", "100",
+               "-sceneChange", "0", "-t", "1"]
+        t0 = time.perf_counter()
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        sec = time.perf_counter() - t0
+        if res.returncode != 0 or not os.path.exists(out):
+            return None
+        return {"fps": round(frames / sec, 3), "frames": frames, "qp": qp, "threads": 1, "bytes": os.path.getsize(out),
+                "what": "1920x1080 synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
 
 
 def main():
