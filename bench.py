@@ -146,11 +146,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # XMI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("XMI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    comm_dev = dev if backend == "nccl" else torch.device("cpu")
 
     L = capi.load()
     capi.check(L.xmi_init(local))
@@ -200,7 +208,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # average duration of the dominant kernel (one launch per step), HIP events on the launch stream
@@ -214,8 +222,11 @@ def main():
     fr = np.arange(args.steps) + rank * args.steps
     rec = segments.make_records(fr, np.ones(args.steps), np.full(args.steps, 32), np.zeros(args.steps),
                                 np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
-    allrec = segments.gather_records(rec, device=dev)
+    allrec = segments.gather_records(rec, device=comm_dev)
     assert allrec.shape[0] == args.steps * world
+    if world > 1:              # all collectives are done: leave the group together, before rank 0's CPU-side legs
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         abytes, cands = algorithmic_bytes(w, h, R, PAD)
@@ -239,8 +250,6 @@ def main():
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
