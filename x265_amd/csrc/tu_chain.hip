@@ -637,7 +637,13 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
     __shared__ uint32_t s_sum[4][64];                  // per wavefront: sum of |level| of the 64 TUs, memory order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    auto mat4 = [](int type, int k, int j) { return type ? (int)k_dst4[k * 4 + j] : dct_coef(4, k, j); };
+    // 4-point DCT / DST-VII matrices (src/pixel.cpp:1415, 1567) with each row packed into a word, so that building the
+    // operand fragments needs no table loads
+    auto mat4 = [](int type, int k, int j) {
+        const unsigned row = type ? (k == 0 ? 0x544a371du : k == 1 ? 0xb6004a4au : k == 2 ? 0x37b6e354u : 0xe34aac37u)
+                                  : (k == 0 ? 0x40404040u : k == 1 ? 0xaddc2453u : k == 2 ? 0x40c0c040u : 0xdc53ad24u);
+        return (int)(int8_t)(row >> (8 * j));
+    };
     auto mat = [&](int type, int k, int j) { return (k >> 2) == (j >> 2) ? mat4(type, k & 3, j & 3) : 0; };
     for (int e = tid; e < 512; e += 256) {
         const int type = e >> 8, kind = (e >> 6) & 3, rr = e & 31, hh = (e >> 5) & 1;
