@@ -222,6 +222,25 @@ def test_intra_prediction_both_edge_filter_settings(lib, golden_dir, n):
                 np.testing.assert_array_equal(dst, want[ci, luma, mode], err_msg=f"case {ci} luma {luma} mode {mode}")
 
 
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_tu_chain_replays_encoder_trace(lib, golden_dir, n):
+    """orc_tu_chain on the chains recorded from the reference's encoder (tests/golden/tu_trace.npz): same levels, sums
+    and reconstructed blocks as the encoder's own xSubDct -> xQuant -> xDeQuant -> xIDctAdd calls produced."""
+    g = np.load(os.path.join(golden_dir, "tu_trace.npz"))
+    meta = g[f"n{n}_meta"]
+    pix, pred, level, rec = g[f"n{n}_pix"], g[f"n{n}_pred"], g[f"n{n}_level"], g[f"n{n}_rec"]
+    assert {int(v) for v in meta[:, 2]} == {O.SLICE_P, O.SLICE_I}
+    for i in range(len(meta)):
+        dst4, qp, slice_, _, _, total, has_rec = (int(v) for v in meta[i])
+        wl, wr = np.zeros((n, n), np.int16), np.zeros((n, n), np.uint8)
+        got = lib.orc_tu_chain(O.p(np.ascontiguousarray(pix[i])), O.p(np.ascontiguousarray(pred[i])), O.p(wr), O.p(wl), n, n, n, qp,
+                               1 if dst4 else O.MODE_INVALID, slice_)
+        assert got == total, f"chain {i}: sum"
+        np.testing.assert_array_equal(wl, level[i], err_msg=f"chain {i}: levels")
+        if has_rec or total == 0:
+            np.testing.assert_array_equal(wr, rec[i], err_msg=f"chain {i}: reconstruction")
+
+
 def test_motion_search_replays_encoder_trace(lib, golden_dir):
     """Every xMotionSearch call the reference's encoder made on three P pictures of the 416x240 QP32 clip
     (recorded by oracle/gen_me_trace.py from a bit-identical encode): the oracle returns the same MV, cost,

@@ -155,6 +155,23 @@ def test_quant_dequant_idct_raw_golden(L, golden_dir, n):
 
 
 @pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_tu_chain_replays_encoder_trace(L, golden_dir, n):
+    """The chains the reference's encoder ran while coding the 416x240 clip at QP 32 and 22 (luma and chroma, intra and
+    inter, DST and DCT; recorded from bit-identical encodes, tests/golden/tu_trace.npz) as one batch: the encoder's own
+    levels, level sums and reconstructed blocks come back."""
+    g = np.load(os.path.join(golden_dir, "tu_trace.npz"))
+    meta = g[f"n{n}_meta"]                      # dst4, qp, slice, poc, stride, sum, has_rec
+    pix, pred = g[f"n{n}_pix"], g[f"n{n}_pred"]
+    flags = (meta[:, 2] == O.SLICE_I).astype(np.uint8) | (meta[:, 0].astype(np.uint8) << 1)
+    lev, rec, sm = tu_chain_gpu(L, n, pix, pred, meta[:, 1], flags)
+    np.testing.assert_array_equal(sm, meta[:, 5].astype(np.uint32))
+    np.testing.assert_array_equal(lev, g[f"n{n}_level"])
+    done = (meta[:, 6] == 1) | (meta[:, 5] == 0)     # reconstructed by the encoder, or all-zero (prediction copied)
+    assert done.sum() > len(meta) // 2
+    np.testing.assert_array_equal(rec[done], g[f"n{n}_rec"][done])
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
 def test_tu_chain_random_vs_oracle(L, orc, n):
     rng = np.random.default_rng(100 + n)
     cnt = 301 if n <= 8 else 67
