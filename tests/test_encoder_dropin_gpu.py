@@ -79,3 +79,12 @@ def test_bitstream_identical_with_every_gpu_service(tmp_path):
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
     got = encode("gpu_all", yuv, str(tmp_path / "a.265"), w, h, frames, qp)
     assert got == (want["md5"], want["bytes"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-ME encoder not built (make -C oracle trace)")
+def test_gop_segments_on_two_ranks_with_gpu_motion_search():
+    """tools/encode_segments.py, two ranks (gloo rendezvous, both on this box's GPU), each encoding its GOP with the GPU
+    motion search: every gathered segment is the stream recorded for it (tests/golden/segment_md5.json)."""
+    from tests.test_segments_gloo import run_segment_encode
+    res = run_segment_encode("gpu_me", 2)
+    assert res["parity"] == "identical" and res["ranks"] == 2

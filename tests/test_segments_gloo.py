@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from x265_amd import segments
 
@@ -66,3 +67,31 @@ def test_gather_world2_gloo(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.count("ok") == 2
+
+
+REFSSE = os.path.join(ROOT, "oracle", "_ref", "x265_refsse")
+
+
+def run_segment_encode(variant, nproc, extra_env=None):
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1", XMI_BENCH_BACKEND="gloo", **(extra_env or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tools", "encode_segments.py"), "--variant", variant, "--frames", "16",
+           "--gop", "8", "--check"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [x for x in res.stdout.splitlines() if x.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.skipif(not os.path.exists(REFSSE), reason="integration harness not built (make -C oracle enc)")
+def test_gop_segments_on_two_ranks_join_into_the_per_segment_reference_streams():
+    """Two ranks encode one GOP each with a fresh encoder (the reference's control flow, CPU primitives); the gathered
+    byte segments are the streams recorded per segment, and the joined stream is the same as one rank produces."""
+    two = run_segment_encode("refsse", 2)
+    assert two["parity"] == "identical" and two["ranks"] == 2 and set(two["segments"]) == {"0-8", "8-16"}
+    one = run_segment_encode("refsse", 1)
+    assert one["md5"] == two["md5"] and one["bytes"] == two["bytes"]
