@@ -11,81 +11,179 @@
 // because the taps add up to 64. All results are clipped to 0..255.
 #include "xmi_common.h"
 
+#include <type_traits>
+
 namespace {
 
-__constant__ int k_luma[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
-                                  { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+typedef unsigned int u32;
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// xg_lumaFilter (src/table.cpp:525-530), fractions 1..3, packed for v_dot4_i32_i8 (taps 0..3 | 4..7 as signed bytes)
+// and for v_dot2_i32_i16 (tap pairs as signed 16-bit halves)
+constexpr int kTap[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+                             { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+constexpr int pack4(int f, int o) { return (kTap[f][o] & 255) | ((kTap[f][o + 1] & 255) << 8) | ((kTap[f][o + 2] & 255) << 16) | ((kTap[f][o + 3] & 255) << 24); }
+constexpr int pack2(int f, int o) { return (kTap[f][o] & 0xffff) | ((kTap[f][o + 1] & 0xffff) << 16); }
 
 constexpr int TW = 64, TH = 16;   // output tile
 constexpr int RW = TW + 8, RH = TH + 7;
 
 __device__ __forceinline__ int clip8(int v) { return min(255, max(0, v)); }
+__device__ __forceinline__ u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+
+// 8-tap sum over bytes held as two dwords of (sample - 128): sum c_t p_t = dot + 128 * 64
+template <int F>
+__device__ __forceinline__ int tap8_bytes(u32 lo, u32 hi)
+{
+    return __builtin_amdgcn_sdot4((int)hi, pack4(F, 4), __builtin_amdgcn_sdot4((int)lo, pack4(F, 0), 8192, false), false);
+}
+// 8-tap sum over 16-bit values held as four dwords of (row 2k, row 2k + 1) pairs
+template <int F>
+__device__ __forceinline__ int tap8_pairs(const u32 (&p)[4])
+{
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = pack2(F, 2 * k);
+        s = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, p[k]), __builtin_bit_cast(s16x2, c), s, false);
+    }
+    return s;
+}
+
+template <int F>
+__device__ __forceinline__ void h_sums(const u32 (&lo)[4], const u32 (&hi)[4], int16_t *dst)
+{
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = tap8_bytes<F>(lo[j], hi[j]);
+    *reinterpret_cast<uint2 *>(dst) = make_uint2((u32)(v[0] & 0xffff) | ((u32)v[1] << 16), (u32)(v[2] & 0xffff) | ((u32)v[3] << 16));
+}
+
+__device__ __forceinline__ void store4(uint8_t *dst, u32 v, int x, int cols, bool aligned)
+{
+    if (x + 4 <= cols - 4 && aligned) {
+        *reinterpret_cast<u32 *>(dst) = v;
+    } else {
+        for (int e = 0; e < 4; e++)
+            if (x + e < cols - 4) dst[e] = (uint8_t)(v >> (8 * e));
+    }
+}
 
 // buffer: `rows` x `stride` bytes; samples within 4 of the buffer edge are left untouched in planes 1..15
 __global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t *planes, int stride, int rows, int cols)
 {
-    __shared__ uint8_t s_ref[RH][RW];
-    __shared__ int16_t s_h[3][RH][TW];     // horizontal sums for xf = 1..3 (unbiased, fit 16 bits)
+    __shared__ __align__(16) uint8_t s_ref[RH][RW];          // window rows y0-3 .., columns x0-4 ..
+    __shared__ __align__(16) int16_t s_h[3][RH][TW];         // horizontal sums for xf = 1..3 (unbiased, fit 16 bits)
     const int tid = threadIdx.x;
     const int x0 = 4 + blockIdx.x * TW, y0 = 4 + blockIdx.y * TH;   // first output sample of the tile
     const size_t plane_bytes = (size_t)rows * stride;
 
-    for (int e = tid; e < RH * RW; e += 256) {
-        const int ry = e / RW, rx = e % RW;
-        const int y = min(rows - 1, y0 - 3 + ry), x = min(cols - 1, x0 - 3 + rx);
-        s_ref[ry][rx] = ref[(size_t)y * stride + x];
+    // window: rows y0-3 .., columns x0-4 .. x0+67 (one column more on the left than the filters need, so that it starts
+    // on a dword of the buffer); whole dwords when the buffer allows it, clamped bytes at the right edge otherwise
+    const bool dwords = ((reinterpret_cast<uintptr_t>(ref) | (uintptr_t)stride) & 3) == 0 && x0 + RW - 4 <= cols;
+    if (dwords) {
+        for (int e = tid; e < RH * (RW / 4); e += 256) {
+            const int ry = e / (RW / 4), c = e % (RW / 4);
+            const int y = min(rows - 1, y0 - 3 + ry);
+            reinterpret_cast<u32 *>(&s_ref[ry][0])[c] = *reinterpret_cast<const u32 *>(ref + (size_t)y * stride + x0 - 4 + 4 * c);
+        }
+    } else {
+        for (int e = tid; e < RH * RW; e += 256) {
+            const int ry = e / RW, rx = e % RW;
+            const int y = min(rows - 1, y0 - 3 + ry), x = min(cols - 1, x0 - 4 + rx);
+            s_ref[ry][rx] = ref[(size_t)y * stride + x];
+        }
     }
     __syncthreads();
-    for (int e = tid; e < RH * TW; e += 256) {
-        const int ry = e / TW, x = e % TW;
+    // horizontal sums: an item = 4 consecutive columns of one window row (bytes 4g + 1 .. 4g + 11 of the row)
+    for (int e = tid; e < RH * (TW / 4); e += 256) {
+        const int ry = e / (TW / 4), g = e % (TW / 4);
+        const u32 *w = reinterpret_cast<const u32 *>(&s_ref[ry][4 * g]);
+        const u32 w0 = w[0] ^ 0x80808080u, w1 = w[1] ^ 0x80808080u, w2 = w[2] ^ 0x80808080u;
+        u32 lo[4], hi[4];
 #pragma unroll
-        for (int xf = 1; xf < 4; xf++) {
-            int s = 0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) s += (int)s_ref[ry][x + t] * k_luma[xf][t];
-            s_h[xf - 1][ry][x] = (int16_t)s;
+        for (int j = 0; j < 3; j++) {
+            lo[j] = __builtin_amdgcn_alignbyte(w1, w0, j + 1);
+            hi[j] = __builtin_amdgcn_alignbyte(w2, w1, j + 1);
         }
+        lo[3] = w1;
+        hi[3] = w2;
+        h_sums<1>(lo, hi, &s_h[0][ry][4 * g]);
+        h_sums<2>(lo, hi, &s_h[1][ry][4 * g]);
+        h_sums<3>(lo, hi, &s_h[2][ry][4 * g]);
     }
     __syncthreads();
     // each thread: 4 consecutive samples of one row, all 16 phases
     const int ty = tid / 16, tx = (tid % 16) * 4;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= rows - 4) return;
-    unsigned out[16];
+    u32 out[16];
+
+    // ---- integer and vertical phases: bytes (row ty + t, columns tx + 4 .. tx + 7) of the window, t = 0..7 ----
+    u32 col_lo[4], col_hi[4];      // per output column j: the 8 rows as (sample - 128) bytes
+    {
+        u32 r[8];
 #pragma unroll
-    for (int ph = 0; ph < 16; ph++) out[ph] = 0;
+        for (int t = 0; t < 8; t++)
+            r[t] = *reinterpret_cast<const u32 *>(&s_ref[ty + t][tx + 4]);
+        out[0] = r[3];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        const int cx = tx + e;
-        out[0] |= (unsigned)s_ref[ty + 3][cx + 3] << (8 * e);
-#pragma unroll
-        for (int xf = 1; xf < 4; xf++) out[xf] |= (unsigned)clip8((s_h[xf - 1][ty + 3][cx] + 32) >> 6) << (8 * e);
-#pragma unroll
-        for (int yf = 1; yf < 4; yf++) {
-            int s = 0;
-#pragma unroll
-            for (int t = 0; t < 8; t++) s += (int)s_ref[ty + t][cx + 3] * k_luma[yf][t];
-            out[yf * 4] |= (unsigned)clip8((s + 32) >> 6) << (8 * e);
-#pragma unroll
-            for (int xf = 1; xf < 4; xf++) {
-                int v = 0;
-#pragma unroll
-                for (int t = 0; t < 8; t++) v += (int)s_h[xf - 1][ty + t][cx] * k_luma[yf][t];
-                out[yf * 4 + xf] |= (unsigned)clip8((v + 2048) >> 12) << (8 * e);
-            }
+        for (int half = 0; half < 2; half++) {       // 4 x 4 byte transposes
+            const u32 a = r[4 * half] ^ 0x80808080u, b = r[4 * half + 1] ^ 0x80808080u, c = r[4 * half + 2] ^ 0x80808080u,
+                      d = r[4 * half + 3] ^ 0x80808080u;
+            const u32 ab_lo = perm(b, a, 0x05010400u), ab_hi = perm(b, a, 0x07030602u);
+            const u32 cd_lo = perm(d, c, 0x05010400u), cd_hi = perm(d, c, 0x07030602u);
+            u32 *dst = half ? col_hi : col_lo;
+            dst[0] = perm(cd_lo, ab_lo, 0x05040100u);
+            dst[1] = perm(cd_lo, ab_lo, 0x07060302u);
+            dst[2] = perm(cd_hi, ab_hi, 0x05040100u);
+            dst[3] = perm(cd_hi, ab_hi, 0x07060302u);
         }
+    }
+    auto pack_v = [&](auto tag) {
+        constexpr int F = decltype(tag)::value;
+        u32 o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o |= (u32)clip8((tap8_bytes<F>(col_lo[j], col_hi[j]) + 32) >> 6) << (8 * j);
+        return o;
+    };
+    out[4] = pack_v(std::integral_constant<int, 1>{});
+    out[8] = pack_v(std::integral_constant<int, 2>{});
+    out[12] = pack_v(std::integral_constant<int, 3>{});
+
+    // ---- horizontal and diagonal phases from the 16-bit horizontal sums ----
+#pragma unroll
+    for (int xf = 1; xf < 4; xf++) {
+        uint2 hrow[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) hrow[t] = *reinterpret_cast<const uint2 *>(&s_h[xf - 1][ty + t][tx]);
+        {   // y fraction 0: row ty + 3
+            const int v0 = (int)(short)(hrow[3].x & 0xffff), v1 = (int)hrow[3].x >> 16, v2 = (int)(short)(hrow[3].y & 0xffff), v3 = (int)hrow[3].y >> 16;
+            out[xf] = (u32)clip8((v0 + 32) >> 6) | ((u32)clip8((v1 + 32) >> 6) << 8) | ((u32)clip8((v2 + 32) >> 6) << 16) | ((u32)clip8((v3 + 32) >> 6) << 24);
+        }
+        u32 pr[4][4];              // [column j][pair k] = (row 2k, row 2k + 1) of column j
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            pr[0][k] = perm(hrow[2 * k + 1].x, hrow[2 * k].x, 0x05040100u);
+            pr[1][k] = perm(hrow[2 * k + 1].x, hrow[2 * k].x, 0x07060302u);
+            pr[2][k] = perm(hrow[2 * k + 1].y, hrow[2 * k].y, 0x05040100u);
+            pr[3][k] = perm(hrow[2 * k + 1].y, hrow[2 * k].y, 0x07060302u);
+        }
+        auto pack_hv = [&](auto tag) {
+            constexpr int F = decltype(tag)::value;
+            u32 o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o |= (u32)clip8((tap8_pairs<F>(pr[j]) + 2048) >> 12) << (8 * j);
+            return o;
+        };
+        out[4 + xf] = pack_hv(std::integral_constant<int, 1>{});
+        out[8 + xf] = pack_hv(std::integral_constant<int, 2>{});
+        out[12 + xf] = pack_hv(std::integral_constant<int, 3>{});
     }
     const size_t at = (size_t)y * stride + x;
+    const bool aligned = (at & 3) == 0;
 #pragma unroll
-    for (int ph = 0; ph < 16; ph++) {
-        uint8_t *dst = planes + ph * plane_bytes + at;
-        if (x + 4 <= cols - 4 && ((at & 3) == 0)) {
-            *reinterpret_cast<unsigned *>(dst) = out[ph];
-        } else {
-            for (int e = 0; e < 4; e++)
-                if (x + e < cols - 4) dst[e] = (uint8_t)(out[ph] >> (8 * e));
-        }
-    }
+    for (int ph = 0; ph < 16; ph++) store4(planes + ph * plane_bytes + at, out[ph], x, cols, aligned);
 }
 
 }  // namespace
