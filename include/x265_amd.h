@@ -260,6 +260,11 @@ int xmi_idct_add(uint8_t *dst, uint32_t stride_dst, const int16_t *src, uint32_t
 int xmi_pred_inter_luma(const uint8_t *ref, uint8_t *pred, uint32_t ref_stride, uint32_t size_x, uint32_t size_y, int mvx, int mvy);
 int xmi_pred_inter_chroma(const uint8_t *ref, uint8_t *pred, uint32_t ref_stride, uint32_t size_x, uint32_t size_y, int mvx, int mvy);
 int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t stride, uint32_t mode, uint32_t size, uint32_t is_luma);
+/* One 35-mode intra search (the loop of src/encode.cpp:4005-4081) with host pointers: src = the PU's source block
+ * (rows src_stride apart, as in the encoder's CTU cache), ref_samples = the 4*size+1 neighbouring samples before
+ * xPaddingRef; the other fields of the request as in xmi_intra_search_batch_dev (x0, y0 are ignored). */
+int xmi_intra_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_samples, const xmi_intra_request *req,
+                     xmi_intra_result *res);
 /* xSubDctQuantRec, src/encode.cpp:3005 */
 int64_t xmi_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef, int size,
                      int stride, int stride_rec, uint32_t qp, uint32_t mode, int slice_type);

@@ -68,6 +68,27 @@ def test_bitstream_identical_with_gpu_interpolation_planes(tmp_path, qp, frames)
     assert got == (want["md5"], want["bytes"])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_intra")), reason="GPU-intra encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_intra_search(tmp_path, qp, frames):
+    """The reference's encoder with every intra luma mode search answered by the GPU (oracle/intra_gpu_hook.cpp: the 35
+    SATD calls of a search return the numbers of one xmi_intra_search on the samples the encoder had before padding;
+    the reference's SATD code does not run for them): the recorded bitstream, i.e. the same 35 SATDs everywhere."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_intra", yuv, str(tmp_path / "i.265"), w, h, frames, qp)
+    assert got == (want["md5"], want["bytes"])
+    # the hook reports how many searches the GPU answered: all of them, not a silent pass-through
+    exe = os.path.join(REFDIR, "x265_gpu_intra")
+    res = subprocess.run([exe, "-i", yuv, "-o", str(tmp_path / "j.265"), "-w", str(w), "-h", str(h), "-f", "1", "-q", str(qp), "-ip", "100",
+                          "-sceneChange", "0", "-t", "1"], capture_output=True, text=True, timeout=600)
+    import re
+    m = re.search(r"intra_gpu_hook: (\d+) searches on the GPU, (\d+) other SATD calls", res.stderr)
+    assert m and int(m.group(1)) > 2000, res.stderr[-500:]
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_all")), reason="all-GPU encoder not built (make -C oracle trace)")
 def test_bitstream_identical_with_every_gpu_service(tmp_path):
     """Motion search from the frame session AND every pixel primitive (SAD / SATD / SSD tables, xSubDct, xQuant,

@@ -135,6 +135,38 @@ def test_intra_search_replays_encoder_trace(L):
             assert res[i].best_mode == int(np.argmin(cost)) and res[i].best_cost == cost.min()
 
 
+def test_percall_intra_search_equals_batch(L):
+    """xmi_intra_search (host pointers, source rows 64 bytes apart as in the encoder's CTU cache) returns what the
+    batch entry point returns for the same search."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intra.npz"))
+    for n in (4, 8, 16, 32):
+        t = f"n{n}_"
+        raw, src = g[t + "raw"], g[t + "src"]
+        nc = len(raw)
+        frame = np.zeros((32, 32 * nc), np.uint8)
+        reqs = (capi.IntraRequest * nc)()
+        refs = np.zeros((nc, capi.INTRA_REF_PITCH), np.uint8)
+        for ci in range(nc):
+            frame[:n, 32 * ci:32 * ci + n] = src[ci]
+            rq = reqs[ci]
+            rq.x0, rq.y0, rq.size = 32 * ci, 0, n
+            rq.valids, rq.strong_smoothing = int(g[t + "valids"][ci]), int(g[t + "strong"][ci])
+            rq.mpm[0], rq.mpm[1], rq.mpm[2] = [int(v) for v in g[t + "mpm"][ci]]
+            rq.sqrt_lambda = float(g[t + "sqrt_lambda"][ci])
+            refs[ci, :4 * n + 1] = raw[ci]
+        batch = run_gpu(L, frame, reqs, refs)
+        cache = np.zeros((64, 64), np.uint8)
+        for ci in range(nc):
+            cache[:] = 0
+            cache[32:32 + n, 16:16 + n] = src[ci]
+            one = capi.IntraResult()
+            capi.check(L.xmi_intra_search(O.at(cache, 32, 16), 64, O.p(np.ascontiguousarray(refs[ci])), C.byref(reqs[ci]), C.byref(one)))
+            assert bytes(one) == bytes(batch[ci]), f"size {n} case {ci}"
+    bad = capi.IntraRequest()
+    bad.size = 64
+    assert L.xmi_intra_search(O.p(cache), 64, O.p(refs[0]), C.byref(bad), C.byref(one)) == -1
+
+
 def test_intra_search_empty_and_errors(L):
     assert L.xmi_intra_search_batch_dev(None, 0, None, None, 0, None, None) == 0
     a = torch.zeros(256, dtype=torch.uint8, device="cuda")

@@ -102,6 +102,8 @@ def load():
     if hasattr(L, "xmi_intra_search_batch_dev"):
         L.xmi_intra_search_batch_dev.restype = i
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
+        L.xmi_intra_search.restype = i
+        L.xmi_intra_search.argtypes = [vp, C.c_uint32, vp, C.POINTER(IntraRequest), C.POINTER(IntraResult)]
     if hasattr(L, "xmi_pred_inter_batch_dev"):
         L.xmi_pred_inter_batch_dev.restype = i
         L.xmi_pred_inter_batch_dev.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp]

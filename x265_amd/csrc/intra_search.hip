@@ -338,6 +338,39 @@ extern "C" int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t str
 }
 
 extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
+                                          const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
+
+extern "C" int xmi_intra_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_samples, const xmi_intra_request *req,
+                                xmi_intra_result *res)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(src && ref_samples && req && res, "xmi_intra_search: null argument");
+    const int n = req->size;
+    XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32, "xmi_intra_search: size %d not in {4,8,16,32}", n);
+    std::lock_guard<std::mutex> lk(g_pred_mu);
+    // staging: source block packed (rows n apart) | samples | request | result
+    const size_t off_ref = 1024, off_req = off_ref + 144, off_res = off_req + 32, total = off_res + sizeof(xmi_intra_result);
+    uint8_t *dev = static_cast<uint8_t *>(xmi::scratch(9, 2048));
+    if (!dev) return XMI_ERR_HIP;
+    uint8_t host[off_res];
+    memset(host, 0, sizeof host);
+    for (int y = 0; y < n; y++) memcpy(host + (size_t)y * n, src + (size_t)y * src_stride, (size_t)n);
+    memcpy(host + off_ref, ref_samples, (size_t)(4 * n + 1));
+    xmi_intra_request rq = *req;
+    rq.x0 = rq.y0 = 0;
+    memcpy(host + off_req, &rq, sizeof rq);
+    static_assert(sizeof(xmi_intra_request) <= 32 && 1024 + 144 + 32 + sizeof(xmi_intra_result) <= 2048, "staging layout");
+    (void)total;
+    XMI_HIP(hipMemcpy(dev, host, sizeof host, hipMemcpyHostToDevice));
+    rc = xmi_intra_search_batch_dev(dev, n, dev + off_ref, reinterpret_cast<const xmi_intra_request *>(dev + off_req), 1,
+                                    reinterpret_cast<xmi_intra_result *>(dev + off_res), nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy(res, dev + off_res, sizeof(xmi_intra_result), hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
+
+extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                           const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream)
 {
     int rc = xmi::require_device();
