@@ -150,3 +150,25 @@ def test_intra_pred_matches_reference_golden(L, n):
         assert not dst[:, n:].any()
     assert L.xmi_enc_intra_pred(O.p(dst), O.p(rf), 64, 35, n, 1) == -1
     assert L.xmi_enc_intra_pred(O.p(dst), O.p(rf), 64, 0, 64, 1) == -1
+
+
+def test_requests_with_impossible_sizes_write_nothing(L):
+    """Request tables live in device memory, so the kernels guard themselves: a size that is no PU size is skipped."""
+    y = torch.full((96, 96), 7, dtype=torch.uint8, device="cuda")
+    reqs = (capi.InterPredRequest * 2)()
+    reqs[0].size, reqs[0].x0, reqs[0].y0, reqs[0].out_y = 8, 16, 16, 0
+    reqs[1].size, reqs[1].x0, reqs[1].y0, reqs[1].out_y = 1000, 16, 16, 64
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    out = torch.full((4096,), 255, dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_pred_inter_batch_dev(y.data_ptr(), 96, None, None, 0, d_req.data_ptr(), 2, out.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert (o[:64] == 7).all() and (o[64:] == 255).all()
+    ir = (capi.IntraPredRequest * 1)()
+    ir[0].size, ir[0].mode, ir[0].is_luma, ir[0].out = 64, 1, 1, 0
+    d_ir = torch.frombuffer(bytearray(bytes(ir)), dtype=torch.uint8).cuda()
+    samples = torch.zeros(capi.INTRA_REF_PITCH, dtype=torch.uint8, device="cuda")
+    out.fill_(255)
+    capi.check(L.xmi_intra_pred_batch_dev(samples.data_ptr(), d_ir.data_ptr(), 1, out.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy() == 255).all()

@@ -246,8 +246,7 @@ __global__ void __launch_bounds__(256) intra_search_kernel(const IntraParams p)
     const int idx = WPR == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
     if (idx >= p.n) return;
     const xmi_intra_request rq = p.req[idx];
-    const int size = rq.size == 4 || rq.size == 8 || rq.size == 16 ? rq.size : 32;
-    if (size != N) return;                      // uniform per workgroup when WPR == 4
+    if (rq.size != N) return;                   // another instance's size, or no PU size at all (then no result is written)
     search<N, WPR>(p, rq, idx, s_ref[wave], s_src[wave], lane, WPR == 4 ? wave : 0, s_best_cost, s_best_mode);
 }
 
@@ -281,6 +280,7 @@ __global__ void __launch_bounds__(256) intra_pred_kernel(const IntraPredParams p
     const int idx = (int)blockIdx.x * 4 + wave;
     if (idx >= p.n) return;
     const xmi_intra_pred_request rq = p.req[idx];
+    if (rq.size != 4 && rq.size != 8 && rq.size != 16 && rq.size != 32) return;       // not a PU size: nothing is written
     const uint8_t *raw = p.refs + (size_t)idx * XMI_INTRA_REF_PITCH;
     for (int i = lane; i < 4 * rq.size + 1; i += 64) s_ref[wave][i] = raw[i];
     __builtin_amdgcn_wave_barrier();

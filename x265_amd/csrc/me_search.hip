@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     case 8: search<8, SURF>(p, rq, idx, lane); break;
     case 16: search<16, SURF>(p, rq, idx, lane); break;
     case 32: search<32, SURF>(p, rq, idx, lane); break;
-    default: search<64, SURF>(p, rq, idx, lane); break;
+    case 64: search<64, SURF>(p, rq, idx, lane); break;
+    default: break;                               // not a PU size: the result entry is left untouched
     }
 }
 

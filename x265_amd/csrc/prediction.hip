@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) inter_pred_kernel(const PredParams p)
     const int plane = blockIdx.y;
     if (!p.pred[plane]) return;                         // uniform per workgroup
     const xmi_inter_pred_request rq = p.req[blockIdx.x];
+    if (rq.size != 8 && rq.size != 16 && rq.size != 32 && rq.size != 64) return;     // not a PU size: nothing is written
     if (plane == 0) {
         const uint8_t *ref = p.ref[0] + (ptrdiff_t)(rq.y0 + (rq.mv[1] >> 2)) * p.stride_y + rq.x0 + (rq.mv[0] >> 2);
         predict_block<8>(ref, p.stride_y, p.pred[0] + rq.out_y, rq.size, rq.mv[0] & 3, rq.mv[1] & 3, s_win, s_h);
