@@ -296,6 +296,20 @@ __global__ void __launch_bounds__(256) intra_pred_kernel(const IntraPredParams p
 
 std::mutex g_pred_mu;   // the per-call form shares one staging area
 
+// one kernel per PU size present in `sizes` (bit mask of 4, 8, 16, 32) over the whole request array
+int launch_search(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples, const xmi_intra_request *d_req, int n,
+                  xmi_intra_result *d_res, int sizes, void *stream)
+{
+    IntraParams p = { d_src, d_ref_samples, d_req, d_res, src_stride, n };
+    const dim3 grid((n + 3) / 4), block(256);
+    if (sizes & 4) hipLaunchKernelGGL(intra_search_kernel<4>, grid, block, 0, xmi::as_stream(stream), p);
+    if (sizes & 8) hipLaunchKernelGGL(intra_search_kernel<8>, grid, block, 0, xmi::as_stream(stream), p);
+    if (sizes & 16) hipLaunchKernelGGL(intra_search_kernel<16>, grid, block, 0, xmi::as_stream(stream), p);
+    if (sizes & 32) hipLaunchKernelGGL(intra_search_kernel<32>, grid, block, 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
 }  // namespace
 
 extern "C" int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream)
@@ -337,9 +351,6 @@ extern "C" int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t str
     return XMI_OK;
 }
 
-extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
-                                          const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
-
 extern "C" int xmi_intra_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_samples, const xmi_intra_request *req,
                                 xmi_intra_result *res)
 {
@@ -363,8 +374,8 @@ extern "C" int xmi_intra_search(const uint8_t *src, uint32_t src_stride, const u
     static_assert(sizeof(xmi_intra_request) <= 32 && 1024 + 144 + 32 + sizeof(xmi_intra_result) <= 2048, "staging layout");
     (void)total;
     XMI_HIP(hipMemcpy(dev, host, sizeof host, hipMemcpyHostToDevice));
-    rc = xmi_intra_search_batch_dev(dev, n, dev + off_ref, reinterpret_cast<const xmi_intra_request *>(dev + off_req), 1,
-                                    reinterpret_cast<xmi_intra_result *>(dev + off_res), nullptr);
+    rc = launch_search(dev, n, dev + off_ref, reinterpret_cast<const xmi_intra_request *>(dev + off_req), 1,
+                       reinterpret_cast<xmi_intra_result *>(dev + off_res), n, nullptr);
     if (rc != XMI_OK) return rc;
     XMI_HIP(hipMemcpy(res, dev + off_res, sizeof(xmi_intra_result), hipMemcpyDeviceToHost));
     return XMI_OK;
@@ -379,12 +390,5 @@ extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, 
     if (n == 0) return XMI_OK;
     XMI_ARG(d_src && d_ref_samples && d_req && d_res, "xmi_intra_search_batch_dev: null argument");
     XMI_ARG(src_stride % 4 == 0 && ((uintptr_t)d_src & 3) == 0, "xmi_intra_search_batch_dev: source frame must be 4-byte aligned");
-    IntraParams p = { d_src, d_ref_samples, d_req, d_res, src_stride, n };
-    const dim3 grid((n + 3) / 4), block(256);
-    hipLaunchKernelGGL(intra_search_kernel<4>, grid, block, 0, xmi::as_stream(stream), p);
-    hipLaunchKernelGGL(intra_search_kernel<8>, grid, block, 0, xmi::as_stream(stream), p);
-    hipLaunchKernelGGL(intra_search_kernel<16>, grid, block, 0, xmi::as_stream(stream), p);
-    hipLaunchKernelGGL(intra_search_kernel<32>, grid, block, 0, xmi::as_stream(stream), p);
-    XMI_HIP(hipGetLastError());
-    return XMI_OK;
+    return launch_search(d_src, src_stride, d_ref_samples, d_req, n, d_res, 4 | 8 | 16 | 32, stream);
 }
