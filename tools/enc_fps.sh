@@ -4,7 +4,7 @@
 frames=${1:-6}; qp=${2:-32}
 d=$(mktemp -d)
 python3 tools/gen_yuv.py 1920 1080 $frames 7 $d/in.yuv
-for v in refsse gpu_me gpu_planes; do
+for v in refsse gpu_me gpu_planes gpu_intra; do
   s=$(date +%s.%N)
   timeout -k 10 600 oracle/_ref/x265_$v -i $d/in.yuv -o $d/$v.265 -w 1920 -h 1080 -f $frames -q $qp -ip 100 -sceneChange 0 -t 1 > $d/$v.log 2>&1 || { echo "$v failed"; tail -3 $d/$v.log; exit 1; }
   e=$(date +%s.%N)
