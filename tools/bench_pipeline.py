@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""GPU-side work of one 1080p P picture as ONE captured HIP graph: quarter-pel planes of the previous reconstruction,
+(optionally) the SAD surface, a picture's worth of motion searches, the prediction blocks of every PU (luma + both
+chroma planes) and the transform chains of every TU, all device-resident, requests synthetic. It measures what a host
+CTU loop would have to keep fed - the decisions themselves (MVPs, splits, modes) are the host's and are given here.
+Prints one JSON line per variant."""
+import ctypes as C
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as B  # noqa: E402
+from x265_amd import capi, layout  # noqa: E402
+
+L = capi.load()
+capi.check(L.xmi_init(0))
+W, H, PAD, R = 1920, 1088, 80, 64
+rng = np.random.default_rng(11)
+f0, f1 = B.synth_frame(W, H, 0, 7), B.synth_frame(W, H, 1, 7)
+ref = torch.from_numpy(B.pad_frame(f0, PAD)).cuda()
+cur = torch.from_numpy(f1).cuda()
+rows, stride = ref.shape
+cpad = PAD // 2
+ref_u = torch.randint(0, 256, (H // 2 + 2 * cpad, W // 2 + 2 * cpad), dtype=torch.uint8, device="cuda")
+ref_v = torch.randint(0, 256, ref_u.shape, dtype=torch.uint8, device="cuda")
+cstride = ref_u.shape[1]
+planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+nctu = (W // 64) * (H // 64)
+geom = capi.SadGeom(W, H, W, stride, R)
+sp = [torch.zeros(layout.plane_elems(nctu, R, lv), dtype=torch.int16 if lv < 2 else torch.int32, device="cuda") for lv in range(4)]
+
+# motion searches: the mix of one picture (every 8x8 of a quarter of the CTUs, 16x16 / 32x32 / 64x64 of all)
+reqs = []
+for n, frac in ((64, 1.0), (32, 1.0), (16, 1.0), (8, 0.85)):
+    for y in range(0, H, n):
+        for x in range(0, W, n):
+            if rng.random() < frac:
+                reqs.append((x, y, n))
+nreq = len(reqs)
+me = (capi.MeRequest * nreq)()
+for i, (x, y, n) in enumerate(reqs):
+    rq = me[i]
+    rq.x0, rq.y0, rq.size = x, y, n
+    rq.mvp[0][0], rq.mvp[0][1] = -12 + int(rng.integers(-4, 5)), -8 + int(rng.integers(-4, 5))
+    rq.mvp[1][0], rq.mvp[1][1] = -12 + int(rng.integers(-4, 5)), -8 + int(rng.integers(-4, 5))
+    rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+    rq.sqrt_lambda = int(math.sqrt(0.578 * 2 ** ((32 - 12) / 3.0)))
+d_me = torch.frombuffer(bytearray(bytes(me)), dtype=torch.uint8).cuda()
+d_me_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+
+# final partition for prediction + transform: 16x16 PUs over the whole picture, one 16x16 luma TU and two 8x8 chroma TUs each
+pus = [(x, y) for y in range(0, H, 16) for x in range(0, W, 16)]
+npu = len(pus)
+pr = (capi.InterPredRequest * npu)()
+for i, (x, y) in enumerate(pus):
+    pr[i].x0, pr[i].y0, pr[i].size = x, y, 16
+    pr[i].mv[0], pr[i].mv[1] = -12 + int(rng.integers(-3, 4)), -8 + int(rng.integers(-3, 4))
+    pr[i].out_y, pr[i].out_c = i * 256, i * 64
+d_pr = torch.frombuffer(bytearray(bytes(pr)), dtype=torch.uint8).cuda()
+pred_y = torch.zeros((npu, 16, 16), dtype=torch.uint8, device="cuda")
+pred_u = torch.zeros((npu, 8, 8), dtype=torch.uint8, device="cuda")
+pred_v = torch.zeros((npu, 8, 8), dtype=torch.uint8, device="cuda")
+# source blocks in the same packed order (a gather the host loop's staging would do once per picture)
+src_y = cur.reshape(H // 16, 16, W // 16, 16).permute(0, 2, 1, 3).contiguous().reshape(npu, 16, 16)
+src_c = torch.randint(0, 256, (2 * npu, 8, 8), dtype=torch.uint8, device="cuda")
+pred_c = torch.zeros((2 * npu, 8, 8), dtype=torch.uint8, device="cuda")
+qp_y = torch.full((npu,), 32, dtype=torch.uint8, device="cuda")
+qp_c = torch.full((2 * npu,), 31, dtype=torch.uint8, device="cuda")
+fl_y = torch.zeros(npu, dtype=torch.uint8, device="cuda")
+fl_c = torch.zeros(2 * npu, dtype=torch.uint8, device="cuda")
+lev_y = torch.zeros((npu, 16, 16), dtype=torch.int16, device="cuda")
+rec_y = torch.zeros((npu, 16, 16), dtype=torch.uint8, device="cuda")
+sum_y = torch.zeros(npu, dtype=torch.int32, device="cuda")
+lev_c = torch.zeros((2 * npu, 8, 8), dtype=torch.int16, device="cuda")
+rec_c = torch.zeros((2 * npu, 8, 8), dtype=torch.uint8, device="cuda")
+sum_c = torch.zeros(2 * npu, dtype=torch.int32, device="cuda")
+
+
+def picture(stream, surface):
+    capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, rows, stride, planes.data_ptr(), stream))
+    if surface:
+        capi.check(L.xmi_sad_surface_dev(C.byref(geom), cur.data_ptr(), ref.data_ptr() + PAD * stride + PAD, sp[0].data_ptr(), sp[1].data_ptr(),
+                                         sp[2].data_ptr(), sp[3].data_ptr(), 0, nctu, stream))
+        capi.check(L.xmi_me_search_surface_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, C.byref(geom), sp[0].data_ptr(),
+                                                     sp[1].data_ptr(), sp[2].data_ptr(), sp[3].data_ptr(), d_me.data_ptr(), nreq, 32,
+                                                     d_me_res.data_ptr(), stream))
+    else:
+        capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_me.data_ptr(), nreq, 32,
+                                             d_me_res.data_ptr(), stream))
+    capi.check(L.xmi_pred_inter_batch_dev(ref.data_ptr() + PAD * stride + PAD, stride, ref_u.data_ptr() + cpad * cstride + cpad,
+                                          ref_v.data_ptr() + cpad * cstride + cpad, cstride, d_pr.data_ptr(), npu, pred_y.data_ptr(),
+                                          pred_u.data_ptr(), pred_v.data_ptr(), stream))
+    capi.check(L.xmi_tu_chain_batch_dev(16, npu, src_y.data_ptr(), pred_y.data_ptr(), qp_y.data_ptr(), fl_y.data_ptr(), lev_y.data_ptr(),
+                                        rec_y.data_ptr(), sum_y.data_ptr(), stream))
+    # the two chroma planes: 8x8 TUs
+    capi.check(L.xmi_tu_chain_batch_dev(8, npu, src_c.data_ptr(), pred_u.data_ptr(), qp_c.data_ptr(), fl_c.data_ptr(), lev_c.data_ptr(),
+                                        rec_c.data_ptr(), sum_c.data_ptr(), stream))
+    capi.check(L.xmi_tu_chain_batch_dev(8, npu, src_c.data_ptr() + npu * 64, pred_v.data_ptr(), qp_c.data_ptr() + npu, fl_c.data_ptr() + npu,
+                                        lev_c.data_ptr() + npu * 128, rec_c.data_ptr() + npu * 64, sum_c.data_ptr() + npu * 4, stream))
+
+
+for surface in (False, True):
+    s = torch.cuda.current_stream().cuda_stream
+    picture(s, surface)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        picture(torch.cuda.current_stream().cuda_stream, surface)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 50
+    a.record()
+    for _ in range(iters):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    t_graph = a.elapsed_time(b) / iters
+    a.record()
+    for _ in range(iters):
+        picture(s, surface)
+    b.record()
+    torch.cuda.synchronize()
+    t_eager = a.elapsed_time(b) / iters
+    print(json.dumps({"pipeline": "1080p P picture: planes" + (" + SAD surface (R=64)" if surface else "") + f" + {nreq} motion searches"
+                      + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains",
+                      "ms_graph": round(t_graph, 3), "ms_eager": round(t_eager, 3), "pictures_per_s_graph": round(1e3 / t_graph, 1),
+                      "coded_levels_nonzero_tus": int((sum_y != 0).sum().item())}))
