@@ -658,3 +658,113 @@ void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw
     out->pred_idx = idx;
     out->best_cost = best;
 }
+
+/* ------------------------------------------------------------------ deblocking filter ---- */
+
+static const uint8_t k_tc_table[54] = { /* src/Deblock.cpp:195-200 */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+    5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+static const uint8_t k_beta_table[52] = { /* src/Deblock.cpp:202-207 */
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30,
+    32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+
+static uint8_t clip_pixel(int a) { return (uint8_t)(a < 0 ? 0 : a > 255 ? 255 : a); }
+
+/* src/Deblock.cpp:61-145: one 4-line segment of a luma edge. xs = step across the edge, ys = step along it. */
+static void deblock_luma_segment(uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int beta, int tc)
+{
+#define PX(i, line) ((int)pix[(i) * xs + (line) * ys])
+    const int dp0 = abs(PX(-3, 0) - 2 * PX(-2, 0) + PX(-1, 0)), dq0 = abs(PX(2, 0) - 2 * PX(1, 0) + PX(0, 0));
+    const int dp3 = abs(PX(-3, 3) - 2 * PX(-2, 3) + PX(-1, 3)), dq3 = abs(PX(2, 3) - 2 * PX(1, 3) + PX(0, 3));
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    if (abs(PX(-4, 0) - PX(-1, 0)) + abs(PX(3, 0) - PX(0, 0)) < beta_3 && abs(PX(-1, 0) - PX(0, 0)) < tc25 &&
+        abs(PX(-4, 3) - PX(-1, 3)) + abs(PX(3, 3) - PX(0, 3)) < beta_3 && abs(PX(-1, 3) - PX(0, 3)) < tc25 &&
+        (d0 << 1) < beta_2 && (d3 << 1) < beta_2) {
+        const int tc2 = tc << 1;
+        for (int d = 0; d < 4; d++, pix += ys) {
+            const int p3 = PX(-4, 0), p2 = PX(-3, 0), p1 = PX(-2, 0), p0 = PX(-1, 0), q0 = PX(0, 0), q1 = PX(1, 0), q2 = PX(2, 0), q3 = PX(3, 0);
+            pix[-1 * xs] = (uint8_t)clip3(p0 - tc2, p0 + tc2, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            pix[-2 * xs] = (uint8_t)clip3(p1 - tc2, p1 + tc2, (p2 + p1 + p0 + q0 + 2) >> 2);
+            pix[-3 * xs] = (uint8_t)clip3(p2 - tc2, p2 + tc2, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            pix[0] = (uint8_t)clip3(q0 - tc2, q0 + tc2, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            pix[xs] = (uint8_t)clip3(q1 - tc2, q1 + tc2, (p0 + q0 + q1 + q2 + 2) >> 2);
+            pix[2 * xs] = (uint8_t)clip3(q2 - tc2, q2 + tc2, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+        }
+    } else {
+        const int tc_2 = tc >> 1, side = (beta + (beta >> 1)) >> 3;
+        const int nd_p = dp0 + dp3 < side ? 2 : 1, nd_q = dq0 + dq3 < side ? 2 : 1;
+        for (int d = 0; d < 4; d++, pix += ys) {
+            const int p2 = PX(-3, 0), p1 = PX(-2, 0), p0 = PX(-1, 0), q0 = PX(0, 0), q1 = PX(1, 0), q2 = PX(2, 0);
+            int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (abs(delta0) >= 10 * tc) continue;
+            delta0 = clip3(-tc, tc, delta0);
+            pix[-1 * xs] = clip_pixel(p0 + delta0);
+            pix[0] = clip_pixel(q0 - delta0);
+            if (nd_p > 1) pix[-2 * xs] = clip_pixel(p1 + clip3(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
+            if (nd_q > 1) pix[xs] = clip_pixel(q1 + clip3(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+        }
+    }
+#undef PX
+}
+
+/* src/Deblock.cpp:147-168 */
+static void deblock_chroma_segment(uint8_t *pix, ptrdiff_t xs, ptrdiff_t ys, int tc)
+{
+    for (int d = 0; d < 4; d++, pix += ys) {
+        const int p1 = pix[-2 * xs], p0 = pix[-xs], q0 = pix[0], q1 = pix[xs];
+        const int delta0 = clip3(-tc, tc, (((q0 - p0) << 2) + p1 - q1 + 4) >> 3);
+        pix[-xs] = clip_pixel(p0 + delta0);
+        pix[0] = clip_pixel(q0 - delta0);
+    }
+}
+
+/* src/Deblock.cpp:209-234 (qp_bd_offset = 0) */
+static int deblock_chroma_tc(int qp_y, int offset, int tc_offset)
+{
+    static const int qp_c[] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+    const int qp_i = clip3(0, 57, qp_y + offset);
+    const int qp = qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : qp_c[qp_i - 30];
+    return k_tc_table[clip3(0, 53, qp + 2 + tc_offset)];
+}
+
+void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_params *p, const uint8_t *vertical_bs,
+                       const uint8_t *horizontal_bs, const uint8_t *qp_tab)
+{
+    const int W = p->width, H = p->height, bsw = W >> 3, qw = W >> 2;   /* QP table: log2_min_coding_block_size = 2 (src/encode.cpp:5060) */
+    /* CTB by CTB in raster order, vertical edges of the CTB, then its horizontal edges shifted 8 samples to the left
+     * (ff_hevc_deblocking_filter_CTB, src/Deblock.cpp:244-342; every CTB is visited once by xDeblockFrame, :524-559) */
+    for (int y0 = 0; y0 < H; y0 += 64)
+        for (int x0 = 0; x0 < W; x0 += 64) {
+            int x_end = x0 + 64 > W ? W : x0 + 64;
+            const int y_end = y0 + 64 > H ? H : y0 + 64;
+            for (int x = x0 ? x0 : 8; x < x_end; x += 8)
+                for (int yy = y0; yy < y_end; yy += 4) {
+                    const int bs = vertical_bs[(x >> 3) + (yy >> 2) * bsw];
+                    if (!bs) continue;
+                    const int qp = (qp_tab[((x - 1) >> 2) + (yy >> 2) * qw] + qp_tab[(x >> 2) + (yy >> 2) * qw] + 1) >> 1;
+                    const int beta = k_beta_table[clip3(0, 51, qp + ((p->beta_offset >> 1) << 1))];
+                    const int tc = k_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + ((p->tc_offset >> 1) << 1))];
+                    deblock_luma_segment(y + (ptrdiff_t)yy * p->stride_y + x, 1, p->stride_y, beta, tc);
+                    if ((x & 15) == 0 && (yy & 7) == 0 && bs == 2) {
+                        deblock_chroma_segment(u + (ptrdiff_t)(yy / 2) * p->stride_c + x / 2, 1, p->stride_c, deblock_chroma_tc(qp, p->cb_qp_offset, p->tc_offset));
+                        deblock_chroma_segment(v + (ptrdiff_t)(yy / 2) * p->stride_c + x / 2, 1, p->stride_c, deblock_chroma_tc(qp, p->cr_qp_offset, p->tc_offset));
+                    }
+                }
+            if (x_end != W) x_end -= 8;
+            for (int yy = y0 ? y0 : 8; yy < y_end; yy += 8)
+                for (int x = x0 ? x0 - 8 : 0; x < x_end; x += 4) {
+                    const int bs = horizontal_bs[(x + yy * bsw) >> 2];
+                    if (!bs) continue;
+                    const int qp = (qp_tab[(x >> 2) + ((yy - 1) >> 2) * qw] + qp_tab[(x >> 2) + (yy >> 2) * qw] + 1) >> 1;
+                    const int beta = k_beta_table[clip3(0, 51, qp + ((p->beta_offset >> 1) << 1))];
+                    const int tc = k_tc_table[clip3(0, 53, qp + 2 * (bs - 1) + ((p->tc_offset >> 1) << 1))];
+                    deblock_luma_segment(y + (ptrdiff_t)yy * p->stride_y + x, p->stride_y, 1, beta, tc);
+                    if ((x & 7) == 0 && (yy & 15) == 0 && bs == 2) {
+                        deblock_chroma_segment(u + (ptrdiff_t)(yy / 2) * p->stride_c + x / 2, p->stride_c, 1, deblock_chroma_tc(qp, p->cb_qp_offset, p->tc_offset));
+                        deblock_chroma_segment(v + (ptrdiff_t)(yy / 2) * p->stride_c + x / 2, p->stride_c, 1, deblock_chroma_tc(qp, p->cr_qp_offset, p->tc_offset));
+                    }
+                }
+        }
+}

@@ -145,6 +145,20 @@ typedef struct {
 void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw, int size, unsigned valids,
                       int strong_smoothing, const uint8_t mpm[3], double sqrt_lambda, orc_intra_result *out);
 
+/* In-loop deblocking of one reconstructed picture, xDeblockFrame (src/Deblock.cpp:524-559): every 64x64 CTB once in
+ * raster order through ff_hevc_deblocking_filter_CTB (:244-342) - its vertical edges, then its horizontal edges
+ * shifted 8 samples to the left - with the luma / chroma segment filters of :61-168, tc and beta tables :195-207,
+ * chroma tc :209-234. Boundary strengths (0, 1, 2) come from the CTU loop: vertical_bs[(x>>3) + (y>>2)*(width>>3)],
+ * horizontal_bs[(x + y*(width>>3)) >> 2]; qp_tab holds one QP per 4x4 block, (width>>2) per row. In place. */
+typedef struct {
+    int width, height;            /* luma picture size */
+    int stride_y, stride_c;
+    int tc_offset, beta_offset;   /* DBParams of the picture (inc/x265.h:329; the reference leaves them 0) */
+    int cb_qp_offset, cr_qp_offset;
+} orc_deblock_params;
+void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_params *p, const uint8_t *vertical_bs,
+                       const uint8_t *horizontal_bs, const uint8_t *qp_tab);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,10 @@ class OrcMEResult(C.Structure):
                 ("mvp_idx", C.c_int), ("n_int_sads", C.c_int), ("n_sub_sads", C.c_int)]
 
 
+class OrcDeblockParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "stride_y", "stride_c", "tc_offset", "beta_offset", "cb_qp_offset", "cr_qp_offset")]
+
+
 class OrcIntraResult(C.Structure):
     _fields_ = [("best_mode", C.c_int), ("pred_idx", C.c_int), ("best_cost", C.c_double), ("satd", C.c_uint32 * 35)]
 
@@ -57,6 +61,8 @@ def load():
     lib.orc_mv_component_bits.argtypes = [i]
     lib.orc_pred_inter_luma.restype = None
     lib.orc_pred_inter_luma.argtypes = [vp, vp, i, i, i, i, i]
+    lib.orc_deblock_frame.restype = None
+    lib.orc_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(OrcDeblockParams), vp, vp, vp]
     lib.orc_pred_inter_chroma.restype = None
     lib.orc_pred_inter_chroma.argtypes = [vp, vp, i, i, i, i, i]
     lib.orc_motion_search.restype = None
@@ -74,14 +80,19 @@ def load():
 
 
 def p(a):
+    """pointer to a C-contiguous array; the pointer object keeps the array alive (temporaries may be passed)"""
     assert a.flags["C_CONTIGUOUS"]
-    return C.c_void_p(a.ctypes.data)
+    ptr = C.c_void_p(a.ctypes.data)
+    ptr._keep = a
+    return ptr
 
 
 def at(a, *idx):
     """pointer to element a[idx] of a C-contiguous array"""
     off = sum(int(i) * int(s) for i, s in zip(idx, a.strides))
-    return C.c_void_p(a.ctypes.data + off)
+    ptr = C.c_void_p(a.ctypes.data + off)
+    ptr._keep = a
+    return ptr
 
 
 def sad_surface(lib, cur, ref_padded, pad, rng, pitch=None, ctu_begin=0, ctu_end=None):

@@ -241,6 +241,22 @@ def test_tu_chain_replays_encoder_trace(lib, golden_dir, n):
             np.testing.assert_array_equal(wr, rec[i], err_msg=f"chain {i}: reconstruction")
 
 
+def test_deblocking_replays_encoder_trace(lib, golden_dir):
+    """orc_deblock_frame on the pictures the reference's encoder deblocked (inputs and outputs of xDeblockFrame recorded
+    from a bit-identical QP37 encode, tests/golden/deblock_trace.npz): same planes after filtering, I and P pictures."""
+    import ctypes as C
+    g = np.load(os.path.join(golden_dir, "deblock_trace.npz"))
+    for poc in g["pocs"]:
+        w, h, slice_, tco, bo, cb, cr = (int(v) for v in g[f"p{poc}_meta"])
+        y, u, v = (g[f"p{poc}_{k}0"].copy() for k in "yuv")
+        prm = O.OrcDeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
+        vbs, hbs, qp = (np.ascontiguousarray(g[f"p{poc}_{k}"]) for k in ("vbs", "hbs", "qp"))     # kept alive across the call
+        lib.orc_deblock_frame(O.p(y), O.p(u), O.p(v), C.byref(prm), O.p(vbs), O.p(hbs), O.p(qp))
+        assert (y != g[f"p{poc}_y0"]).sum() > 1000          # the filter did something
+        for k, a in zip("yuv", (y, u, v)):
+            np.testing.assert_array_equal(a, g[f"p{poc}_{k}1"], err_msg=f"picture {poc} plane {k}")
+
+
 def test_motion_search_replays_encoder_trace(lib, golden_dir):
     """Every xMotionSearch call the reference's encoder made on three P pictures of the 416x240 QP32 clip
     (recorded by oracle/gen_me_trace.py from a bit-identical encode): the oracle returns the same MV, cost,
