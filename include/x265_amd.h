@@ -175,6 +175,25 @@ typedef struct xmi_intra_pred_request {
 } xmi_intra_pred_request;
 int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream);
 
+/* ---- in-loop deblocking -----------------------------------------------------------------------------
+ * xDeblockFrame (src/Deblock.cpp:524-559) for one reconstructed 4:2:0 picture, in place: every vertical edge on the
+ * 8-sample grid, then every horizontal edge, each 4-sample segment filtered when the boundary strength the CTU loop
+ * stored for it (ff_hevc_deblocking_boundary_strengths, src/Deblock.cpp:369) is 1 or 2; chroma on the 16-sample luma
+ * grid for strength 2. Tables as the reference keeps them: vertical_bs[(x>>3) + (y>>2)*(width>>3)],
+ * horizontal_bs[(x + y*(width>>3)) >> 2] (both (width/4)*(height/4) bytes), qp_tab one QP per 4x4 block, width/4 per
+ * row. tc_offset / beta_offset are the picture's DBParams (inc/x265.h:329), cb/cr_qp_offset the PPS offsets. */
+typedef struct xmi_deblock_params {
+    int32_t width, height;            /* luma picture size, multiples of 8 */
+    int32_t stride_y, stride_c;
+    int32_t tc_offset, beta_offset;
+    int32_t cb_qp_offset, cr_qp_offset;
+} xmi_deblock_params;
+int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_deblock_params *p, const uint8_t *d_vertical_bs,
+                          const uint8_t *d_horizontal_bs, const uint8_t *d_qp_tab, void *stream);
+/* the same with host pointers: planes and tables are copied to the device, filtered, and the planes copied back */
+int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_params *p, const uint8_t *vertical_bs,
+                      const uint8_t *horizontal_bs, const uint8_t *qp_tab);
+
 /* ---- frame session: host-pointer batch interface --------------------------------------------------
  * For a host CTU loop without device pointers of its own. The session holds one picture pair on the device (source
  * luma, padded previous reconstruction, its 16 quarter-pel planes) and stages request / result tables.

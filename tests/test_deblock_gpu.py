@@ -1,0 +1,93 @@
+"""GPU: in-loop deblocking (xmi_deblock_frame_dev / xmi_deblock_frame) against the pictures the reference's encoder
+deblocked (tests/golden/deblock_trace.npz, recorded around xDeblockFrame in a bit-identical encode) and against the
+oracle's CTB-ordered restatement on seeded pictures with every boundary strength, QP and offset."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from x265_amd import capi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = capi.load()
+    capi.check(lib.xmi_init(0))
+    return lib
+
+
+def gpu_deblock(L, y, u, v, prm, vbs, hbs, qp):
+    dy, du, dv = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (y, u, v))
+    dvb, dhb, dq = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (vbs, hbs, qp))
+    capi.check(L.xmi_deblock_frame_dev(dy.data_ptr(), du.data_ptr(), dv.data_ptr(), C.byref(prm), dvb.data_ptr(), dhb.data_ptr(), dq.data_ptr(), None))
+    torch.cuda.synchronize()
+    return dy.cpu().numpy(), du.cpu().numpy(), dv.cpu().numpy()
+
+
+def test_deblocking_replays_encoder_trace(L):
+    g = np.load(os.path.join(GOLDEN, "deblock_trace.npz"))
+    for poc in g["pocs"]:
+        w, h, slice_, tco, bo, cb, cr = (int(x) for x in g[f"p{poc}_meta"])
+        prm = capi.DeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
+        y, u, v = gpu_deblock(L, g[f"p{poc}_y0"], g[f"p{poc}_u0"], g[f"p{poc}_v0"], prm, g[f"p{poc}_vbs"], g[f"p{poc}_hbs"], g[f"p{poc}_qp"])
+        for k, a in zip("yuv", (y, u, v)):
+            np.testing.assert_array_equal(a, g[f"p{poc}_{k}1"], err_msg=f"picture {poc} plane {k}")
+        # host-pointer form on planes with the encoder's kind of strides (padding around the picture stays untouched)
+        pad = 24
+        Y = np.full((h + 2 * pad, w + 2 * pad + 4), 99, np.uint8)
+        U = np.full((h // 2 + pad, w // 2 + pad + 2), 98, np.uint8)
+        V = U.copy()
+        Y[pad:pad + h, pad:pad + w] = g[f"p{poc}_y0"]
+        U[pad // 2:pad // 2 + h // 2, pad // 2:pad // 2 + w // 2] = g[f"p{poc}_u0"]
+        V[pad // 2:pad // 2 + h // 2, pad // 2:pad // 2 + w // 2] = g[f"p{poc}_v0"]
+        prm2 = capi.DeblockParams(w, h, Y.strides[0], U.strides[0], tco, bo, cb, cr)
+        vbs, hbs, qp = (np.ascontiguousarray(g[f"p{poc}_{k}"]) for k in ("vbs", "hbs", "qp"))
+        capi.check(L.xmi_deblock_frame(O.at(Y, pad, pad), O.at(U, pad // 2, pad // 2), O.at(V, pad // 2, pad // 2), C.byref(prm2), O.p(vbs), O.p(hbs), O.p(qp)))
+        np.testing.assert_array_equal(Y[pad:pad + h, pad:pad + w], g[f"p{poc}_y1"])
+        np.testing.assert_array_equal(U[pad // 2:pad // 2 + h // 2, pad // 2:pad // 2 + w // 2], g[f"p{poc}_u1"])
+        np.testing.assert_array_equal(V[pad // 2:pad // 2 + h // 2, pad // 2:pad // 2 + w // 2], g[f"p{poc}_v1"])
+        assert (Y[:pad] == 99).all() and (Y[:, :pad] == 99).all() and (Y[:, pad + w:] == 99).all() and (U[:pad // 2] == 98).all()
+
+
+@pytest.mark.parametrize("w,h,seed", [(192, 128, 1), (448, 256, 2), (72, 40, 3), (1920, 1088, 4)])
+def test_deblocking_matches_oracle(L, w, h, seed):
+    """Seeded pictures (smooth ramps with block steps so that weak, strong and no filtering all occur), random
+    boundary strengths 0/1/2 on every segment, QP table 20..51, non-zero offsets."""
+    orc = O.load()
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 128 + 50 * np.sin(xx / 37.0) + 40 * np.cos(yy / 23.0)
+    steps = rng.integers(-12, 13, (h // 8 + 1, w // 8 + 1))
+    y = np.clip(base + np.kron(steps, np.ones((8, 8)))[:h, :w] + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8)
+    y[: h // 4] = rng.integers(0, 256, (h // 4, w), dtype=np.uint8)          # a noisy band: mostly "no filtering"
+    cs = rng.integers(-10, 11, (h // 16 + 1, w // 16 + 1))
+    u = np.clip(128 + np.kron(cs, np.ones((8, 8)))[: h // 2, : w // 2] + rng.integers(-1, 2, (h // 2, w // 2)), 0, 255).astype(np.uint8)
+    v = np.clip(100 + 2 * np.kron(cs, np.ones((8, 8)))[: h // 2, : w // 2] + rng.integers(-3, 4, (h // 2, w // 2)), 0, 255).astype(np.uint8)
+    tab = (w // 4) * (h // 4)
+    vbs = rng.choice([0, 1, 2], tab, p=[0.3, 0.35, 0.35]).astype(np.uint8)
+    hbs = rng.choice([0, 1, 2], tab, p=[0.3, 0.35, 0.35]).astype(np.uint8)
+    qp = rng.integers(20, 52, (h // 4, w // 4)).astype(np.uint8)
+    tco, bo, cb, cr = int(rng.integers(-6, 7)), int(rng.integers(-6, 7)), int(rng.integers(-4, 5)), int(rng.integers(-4, 5))
+    wy, wu, wv = y.copy(), u.copy(), v.copy()
+    oprm = O.OrcDeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
+    orc.orc_deblock_frame(O.p(wy), O.p(wu), O.p(wv), C.byref(oprm), O.p(vbs), O.p(hbs), O.p(qp))
+    assert (wy != y).sum() > w * h // 50 and (wu != u).sum() > 0
+    prm = capi.DeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
+    gy, gu, gv = gpu_deblock(L, y, u, v, prm, vbs, hbs, qp)
+    np.testing.assert_array_equal(gy, wy)
+    np.testing.assert_array_equal(gu, wu)
+    np.testing.assert_array_equal(gv, wv)
+
+
+def test_deblocking_errors(L):
+    a = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    bad = capi.DeblockParams(20, 16, 20, 10, 0, 0, 0, 0)
+    assert L.xmi_deblock_frame_dev(a.data_ptr(), a.data_ptr(), a.data_ptr(), C.byref(bad), a.data_ptr(), a.data_ptr(), a.data_ptr(), None) == -1
+    ok = capi.DeblockParams(16, 16, 16, 8, 0, 0, 0, 0)
+    assert L.xmi_deblock_frame_dev(None, a.data_ptr(), a.data_ptr(), C.byref(ok), a.data_ptr(), a.data_ptr(), a.data_ptr(), None) == -1

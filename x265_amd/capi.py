@@ -42,6 +42,10 @@ class IntraResult(C.Structure):
                 ("satd", C.c_uint32 * 35), ("reserved", C.c_uint32)]
 
 
+class DeblockParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "stride_y", "stride_c", "tc_offset", "beta_offset", "cb_qp_offset", "cr_qp_offset")]
+
+
 class InterPredRequest(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_int32), ("mv", C.c_int16 * 2),
                 ("out_y", C.c_uint32), ("out_c", C.c_uint32)]
@@ -104,6 +108,11 @@ def load():
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.xmi_intra_search.restype = i
         L.xmi_intra_search.argtypes = [vp, C.c_uint32, vp, C.POINTER(IntraRequest), C.POINTER(IntraResult)]
+    if hasattr(L, "xmi_deblock_frame_dev"):
+        L.xmi_deblock_frame_dev.restype = i
+        L.xmi_deblock_frame_dev.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp, vp]
+        L.xmi_deblock_frame.restype = i
+        L.xmi_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp]
     if hasattr(L, "xmi_pred_inter_batch_dev"):
         L.xmi_pred_inter_batch_dev.restype = i
         L.xmi_pred_inter_batch_dev.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp]

@@ -1,0 +1,240 @@
+// In-loop deblocking filter of one reconstructed picture for gfx950: xDeblockFrame (src/Deblock.cpp:524-559).
+//
+// The reference walks the CTBs in raster order and filters, per CTB, its vertical edges and then its horizontal edges
+// shifted 8 samples to the left (ff_hevc_deblocking_filter_CTB, src/Deblock.cpp:244-342) - an arrangement whose
+// result is that of filtering every vertical edge of the picture first and every horizontal edge afterwards, because
+// an edge segment only modifies 3 samples on either side and reads 4. That is what runs here, as two kernels:
+//   vertical edges:   one thread per (edge x = 8, 16, .., 4-row segment): 4 rows x 8 samples as two dwords per row
+//   horizontal edges: one thread per (4-column segment, edge y = 8, 16, ..): 8 rows x one dword
+// Every dword a thread rewrites belongs to its own segment, so the planes are filtered in place without atomics.
+// Decisions and arithmetic are the reference's (hevc_loop_filter_luma :61-145, hevc_loop_filter_chroma :147-168, tables
+// :195-207, chroma tc :209-234): a segment is filtered when the boundary strength the CTU loop stored for it is
+// non-zero; chroma (4:2:0) only on the 16-sample luma grid and only for strength 2.
+#include "xmi_common.h"
+
+namespace {
+
+typedef unsigned int u32;
+
+__constant__ uint8_t k_tc[54] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+                                  5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24 };
+__constant__ uint8_t k_beta[52] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26,
+                                    28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64 };
+__constant__ uint8_t k_qpc[14] = { 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37 };
+
+struct DbParams {
+    uint8_t *y, *u, *v;
+    const uint8_t *vbs, *hbs, *qp;
+    int width, height, stride_y, stride_c, tc_offset, beta_offset, cb_qp_offset, cr_qp_offset;
+};
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(hi, max(lo, v)); }
+__device__ __forceinline__ int clip8(int v) { return min(255, max(0, v)); }
+
+// one luma segment: s[line][position], position 0..7 = P3 P2 P1 P0 Q0 Q1 Q2 Q3; decisions from lines 0 and 3
+__device__ __forceinline__ void filter_luma(int (&s)[4][8], int beta, int tc)
+{
+    const int dp0 = abs(s[0][1] - 2 * s[0][2] + s[0][3]), dq0 = abs(s[0][6] - 2 * s[0][5] + s[0][4]);
+    const int dp3 = abs(s[3][1] - 2 * s[3][2] + s[3][3]), dq3 = abs(s[3][6] - 2 * s[3][5] + s[3][4]);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+    if (d0 + d3 >= beta) return;
+    const int beta_3 = beta >> 3, beta_2 = beta >> 2, tc25 = (tc * 5 + 1) >> 1;
+    const bool strong = abs(s[0][0] - s[0][3]) + abs(s[0][7] - s[0][4]) < beta_3 && abs(s[0][3] - s[0][4]) < tc25 &&
+                        abs(s[3][0] - s[3][3]) + abs(s[3][7] - s[3][4]) < beta_3 && abs(s[3][3] - s[3][4]) < tc25 &&
+                        (d0 << 1) < beta_2 && (d3 << 1) < beta_2;
+    if (strong) {
+        const int tc2 = tc << 1;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int p3 = s[d][0], p2 = s[d][1], p1 = s[d][2], p0 = s[d][3], q0 = s[d][4], q1 = s[d][5], q2 = s[d][6], q3 = s[d][7];
+            s[d][3] = clip3(p0 - tc2, p0 + tc2, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            s[d][2] = clip3(p1 - tc2, p1 + tc2, (p2 + p1 + p0 + q0 + 2) >> 2);
+            s[d][1] = clip3(p2 - tc2, p2 + tc2, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            s[d][4] = clip3(q0 - tc2, q0 + tc2, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            s[d][5] = clip3(q1 - tc2, q1 + tc2, (p0 + q0 + q1 + q2 + 2) >> 2);
+            s[d][6] = clip3(q2 - tc2, q2 + tc2, (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+        }
+    } else {
+        const int tc_2 = tc >> 1, side = (beta + (beta >> 1)) >> 3;
+        const bool two_p = dp0 + dp3 < side, two_q = dq0 + dq3 < side;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const int p2 = s[d][1], p1 = s[d][2], p0 = s[d][3], q0 = s[d][4], q1 = s[d][5], q2 = s[d][6];
+            int delta0 = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (abs(delta0) < 10 * tc) {
+                delta0 = clip3(-tc, tc, delta0);
+                s[d][3] = clip8(p0 + delta0);
+                s[d][4] = clip8(q0 - delta0);
+                if (two_p) s[d][2] = clip8(p1 + clip3(-tc_2, tc_2, (((p2 + p0 + 1) >> 1) - p1 + delta0) >> 1));
+                if (two_q) s[d][5] = clip8(q1 + clip3(-tc_2, tc_2, (((q2 + q0 + 1) >> 1) - q1 - delta0) >> 1));
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int chroma_tc(int qp_y, int offset, int tc_offset)
+{
+    const int qp_i = clip3(0, 57, qp_y + offset);
+    const int qp = qp_i < 30 ? qp_i : qp_i > 43 ? qp_i - 6 : (int)k_qpc[qp_i - 30];
+    return k_tc[clip3(0, 53, qp + 2 + tc_offset)];
+}
+
+// chroma: p1 p0 | q0 q1 of one line -> new p0, q0
+__device__ __forceinline__ void filter_chroma(int p1, int &p0, int &q0, int q1, int tc)
+{
+    const int delta0 = clip3(-tc, tc, (((q0 - p0) << 2) + p1 - q1 + 4) >> 3);
+    p0 = clip8(p0 + delta0);
+    q0 = clip8(q0 - delta0);
+}
+
+__device__ __forceinline__ void edge_strengths(const DbParams &p, int bs, int qp, int &beta, int &tc)
+{
+    beta = k_beta[clip3(0, 51, qp + ((p.beta_offset >> 1) << 1))];
+    tc = k_tc[clip3(0, 53, qp + 2 * (bs - 1) + ((p.tc_offset >> 1) << 1))];
+}
+
+__global__ void __launch_bounds__(256) deblock_vertical_kernel(const DbParams p)
+{
+    const int ex = blockIdx.x * 64 + (threadIdx.x & 63) + 1, sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = 8 * ex, y = 4 * sy;
+    if (x >= p.width || y >= p.height) return;
+    const int bs = p.vbs[ex + sy * (p.width >> 3)];
+    if (!bs) return;
+    const int qw = p.width >> 2;
+    const int qp = (p.qp[((x - 1) >> 2) + (y >> 2) * qw] + p.qp[(x >> 2) + (y >> 2) * qw] + 1) >> 1;
+    int beta, tc;
+    edge_strengths(p, bs, qp, beta, tc);
+    uint8_t *row = p.y + (size_t)y * p.stride_y + x - 4;
+    int s[4][8];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(row + (size_t)d * p.stride_y);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            s[d][i] = (w.x >> (8 * i)) & 255;
+            s[d][4 + i] = (w.y >> (8 * i)) & 255;
+        }
+    }
+    filter_luma(s, beta, tc);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint2 w;
+        w.x = (u32)s[d][0] | ((u32)s[d][1] << 8) | ((u32)s[d][2] << 16) | ((u32)s[d][3] << 24);
+        w.y = (u32)s[d][4] | ((u32)s[d][5] << 8) | ((u32)s[d][6] << 16) | ((u32)s[d][7] << 24);
+        *reinterpret_cast<uint2 *>(row + (size_t)d * p.stride_y) = w;
+    }
+    if ((x & 15) == 0 && (y & 7) == 0 && bs == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int tcc = chroma_tc(qp, c ? p.cr_qp_offset : p.cb_qp_offset, p.tc_offset);
+            uint8_t *pl = (c ? p.v : p.u) + (size_t)(y >> 1) * p.stride_c + (x >> 1);
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint8_t *q = pl + (size_t)d * p.stride_c;
+                int p0 = q[-1], q0 = q[0];
+                filter_chroma(q[-2], p0, q0, q[1], tcc);
+                q[-1] = (uint8_t)p0;
+                q[0] = (uint8_t)q0;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) deblock_horizontal_kernel(const DbParams p)
+{
+    const int x4 = blockIdx.x * 64 + (threadIdx.x & 63), ey = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+    const int x = 4 * x4, y = 8 * ey;
+    if (x >= p.width || y >= p.height) return;
+    const int bs = p.hbs[(x + y * (p.width >> 3)) >> 2];
+    if (!bs) return;
+    const int qw = p.width >> 2;
+    const int qp = (p.qp[(x >> 2) + ((y - 1) >> 2) * qw] + p.qp[(x >> 2) + (y >> 2) * qw] + 1) >> 1;
+    int beta, tc;
+    edge_strengths(p, bs, qp, beta, tc);
+    uint8_t *col = p.y + (size_t)(y - 4) * p.stride_y + x;
+    int s[4][8];      // line = column of the segment, position = row across the edge
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 w = *reinterpret_cast<const u32 *>(col + (size_t)i * p.stride_y);
+#pragma unroll
+        for (int d = 0; d < 4; d++) s[d][i] = (w >> (8 * d)) & 255;
+    }
+    filter_luma(s, beta, tc);
+#pragma unroll
+    for (int i = 1; i < 7; i++)
+        *reinterpret_cast<u32 *>(col + (size_t)i * p.stride_y) = (u32)s[0][i] | ((u32)s[1][i] << 8) | ((u32)s[2][i] << 16) | ((u32)s[3][i] << 24);
+    if ((x & 7) == 0 && (y & 15) == 0 && bs == 2) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int tcc = chroma_tc(qp, c ? p.cr_qp_offset : p.cb_qp_offset, p.tc_offset);
+            uint8_t *pl = (c ? p.v : p.u) + (size_t)(y >> 1) * p.stride_c + (x >> 1);
+            const ptrdiff_t st = p.stride_c;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                int p0 = pl[d - st], q0 = pl[d];
+                filter_chroma(pl[d - 2 * st], p0, q0, pl[d + st], tcc);
+                pl[d - st] = (uint8_t)p0;
+                pl[d] = (uint8_t)q0;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_deblock_params *prm, const uint8_t *d_vertical_bs,
+                          const uint8_t *d_horizontal_bs, const uint8_t *d_qp_tab, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(d_y && d_u && d_v && prm && d_vertical_bs && d_horizontal_bs && d_qp_tab, "xmi_deblock_frame_dev: null argument");
+    XMI_ARG(prm->width >= 16 && prm->height >= 16 && prm->width % 8 == 0 && prm->height % 8 == 0,
+            "xmi_deblock_frame_dev: picture %dx%d must be a multiple of 8, at least 16x16", prm->width, prm->height);
+    XMI_ARG(prm->stride_y >= prm->width && prm->stride_y % 4 == 0 && ((uintptr_t)d_y & 3) == 0 && prm->stride_c >= prm->width / 2,
+            "xmi_deblock_frame_dev: luma plane and stride (%d) must be 4-byte aligned, strides must cover the picture", prm->stride_y);
+    DbParams p = { d_y, d_u, d_v, d_vertical_bs, d_horizontal_bs, d_qp_tab, prm->width, prm->height, prm->stride_y, prm->stride_c,
+                   prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset };
+    hipStream_t st = xmi::as_stream(stream);
+    const int nev = prm->width / 8 - 1, nsv = prm->height / 4;      // vertical edges x segments
+    hipLaunchKernelGGL(deblock_vertical_kernel, dim3((nev + 63) / 64, (nsv + 3) / 4), dim3(256), 0, st, p);
+    const int nsh = prm->width / 4, neh = prm->height / 8 - 1;      // segments x horizontal edges
+    hipLaunchKernelGGL(deblock_horizontal_kernel, dim3((nsh + 63) / 64, (neh + 3) / 4), dim3(256), 0, st, p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_params *prm, const uint8_t *vertical_bs,
+                      const uint8_t *horizontal_bs, const uint8_t *qp_tab)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(y && u && v && prm && vertical_bs && horizontal_bs && qp_tab, "xmi_deblock_frame: null argument");
+    XMI_ARG(prm->width >= 16 && prm->height >= 16 && prm->width % 8 == 0 && prm->height % 8 == 0 && prm->stride_y >= prm->width &&
+                prm->stride_c >= prm->width / 2,
+            "xmi_deblock_frame: bad geometry %dx%d, strides %d / %d", prm->width, prm->height, prm->stride_y, prm->stride_c);
+    const size_t w = (size_t)prm->width, h = (size_t)prm->height, tab = (w / 4) * (h / 4);
+    const size_t sy = (w + 3) & ~(size_t)3, sc = w / 2;
+    const size_t off_u = sy * h, off_v = off_u + sc * (h / 2), off_vbs = (off_v + sc * (h / 2) + 15) & ~(size_t)15;
+    const size_t off_hbs = off_vbs + tab, off_qp = off_hbs + tab, total = off_qp + tab;
+    uint8_t *d = static_cast<uint8_t *>(xmi::scratch(10, total));
+    if (!d) return XMI_ERR_HIP;
+    XMI_HIP(hipMemcpy2D(d, sy, y, (size_t)prm->stride_y, w, h, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy2D(d + off_u, sc, u, (size_t)prm->stride_c, w / 2, h / 2, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy2D(d + off_v, sc, v, (size_t)prm->stride_c, w / 2, h / 2, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_vbs, vertical_bs, tab, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_hbs, horizontal_bs, tab, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_qp, qp_tab, tab, hipMemcpyHostToDevice));
+    xmi_deblock_params dp = *prm;
+    dp.stride_y = (int)sy;
+    dp.stride_c = (int)sc;
+    rc = xmi_deblock_frame_dev(d, d + off_u, d + off_v, &dp, d + off_vbs, d + off_hbs, d + off_qp, nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy2D(y, (size_t)prm->stride_y, d, sy, w, h, hipMemcpyDeviceToHost));
+    XMI_HIP(hipMemcpy2D(u, (size_t)prm->stride_c, d + off_u, sc, w / 2, h / 2, hipMemcpyDeviceToHost));
+    XMI_HIP(hipMemcpy2D(v, (size_t)prm->stride_c, d + off_v, sc, w / 2, h / 2, hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
+
+}  // extern "C"

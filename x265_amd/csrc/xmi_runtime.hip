@@ -9,7 +9,7 @@ namespace xmi {
 static thread_local char g_err[512] = "";
 static std::mutex g_mu;
 static int g_device = -1;
-static constexpr int kSlots = 10;
+static constexpr int kSlots = 12;
 static void *g_scratch[kSlots] = {};
 static size_t g_scratch_bytes[kSlots] = {};
 
