@@ -173,3 +173,20 @@ for n in (4, 8, 16, 32):
                                                                d_res.data_ptr(), s)), iters=5)
     print(json.dumps({"kernel": f"intra_search {n}x{n}", "requests": nreq, "ms": round(t * 1e3, 3),
                       "Msearch_per_s": round(nreq / t / 1e6, 2), "Gpixel_modes_per_s": round(nreq * n * n * 35 / t / 1e9, 1)}))
+
+# ---- in-loop deblocking of a 1080p picture: strengths as an I picture has them (2 on the 8x8 transform grid) and as a
+# P picture has them (1 on a third of the segments) ----
+for label, dens, val in (("I picture, strength 2 on every edge segment", 1.0, 2), ("P picture, strength 1 on a third of the segments", 0.33, 1)):
+    yp = torch.from_numpy(f1).cuda().clone()
+    up = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g)
+    vp = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g)
+    tab = (W // 4) * (H // 4)
+    vb = ((torch.rand(tab, device="cuda", generator=g) < dens) * val).to(torch.uint8)
+    hb = ((torch.rand(tab, device="cuda", generator=g) < dens) * val).to(torch.uint8)
+    qpt = torch.full((tab,), 32, dtype=torch.uint8, device="cuda")
+    prm = capi.DeblockParams(W, H, W, W // 2, 0, 0, 0, 0)
+    t = timeit(lambda: capi.check(L.xmi_deblock_frame_dev(yp.data_ptr(), up.data_ptr(), vp.data_ptr(), C.byref(prm), vb.data_ptr(), hb.data_ptr(),
+                                                          qpt.data_ptr(), s)))
+    by = 2 * (W * H * 3 // 2) + 3 * tab
+    print(json.dumps({"kernel": f"deblock 1080p ({label})", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
+                      "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
