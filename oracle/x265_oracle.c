@@ -768,3 +768,49 @@ void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_par
                 }
         }
 }
+
+/* ------------------------------------------------------------------ SAO statistics ---- */
+
+static int sao_sign(int x) { return (x > 0) - (x < 0); }
+
+void orc_sao_stats_ctu(const uint8_t *rec, int rec_stride, const uint8_t *org, int org_stride, int pic_w, int pic_h,
+                       int ctu_x, int ctu_y, int ctu_size, int is_chroma, int64_t count[5][33], int64_t offset_org[5][33])
+{
+    static const int eo_table[5] = { 1, 2, 0, 3, 4 };      /* g_eoTable, src/encode.cpp:274 */
+    const int skip = is_chroma ? 2 : 4, skip_right = is_chroma ? 3 : 5;
+    const int lpelx = ctu_x * ctu_size, tpely = ctu_y * ctu_size;
+    const int rpelx = lpelx + ctu_size > pic_w ? pic_w : lpelx + ctu_size, bpely = tpely + ctu_size > pic_h ? pic_h : tpely + ctu_size;
+    const int lw = rpelx - lpelx, lh = bpely - tpely;
+    const int at_right = rpelx == pic_w, at_bottom = bpely == pic_h;
+    rec += (ptrdiff_t)tpely * rec_stride + lpelx;
+    org += (ptrdiff_t)tpely * org_stride + lpelx;
+    memset(count, 0, sizeof(int64_t) * 5 * 33);
+    memset(offset_org, 0, sizeof(int64_t) * 5 * 33);
+#define REC(x, y) ((int)rec[(ptrdiff_t)(y) * rec_stride + (x)])
+#define ADD(type, cls, x, y) (offset_org[type][cls] += (int)org[(ptrdiff_t)(y) * org_stride + (x)] - REC(x, y), count[type][cls]++)
+    /* band offset (src/encode.cpp:415-438): class = 1 + (sample >> 3) */
+    for (int y = 0; y < (at_bottom ? lh : lh - skip); y++)
+        for (int x = 0; x < (at_right ? lw : lw - skip_right); x++) ADD(4, 1 + (REC(x, y) >> 3), x, y);
+    const int sx = lpelx == 0 ? 1 : 0, sy = tpely == 0 ? 1 : 0;
+    const int ex_in = at_right ? lw - 1 : lw - skip_right;           /* EO_0, EO_2, EO_3 */
+    const int ex_v = at_right ? lw : lw - skip_right;                /* EO_1 */
+    const int ey = at_bottom ? lh - 1 : lh - skip;
+    /* EO_0, horizontal neighbours (:456-480): rows 0 .. lh - skip even in the last CTU row */
+    for (int y = 0; y < lh - skip; y++)
+        for (int x = sx; x < ex_in; x++)
+            ADD(0, eo_table[sao_sign(REC(x, y) - REC(x - 1, y)) + sao_sign(REC(x, y) - REC(x + 1, y)) + 2], x, y);
+    /* EO_1, vertical neighbours (:489-524) */
+    for (int y = sy; y < ey; y++)
+        for (int x = 0; x < ex_v; x++)
+            ADD(1, eo_table[sao_sign(REC(x, y) - REC(x, y - 1)) + sao_sign(REC(x, y) - REC(x, y + 1)) + 2], x, y);
+    /* EO_2, up-left / down-right (:532-574) */
+    for (int y = sy; y < ey; y++)
+        for (int x = sx; x < ex_in; x++)
+            ADD(2, eo_table[sao_sign(REC(x, y) - REC(x - 1, y - 1)) + sao_sign(REC(x, y) - REC(x + 1, y + 1)) + 2], x, y);
+    /* EO_3, up-right / down-left (:582-620) */
+    for (int y = sy; y < ey; y++)
+        for (int x = sx; x < ex_in; x++)
+            ADD(3, eo_table[sao_sign(REC(x, y) - REC(x + 1, y - 1)) + sao_sign(REC(x, y) - REC(x - 1, y + 1)) + 2], x, y);
+#undef ADD
+#undef REC
+}

@@ -159,6 +159,15 @@ typedef struct {
 void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_params *p, const uint8_t *vertical_bs,
                        const uint8_t *horizontal_bs, const uint8_t *qp_tab);
 
+/* calcSaoStatsCu (src/encode.cpp:364-622) for one CTU of one component plane: per SAO type (0..3 = edge offset
+ * classes EO_0..EO_3, 4 = band offset) and category, the number of samples and the sum of (original - reconstructed)
+ * over the CTU's window: the bottom 4 (chroma 2) rows and the right 5 (chroma 3) columns are left out unless the CTU
+ * touches that picture border, edge classes also skip the picture's first / last row or column where a neighbour is
+ * missing (EO_0 leaves the bottom rows out even in the last CTU row). rec / org point at the plane's sample (0,0);
+ * pic_w, pic_h and ctu_size are in samples of that plane (chroma: halved). */
+void orc_sao_stats_ctu(const uint8_t *rec, int rec_stride, const uint8_t *org, int org_stride, int pic_w, int pic_h,
+                       int ctu_x, int ctu_y, int ctu_size, int is_chroma, int64_t count[5][33], int64_t offset_org[5][33]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ def load():
     lib.orc_mv_component_bits.argtypes = [i]
     lib.orc_pred_inter_luma.restype = None
     lib.orc_pred_inter_luma.argtypes = [vp, vp, i, i, i, i, i]
+    lib.orc_sao_stats_ctu.restype = None
+    lib.orc_sao_stats_ctu.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, vp]
     lib.orc_deblock_frame.restype = None
     lib.orc_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(OrcDeblockParams), vp, vp, vp]
     lib.orc_pred_inter_chroma.restype = None

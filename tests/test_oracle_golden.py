@@ -257,6 +257,22 @@ def test_deblocking_replays_encoder_trace(lib, golden_dir):
             np.testing.assert_array_equal(a, g[f"p{poc}_{k}1"], err_msg=f"picture {poc} plane {k}")
 
 
+def test_sao_statistics_replay_encoder_trace(lib, golden_dir):
+    """orc_sao_stats_ctu on the deblocked pictures of a real encode (tests/golden/sao_trace.npz, recorded around
+    calcSaoStatsCu): the count and offset tables of every CTU and component, I and P picture."""
+    g = np.load(os.path.join(golden_dir, "sao_trace.npz"))
+    for poc in g["pocs"]:
+        rec = [np.ascontiguousarray(g[f"p{poc}_rec_{k}"]) for k in "yuv"]
+        org = [np.ascontiguousarray(g[f"p{poc}_org_{k}"]) for k in "yuv"]
+        for (cx, cy, comp), want_c, want_o in zip(g[f"p{poc}_ctu"], g[f"p{poc}_count"], g[f"p{poc}_offset"]):
+            r, o = rec[comp], org[comp]
+            cnt, off = np.zeros((5, 33), np.int64), np.zeros((5, 33), np.int64)
+            lib.orc_sao_stats_ctu(O.p(r), r.strides[0], O.p(o), o.strides[0], r.shape[1], r.shape[0], int(cx), int(cy),
+                                  64 if comp == 0 else 32, int(comp != 0), O.p(cnt), O.p(off))
+            np.testing.assert_array_equal(cnt, want_c, err_msg=f"picture {poc} CTU ({cx},{cy}) component {comp}: counts")
+            np.testing.assert_array_equal(off, want_o, err_msg=f"picture {poc} CTU ({cx},{cy}) component {comp}: offsets")
+
+
 def test_motion_search_replays_encoder_trace(lib, golden_dir):
     """Every xMotionSearch call the reference's encoder made on three P pictures of the 416x240 QP32 clip
     (recorded by oracle/gen_me_trace.py from a bit-identical encode): the oracle returns the same MV, cost,
