@@ -194,6 +194,26 @@ int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_de
 int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_params *p, const uint8_t *vertical_bs,
                       const uint8_t *horizontal_bs, const uint8_t *qp_tab);
 
+/* ---- SAO statistics -----------------------------------------------------------------------------------
+ * calcSaoStatsCu (src/encode.cpp:364-622) for every 64x64 CTU and component of a deblocked 4:2:0 picture in one launch:
+ * stats[ctu * 3 + component] holds, per SAO type (0..3 = edge classes EO_0..EO_3, 4 = band offset) and category, the
+ * number of samples and the sum of (source - reconstruction) - what the reference leaves in h->m_count[component] and
+ * h->m_offsetOrg[component] (inc/x265.h:545) after the call for that CTU, with its windows (bottom 4 / 2 rows and right
+ * 5 / 3 columns left out inside the picture, picture-border samples without a neighbour left out of the edge classes). */
+typedef struct xmi_sao_stats {
+    int32_t count[5][33];
+    int32_t offset_org[5][33];
+} xmi_sao_stats;
+typedef struct xmi_sao_geom {
+    int32_t width, height;                       /* luma picture size (even) */
+    int32_t rec_stride_y, rec_stride_c, org_stride_y, org_stride_c;
+} xmi_sao_geom;
+int xmi_sao_stats_dev(const xmi_sao_geom *g, const uint8_t *d_rec_y, const uint8_t *d_rec_u, const uint8_t *d_rec_v,
+                      const uint8_t *d_org_y, const uint8_t *d_org_u, const uint8_t *d_org_v, xmi_sao_stats *d_stats, void *stream);
+/* the same with host pointers (planes are copied to the device, the tables copied back) */
+int xmi_sao_stats_frame(const xmi_sao_geom *g, const uint8_t *rec_y, const uint8_t *rec_u, const uint8_t *rec_v, const uint8_t *org_y,
+                  const uint8_t *org_u, const uint8_t *org_v, xmi_sao_stats *stats);
+
 /* ---- frame session: host-pointer batch interface --------------------------------------------------
  * For a host CTU loop without device pointers of its own. The session holds one picture pair on the device (source
  * luma, padded previous reconstruction, its 16 quarter-pel planes) and stages request / result tables.

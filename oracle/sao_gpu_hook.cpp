@@ -1,0 +1,52 @@
+// sao_gpu_hook.cpp - TEST INFRASTRUCTURE: the reference's encoder with its SAO statistics gathered by the GPU.
+//
+// calcSaoStatsCu (src/encode.cpp:364) is called per CTU and component through the PLT of the position-independent
+// build, always on the deblocked picture and before any offset is applied. At the first call of a picture this
+// definition has the GPU gather the tables of every CTU and component (xmi_sao_stats_frame); every call then copies
+// its CTU's tables into h->m_count[partIdx] / h->m_offsetOrg[partIdx] (the caller zeroed them, src/encode.cpp:1417).
+// The original is never called. The SAO parameters decided from the tables are coded into the stream and shape the
+// reconstruction, so an identical bitstream means identical tables wherever they matter.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "x265.h"
+#include "../include/x265_amd.h"
+
+namespace {
+int g_poc = -1;
+unsigned long g_pictures = 0;
+std::vector<xmi_sao_stats> g_stats;
+void report() { fprintf(stderr, "sao_gpu_hook: SAO statistics of %lu pictures gathered on the GPU\n", g_pictures); }
+}  // namespace
+
+void calcSaoStatsCu(X265_t *h, UInt32 uiX, UInt32 uiY, int partIdx, int yCbCr)
+{
+    static bool once = false;
+    if (!once) {
+        once = true;
+        if (xmi_init(0) != 0) {
+            fprintf(stderr, "sao_gpu_hook: %s\n", xmi_last_error());
+            abort();
+        }
+        atexit(report);
+    }
+    const int wc = (h->iWidth + 63) / 64, hc = (h->iHeight + 63) / 64;
+    if (h->iPoc != g_poc) {
+        g_poc = h->iPoc;
+        g_stats.resize((size_t)wc * hc * 3);
+        const xFrame *r = h->pFrameRec, *o = h->pFrameCur;
+        const xmi_sao_geom g = { h->iWidth, h->iHeight, r->iStrideY, r->iStrideC, o->iStrideY, o->iStrideC };
+        if (xmi_sao_stats_frame(&g, r->pucY, r->pucU, r->pucV, o->pucY, o->pucU, o->pucV, g_stats.data()) != 0) {
+            fprintf(stderr, "sao_gpu_hook: %s\n", xmi_last_error());
+            abort();
+        }
+        g_pictures++;
+    }
+    const xmi_sao_stats &s = g_stats[((size_t)uiY * wc + uiX) * 3 + yCbCr];
+    for (int t = 0; t < MAX_NUM_SAO_TYPE; t++)
+        for (int c = 0; c < MAX_NUM_SAO_CLASS; c++) {
+            h->m_count[partIdx][t][c] = s.count[t][c];
+            h->m_offsetOrg[partIdx][t][c] = s.offset_org[t][c];
+        }
+}

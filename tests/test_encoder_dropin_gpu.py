@@ -82,6 +82,20 @@ def test_bitstream_identical_with_gpu_deblocking(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_sao")), reason="GPU-SAO encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_sao_statistics(tmp_path, qp, frames):
+    """The reference's encoder with calcSaoStatsCu served from one GPU launch per picture (oracle/sao_gpu_hook.cpp; the
+    original is never called): the SAO parameters decided from the tables are coded into the stream and shape the
+    reconstruction, so the recorded bitstream means identical tables."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_sao", yuv, str(tmp_path / "s.265"), w, h, frames, qp)
+    assert got == (want["md5"], want["bytes"])
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_intra")), reason="GPU-intra encoder not built (make -C oracle trace)")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_intra_search(tmp_path, qp, frames):

@@ -1,0 +1,87 @@
+"""GPU: SAO statistics (xmi_sao_stats_dev / xmi_sao_stats_frame) against the tables the reference's encoder gathered
+(tests/golden/sao_trace.npz, recorded around calcSaoStatsCu in a bit-identical encode) and against the oracle on seeded
+pictures whose size is not a multiple of the CTU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from x265_amd import capi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = capi.load()
+    capi.check(lib.xmi_init(0))
+    return lib
+
+
+def gpu_stats(L, rec, org):
+    h, w = rec[0].shape
+    nctu = ((w + 63) // 64) * ((h + 63) // 64)
+    d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in rec + org]
+    out = torch.zeros(nctu * 3 * C.sizeof(capi.SaoStats), dtype=torch.uint8, device="cuda")
+    g = capi.SaoGeom(w, h, w, w // 2, w, w // 2)
+    capi.check(L.xmi_sao_stats_dev(C.byref(g), *[t.data_ptr() for t in d], out.data_ptr(), None))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.int32).reshape(nctu, 3, 2, 5, 33)
+
+
+def test_sao_statistics_replay_encoder_trace(L):
+    g = np.load(os.path.join(GOLDEN, "sao_trace.npz"))
+    for poc in g["pocs"]:
+        rec = [g[f"p{poc}_rec_{k}"] for k in "yuv"]
+        org = [g[f"p{poc}_org_{k}"] for k in "yuv"]
+        got = gpu_stats(L, rec, org)
+        wc = (rec[0].shape[1] + 63) // 64
+        for (cx, cy, comp), want_c, want_o in zip(g[f"p{poc}_ctu"], g[f"p{poc}_count"], g[f"p{poc}_offset"]):
+            np.testing.assert_array_equal(got[cy * wc + cx, comp, 0], want_c, err_msg=f"picture {poc} CTU ({cx},{cy}) component {comp}: counts")
+            np.testing.assert_array_equal(got[cy * wc + cx, comp, 1], want_o, err_msg=f"picture {poc} CTU ({cx},{cy}) component {comp}: offsets")
+        # host-pointer form on strided planes
+        h, w = rec[0].shape
+        Y = np.zeros((h, w + 32), np.uint8)
+        Y[:, :w] = rec[0]
+        geom = capi.SaoGeom(w, h, Y.strides[0], w // 2, w, w // 2)
+        planes = [np.ascontiguousarray(a) for a in (rec[1], rec[2], org[0], org[1], org[2])]
+        nctu = wc * ((h + 63) // 64)
+        res = (capi.SaoStats * (nctu * 3))()
+        capi.check(L.xmi_sao_stats_frame(C.byref(geom), O.p(Y), *[O.p(a) for a in planes], res))
+        assert bytes(res) == got.tobytes()
+
+
+@pytest.mark.parametrize("w,h,seed", [(200, 136, 1), (448, 256, 2), (1920, 1080, 3)])
+def test_sao_statistics_match_oracle(L, w, h, seed):
+    orc = O.load()
+    rng = np.random.default_rng(seed)
+    org = [rng.integers(0, 256, (h >> c, w >> c), dtype=np.uint8) for c in (0, 1, 1)]
+    rec = [np.clip(o.astype(int) + rng.integers(-9, 10, o.shape), 0, 255).astype(np.uint8) for o in org]
+    rec[0][: h // 3] = (rec[0][: h // 3] // 16) * 16          # flat steps: many ties in the edge classes
+    got = gpu_stats(L, rec, org)
+    wc, hc = (w + 63) // 64, (h + 63) // 64
+    ctus = [(x, y) for y in range(hc) for x in range(wc)]
+    if len(ctus) > 40:          # corners, borders and a sample of the interior
+        keep = {(0, 0), (wc - 1, 0), (0, hc - 1), (wc - 1, hc - 1), (wc // 2, 0), (0, hc // 2), (wc - 1, hc // 2), (wc // 2, hc - 1)}
+        keep |= {ctus[i] for i in rng.choice(len(ctus), 24, replace=False)}
+        ctus = sorted(keep)
+    for cx, cy in ctus:
+        for comp in range(3):
+            r, o = rec[comp], org[comp]
+            cnt, off = np.zeros((5, 33), np.int64), np.zeros((5, 33), np.int64)
+            orc.orc_sao_stats_ctu(O.p(r), r.strides[0], O.p(o), o.strides[0], r.shape[1], r.shape[0], cx, cy, 64 if comp == 0 else 32,
+                                  int(comp != 0), O.p(cnt), O.p(off))
+            np.testing.assert_array_equal(got[cy * wc + cx, comp, 0], cnt, err_msg=f"CTU ({cx},{cy}) component {comp}: counts")
+            np.testing.assert_array_equal(got[cy * wc + cx, comp, 1], off, err_msg=f"CTU ({cx},{cy}) component {comp}: offsets")
+
+
+def test_sao_statistics_errors(L):
+    a = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    bad = capi.SaoGeom(64, 64, 32, 32, 64, 32)
+    assert L.xmi_sao_stats_dev(C.byref(bad), *[a.data_ptr()] * 6, a.data_ptr(), None) == -1
+    ok = capi.SaoGeom(64, 64, 64, 32, 64, 32)
+    assert L.xmi_sao_stats_dev(C.byref(ok), None, *[a.data_ptr()] * 5, a.data_ptr(), None) == -1

@@ -190,3 +190,14 @@ for label, dens, val in (("I picture, strength 2 on every edge segment", 1.0, 2)
     by = 2 * (W * H * 3 // 2) + 3 * tab
     print(json.dumps({"kernel": f"deblock 1080p ({label})", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
                       "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+
+# ---- SAO statistics of a 1080p picture (every CTU and component, five types) ----
+recs = [torch.from_numpy(f0).cuda(), torch.randint(0, 256, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g),
+        torch.randint(0, 256, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g)]
+orgs = [torch.from_numpy(f1).cuda(), recs[1].clone(), recs[2].clone()]
+sg = capi.SaoGeom(W, H, W, W // 2, W, W // 2)
+st_out = torch.zeros(nctu * 3 * C.sizeof(capi.SaoStats), dtype=torch.uint8, device="cuda")
+t = timeit(lambda: capi.check(L.xmi_sao_stats_dev(C.byref(sg), recs[0].data_ptr(), recs[1].data_ptr(), recs[2].data_ptr(), orgs[0].data_ptr(),
+                                                  orgs[1].data_ptr(), orgs[2].data_ptr(), st_out.data_ptr(), s)))
+by = 2 * (W * H * 3 // 2) + st_out.numel()
+print(json.dumps({"kernel": "sao_stats 1080p", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))

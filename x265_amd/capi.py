@@ -42,6 +42,14 @@ class IntraResult(C.Structure):
                 ("satd", C.c_uint32 * 35), ("reserved", C.c_uint32)]
 
 
+class SaoGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("width", "height", "rec_stride_y", "rec_stride_c", "org_stride_y", "org_stride_c")]
+
+
+class SaoStats(C.Structure):
+    _fields_ = [("count", C.c_int32 * 33 * 5), ("offset_org", C.c_int32 * 33 * 5)]
+
+
 class DeblockParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "stride_y", "stride_c", "tc_offset", "beta_offset", "cb_qp_offset", "cr_qp_offset")]
 
@@ -108,6 +116,11 @@ def load():
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.xmi_intra_search.restype = i
         L.xmi_intra_search.argtypes = [vp, C.c_uint32, vp, C.POINTER(IntraRequest), C.POINTER(IntraResult)]
+    if hasattr(L, "xmi_sao_stats_dev"):
+        L.xmi_sao_stats_dev.restype = i
+        L.xmi_sao_stats_dev.argtypes = [C.POINTER(SaoGeom), vp, vp, vp, vp, vp, vp, vp, vp]
+        L.xmi_sao_stats_frame.restype = i
+        L.xmi_sao_stats_frame.argtypes = [C.POINTER(SaoGeom), vp, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "xmi_deblock_frame_dev"):
         L.xmi_deblock_frame_dev.restype = i
         L.xmi_deblock_frame_dev.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp, vp]
