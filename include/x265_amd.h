@@ -214,6 +214,21 @@ int xmi_sao_stats_dev(const xmi_sao_geom *g, const uint8_t *d_rec_y, const uint8
 int xmi_sao_stats_frame(const xmi_sao_geom *g, const uint8_t *rec_y, const uint8_t *rec_u, const uint8_t *rec_v, const uint8_t *org_y,
                   const uint8_t *org_u, const uint8_t *org_v, xmi_sao_stats *stats);
 
+/* processSaoUnitAll (src/encode.cpp:1762-1904) for one component plane: every sample gets the offset of its category
+ * under its CTU's decided parameters (SaoLcuParam after merging, inc/x265.h:337: typeIdx -1 off / 0..3 edge classes / 4
+ * band offset, subTypeIdx = first band, offset[4]); categories are derived from the samples BEFORE any offset, samples
+ * of an edge class without both neighbours inside the picture stay. d_src and d_dst are different planes; the
+ * host-pointer form filters in place. ctu_size: 64 for luma, 32 for 4:2:0 chroma; params in CTU raster order. */
+typedef struct xmi_sao_ctu_param {
+    int8_t type_idx;
+    uint8_t band_position;
+    int8_t offset[4];
+    uint8_t reserved[2];
+} xmi_sao_ctu_param;
+int xmi_sao_apply_plane_dev(const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int width, int height, int ctu_size,
+                            const xmi_sao_ctu_param *d_params, void *stream);
+int xmi_sao_apply_plane(uint8_t *plane, int stride, int width, int height, int ctu_size, const xmi_sao_ctu_param *params);
+
 /* ---- frame session: host-pointer batch interface --------------------------------------------------
  * For a host CTU loop without device pointers of its own. The session holds one picture pair on the device (source
  * luma, padded previous reconstruction, its 16 quarter-pel planes) and stages request / result tables.

@@ -3,8 +3,9 @@
 
 `make -C oracle trace` builds oracle/_ref/x265_sao_trace (oracle/sao_trace_hook.cpp interposed on calcSaoStatsCu). This
 script encodes the 416x240 IPPP clip at QP 37 with it, checks the bitstream against tests/golden/encoder_md5.json and
-stores, for the I picture and one P picture, the deblocked reconstruction, the source picture and the count / offset
-tables of every CTU and component in tests/golden/sao_trace.npz."""
+stores, for the I picture and one P picture, the deblocked reconstruction, the source picture, the count / offset
+tables of every CTU and component, and (processSaoUnitAll) the SAO parameters of every CTU with the planes after the
+offsets were applied, in tests/golden/sao_trace.npz."""
 import hashlib
 import json
 import os
@@ -49,6 +50,18 @@ def main():
                 for k, name in enumerate(("rec_y", "rec_u", "rec_v", "org_y", "org_u", "org_v")):
                     out[f"p{poc}_{name}"] = planes[k]
                 stats[poc] = []
+        elif tag == 3:
+            comp, nctu = a, b
+            prm = np.frombuffer(raw, np.int32, nctu * 8, pos).reshape(nctu, 8)
+            pos += nctu * 32
+            shape = (h, w) if comp == 0 else (h // 2, w // 2)
+            after = np.frombuffer(raw, np.uint8, shape[0] * shape[1], pos).reshape(shape)
+            pos += shape[0] * shape[1]
+            if c in KEEP:
+                out[f"p{c}_param_{'yuv'[comp]}"] = prm
+                out[f"p{c}_sao_{'yuv'[comp]}"] = after
+                print(f"poc {c} component {comp}: types {sorted(set(prm[:, 0].tolist()))}, merge-left {int(prm[:, 6].sum())}, merge-up {int(prm[:, 7].sum())}, "
+                      f"samples changed {int((after != out[f'p{c}_rec_' + 'yuv'[comp]]).sum())}")
         else:
             cnt = np.frombuffer(raw, np.int64, 165, pos).reshape(5, 33)
             off = np.frombuffer(raw, np.int64, 165, pos + 1320).reshape(5, 33)

@@ -1,4 +1,5 @@
-// sao_gpu_hook.cpp - TEST INFRASTRUCTURE: the reference's encoder with its SAO statistics gathered by the GPU.
+// sao_gpu_hook.cpp - TEST INFRASTRUCTURE: the reference's encoder with its SAO statistics gathered and its SAO offsets
+// applied by the GPU.
 //
 // calcSaoStatsCu (src/encode.cpp:364) is called per CTU and component through the PLT of the position-independent
 // build, always on the deblocked picture and before any offset is applied. At the first call of a picture this
@@ -6,6 +7,9 @@
 // its CTU's tables into h->m_count[partIdx] / h->m_offsetOrg[partIdx] (the caller zeroed them, src/encode.cpp:1417).
 // The original is never called. The SAO parameters decided from the tables are coded into the stream and shape the
 // reconstruction, so an identical bitstream means identical tables wherever they matter.
+// processSaoUnitAll (src/encode.cpp:1762), called once per component after the decision, is replaced by
+// xmi_sao_apply_plane with the decided parameters of every CTU; the filtered planes are the next picture's reference and
+// are hashed into the stream's MD5 SEI.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -49,4 +53,24 @@ void calcSaoStatsCu(X265_t *h, UInt32 uiX, UInt32 uiY, int partIdx, int yCbCr)
             h->m_count[partIdx][t][c] = s.count[t][c];
             h->m_offsetOrg[partIdx][t][c] = s.offset_org[t][c];
         }
+}
+
+void processSaoUnitAll(X265_t *h, SaoLcuParam *saoLcuParam, int yCbCr)
+{
+    const int nctu = h->PicWidthInCUs * h->PicHeightInCUs;
+    std::vector<xmi_sao_ctu_param> prm((size_t)nctu);
+    for (int i = 0; i < nctu; i++) {
+        const SaoLcuParam &u = saoLcuParam[i];
+        prm[i].type_idx = (int8_t)u.typeIdx;
+        prm[i].band_position = (uint8_t)u.subTypeIdx;
+        for (int k = 0; k < 4; k++) prm[i].offset[k] = (int8_t)u.offset[k];
+        prm[i].reserved[0] = prm[i].reserved[1] = 0;
+    }
+    xFrame *f = h->pFrameRec;
+    uint8_t *plane = yCbCr == 0 ? f->pucY : yCbCr == 1 ? f->pucU : f->pucV;
+    const int chroma = yCbCr != 0;
+    if (xmi_sao_apply_plane(plane, chroma ? f->iStrideC : f->iStrideY, h->iWidth >> chroma, h->iHeight >> chroma, 64 >> chroma, prm.data()) != 0) {
+        fprintf(stderr, "sao_gpu_hook: %s\n", xmi_last_error());
+        abort();
+    }
 }

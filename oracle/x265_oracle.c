@@ -814,3 +814,31 @@ void orc_sao_stats_ctu(const uint8_t *rec, int rec_stride, const uint8_t *org, i
 #undef ADD
 #undef REC
 }
+
+/* ------------------------------------------------------------------ SAO: applying the offsets ---- */
+
+void orc_sao_apply_plane(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width, int height, int ctu_size,
+                         const orc_sao_ctu_param *params)
+{
+    static const int eo_table[5] = { 1, 2, 0, 3, 4 };      /* g_eoTable, src/encode.cpp:274 */
+    static const int nb[4][2][2] = { { { -1, 0 }, { 1, 0 } }, { { 0, -1 }, { 0, 1 } }, { { -1, -1 }, { 1, 1 } }, { { 1, -1 }, { -1, 1 } } };
+    const int wc = (width + ctu_size - 1) / ctu_size;
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const orc_sao_ctu_param *p = &params[(y / ctu_size) * wc + x / ctu_size];
+            const int c = src[(ptrdiff_t)y * src_stride + x];
+            int v = c;
+            if (p->type_idx == 4) {   /* band offset: src/encode.cpp:1844-1862, 1737-1749 */
+                const int band = c >> 3, k = (band - p->band_position) & 31;
+                if (k < 4) v = clip3(0, 255, c + p->offset[k]);
+            } else if (p->type_idx >= 0) {   /* edge offset classes: :1607-1736; the two neighbours are samples before SAO */
+                const int (*n)[2] = nb[p->type_idx];
+                const int xa = x + n[0][0], ya = y + n[0][1], xb = x + n[1][0], yb = y + n[1][1];
+                if (xa >= 0 && xa < width && xb >= 0 && xb < width && ya >= 0 && ya < height && yb >= 0 && yb < height) {
+                    const int cat = eo_table[sao_sign(c - src[(ptrdiff_t)ya * src_stride + xa]) + sao_sign(c - src[(ptrdiff_t)yb * src_stride + xb]) + 2];
+                    if (cat) v = clip3(0, 255, c + p->offset[cat - 1]);
+                }
+            }
+            dst[(ptrdiff_t)y * dst_stride + x] = (uint8_t)v;
+        }
+}

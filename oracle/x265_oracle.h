@@ -168,6 +168,22 @@ void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_par
 void orc_sao_stats_ctu(const uint8_t *rec, int rec_stride, const uint8_t *org, int org_stride, int pic_w, int pic_h,
                        int ctu_x, int ctu_y, int ctu_size, int is_chroma, int64_t count[5][33], int64_t offset_org[5][33]);
 
+/* processSaoUnitAll / processSaoCu (src/encode.cpp:1762-1904, 1524-1760) for one component plane: every sample gets
+ * the offset of its category under its CTU's SAO parameters - edge classes 0..3 from the signs against the two
+ * neighbours of the class taken BEFORE any offset was applied (the reference keeps line and column buffers for
+ * that), samples without both neighbours inside the picture unchanged; band offset for the four bands starting at
+ * band_position (bands of 8 levels, wrapping at 32). type_idx -1 = off. The reference works in place; src and dst are
+ * separate here so that the unmodified neighbours are simply src. params: one entry per CTU in raster order, taken
+ * from SaoLcuParam after merging (typeIdx, subTypeIdx, offset[4], inc/x265.h:337). */
+typedef struct {
+    int8_t type_idx;          /* -1 off, 0..3 edge classes EO_0..EO_3, 4 band offset */
+    uint8_t band_position;    /* subTypeIdx of a band offset */
+    int8_t offset[4];
+    uint8_t reserved[2];
+} orc_sao_ctu_param;
+void orc_sao_apply_plane(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width, int height, int ctu_size,
+                         const orc_sao_ctu_param *params);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,8 @@ def load():
     lib.orc_mv_component_bits.argtypes = [i]
     lib.orc_pred_inter_luma.restype = None
     lib.orc_pred_inter_luma.argtypes = [vp, vp, i, i, i, i, i]
+    lib.orc_sao_apply_plane.restype = None
+    lib.orc_sao_apply_plane.argtypes = [vp, i, vp, i, i, i, i, vp]
     lib.orc_sao_stats_ctu.restype = None
     lib.orc_sao_stats_ctu.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, vp]
     lib.orc_deblock_frame.restype = None
@@ -112,3 +114,12 @@ def sad_surface(lib, cur, ref_padded, pad, rng, pitch=None, ctu_begin=0, ctu_end
     lib.orc_sad_surface(p(cur), cur.strides[0], at(ref_padded, pad, pad), ref_padded.strides[0],
                         w, h, rng, pitch, p(s8), p(s16), p(s32), p(s64), ctu_begin, ctu_end)
     return s8, s16, s32, s64
+
+
+def sao_params(table):
+    """(CTUs, >= 6) int array of typeIdx, subTypeIdx, offset[4] -> packed 8-byte records of the C structs"""
+    out = np.zeros((len(table), 8), np.uint8)
+    out[:, 0] = table[:, 0].astype(np.int8).view(np.uint8)
+    out[:, 1] = table[:, 1].astype(np.uint8)
+    out[:, 2:6] = table[:, 2:6].astype(np.int8).view(np.uint8)
+    return np.ascontiguousarray(out)

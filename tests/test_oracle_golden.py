@@ -273,6 +273,20 @@ def test_sao_statistics_replay_encoder_trace(lib, golden_dir):
             np.testing.assert_array_equal(off, want_o, err_msg=f"picture {poc} CTU ({cx},{cy}) component {comp}: offsets")
 
 
+def test_sao_offsets_replay_encoder_trace(lib, golden_dir):
+    """orc_sao_apply_plane with the parameters the encoder decided (recorded around processSaoUnitAll): the planes after
+    SAO, every component of the I picture and a P picture (edge classes 0..3, band offsets, merged and switched-off CTUs)."""
+    g = np.load(os.path.join(golden_dir, "sao_trace.npz"))
+    for poc in g["pocs"]:
+        for ci, k in enumerate("yuv"):
+            src = np.ascontiguousarray(g[f"p{poc}_rec_{k}"])
+            prm = O.sao_params(g[f"p{poc}_param_{k}"])
+            dst = np.zeros_like(src)
+            lib.orc_sao_apply_plane(O.p(src), src.strides[0], O.p(dst), dst.strides[0], src.shape[1], src.shape[0], 64 if ci == 0 else 32, O.p(prm))
+            np.testing.assert_array_equal(dst, g[f"p{poc}_sao_{k}"], err_msg=f"picture {poc} plane {k}")
+    assert (g["p0_sao_y"] != g["p0_rec_y"]).sum() > 10000
+
+
 def test_motion_search_replays_encoder_trace(lib, golden_dir):
     """Every xMotionSearch call the reference's encoder made on three P pictures of the 416x240 QP32 clip
     (recorded by oracle/gen_me_trace.py from a bit-identical encode): the oracle returns the same MV, cost,

@@ -85,3 +85,49 @@ def test_sao_statistics_errors(L):
     assert L.xmi_sao_stats_dev(C.byref(bad), *[a.data_ptr()] * 6, a.data_ptr(), None) == -1
     ok = capi.SaoGeom(64, 64, 64, 32, 64, 32)
     assert L.xmi_sao_stats_dev(C.byref(ok), None, *[a.data_ptr()] * 5, a.data_ptr(), None) == -1
+
+
+def test_sao_offsets_replay_encoder_trace(L):
+    """xmi_sao_apply_plane_dev / xmi_sao_apply_plane with the parameters the encoder decided: the planes the reference's
+    in-place processSaoUnitAll left behind."""
+    g = np.load(os.path.join(GOLDEN, "sao_trace.npz"))
+    for poc in g["pocs"]:
+        for ci, k in enumerate("yuv"):
+            src = np.ascontiguousarray(g[f"p{poc}_rec_{k}"])
+            prm = O.sao_params(g[f"p{poc}_param_{k}"])
+            h, w = src.shape
+            d_src, d_prm = torch.from_numpy(src).cuda(), torch.from_numpy(prm).cuda()
+            d_dst = torch.zeros_like(d_src)
+            capi.check(L.xmi_sao_apply_plane_dev(d_src.data_ptr(), w, d_dst.data_ptr(), w, w, h, 64 if ci == 0 else 32, d_prm.data_ptr(), None))
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(d_dst.cpu().numpy(), g[f"p{poc}_sao_{k}"], err_msg=f"picture {poc} plane {k}")
+            plane = np.full((h + 4, w + 12), 77, np.uint8)
+            plane[2:2 + h, 4:4 + w] = src
+            capi.check(L.xmi_sao_apply_plane(O.at(plane, 2, 4), plane.strides[0], w, h, 64 if ci == 0 else 32, O.p(prm)))
+            np.testing.assert_array_equal(plane[2:2 + h, 4:4 + w], g[f"p{poc}_sao_{k}"])
+            assert (plane[:2] == 77).all() and (plane[:, :4] == 77).all() and (plane[:, 4 + w:] == 77).all()
+
+
+@pytest.mark.parametrize("w,h,ctu,seed", [(200, 136, 64, 1), (100, 68, 32, 2), (1920, 1088, 64, 3)])
+def test_sao_offsets_match_oracle(L, w, h, ctu, seed):
+    orc = O.load()
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    src[: h // 2] = (src[: h // 2] // 8) * 8                 # plateaus: category 0 and ties
+    src[:, : w // 4] = np.where(src[:, : w // 4] > 128, 254, 1)       # clipping at both ends
+    nctu = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    table = np.zeros((nctu, 6), np.int64)
+    table[:, 0] = rng.integers(-1, 5, nctu)
+    table[:, 1] = rng.integers(0, 32, nctu)
+    table[:, 2:6] = rng.integers(-7, 8, (nctu, 4))
+    prm = O.sao_params(table)
+    want = np.zeros_like(src)
+    orc.orc_sao_apply_plane(O.p(src), w, O.p(want), w, w, h, ctu, O.p(prm))
+    assert (want != src).sum() > w * h // 10
+    d_src, d_prm = torch.from_numpy(src).cuda(), torch.from_numpy(prm).cuda()
+    d_dst = torch.zeros_like(d_src)
+    capi.check(L.xmi_sao_apply_plane_dev(d_src.data_ptr(), w, d_dst.data_ptr(), w, w, h, ctu, d_prm.data_ptr(), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_dst.cpu().numpy(), want)
+    assert L.xmi_sao_apply_plane_dev(d_src.data_ptr(), w, d_src.data_ptr(), w, w, h, ctu, d_prm.data_ptr(), None) == -1
+    assert L.xmi_sao_apply_plane_dev(d_src.data_ptr(), w, d_dst.data_ptr(), w, w, h, 16, d_prm.data_ptr(), None) == -1

@@ -201,3 +201,21 @@ t = timeit(lambda: capi.check(L.xmi_sao_stats_dev(C.byref(sg), recs[0].data_ptr(
                                                   orgs[1].data_ptr(), orgs[2].data_ptr(), st_out.data_ptr(), s)))
 by = 2 * (W * H * 3 // 2) + st_out.numel()
 print(json.dumps({"kernel": "sao_stats 1080p", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+# ---- SAO offsets applied to the three planes of a 1080p picture (every CTU with an edge class or a band offset) ----
+prm_tab = np.zeros((nctu, 8), np.uint8)
+prm_tab[:, 0] = rng.integers(0, 5, nctu)
+prm_tab[:, 1] = rng.integers(0, 32, nctu)
+prm_tab[:, 2:6] = rng.integers(-3, 4, (nctu, 4)).astype(np.int8).view(np.uint8)
+d_prm = torch.from_numpy(prm_tab).cuda()
+dsts = [torch.zeros_like(r) for r in recs]
+
+
+def sao_apply():
+    for c in range(3):
+        capi.check(L.xmi_sao_apply_plane_dev(recs[c].data_ptr(), W >> (c > 0), dsts[c].data_ptr(), W >> (c > 0), W >> (c > 0), H >> (c > 0),
+                                             64 >> (c > 0), d_prm.data_ptr(), s))
+
+
+t = timeit(sao_apply)
+by = 2 * (W * H * 3 // 2)
+print(json.dumps({"kernel": "sao_apply 1080p (Y, U, V)", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1), "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))

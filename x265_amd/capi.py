@@ -119,6 +119,10 @@ def load():
     if hasattr(L, "xmi_sao_stats_dev"):
         L.xmi_sao_stats_dev.restype = i
         L.xmi_sao_stats_dev.argtypes = [C.POINTER(SaoGeom), vp, vp, vp, vp, vp, vp, vp, vp]
+        L.xmi_sao_apply_plane_dev.restype = i
+        L.xmi_sao_apply_plane_dev.argtypes = [vp, i, vp, i, i, i, i, vp, vp]
+        L.xmi_sao_apply_plane.restype = i
+        L.xmi_sao_apply_plane.argtypes = [vp, i, i, i, i, vp]
         L.xmi_sao_stats_frame.restype = i
         L.xmi_sao_stats_frame.argtypes = [C.POINTER(SaoGeom), vp, vp, vp, vp, vp, vp, vp]
     if hasattr(L, "xmi_deblock_frame_dev"):

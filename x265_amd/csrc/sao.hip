@@ -74,6 +74,42 @@ __global__ void __launch_bounds__(256) sao_stats_kernel(const SaoParams p)
     }
 }
 
+// ---- applying the decided offsets: processSaoUnitAll / processSaoCu (src/encode.cpp:1762-1904, 1524-1760) ----
+// The reference filters a plane in place, CTU by CTU, and keeps the row above and the column to the left in side buffers
+// so that every category is derived from samples BEFORE any offset; with separate source and destination planes that
+// is simply "classify on src, write dst", one thread per sample.
+struct SaoApplyParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    const xmi_sao_ctu_param *prm;
+    int src_stride, dst_stride, width, height, ctu_log2, wc;
+};
+
+__global__ void __launch_bounds__(256) sao_apply_kernel(const SaoApplyParams p)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.width || y >= p.height) return;
+    const xmi_sao_ctu_param q = p.prm[(y >> p.ctu_log2) * p.wc + (x >> p.ctu_log2)];
+    const uint8_t *s = p.src + (size_t)y * p.src_stride + x;
+    const int c = s[0];
+    int v = c;
+    if (q.type_idx == 4) {
+        const int k = ((c >> 3) - q.band_position) & 31;
+        if (k < 4) v = min(255, max(0, c + q.offset[k]));
+    } else if (q.type_idx >= 0) {
+        const int t = q.type_idx;
+        const int dx = t == 1 ? 0 : t == 3 ? 1 : -1, dy = t == 0 ? 0 : -1;      // first neighbour; the second is its mirror
+        const int xa = x + dx, ya = y + dy, xb = x - dx, yb = y - dy;
+        if (min(xa, xb) >= 0 && max(xa, xb) < p.width && min(ya, yb) >= 0 && max(ya, yb) < p.height) {
+            const int a = s[dy * p.src_stride + dx], b = s[-dy * p.src_stride - dx];
+            const int eo_table = 1 | (2 << 4) | (0 << 8) | (3 << 12) | (4 << 16);
+            const int cat = (eo_table >> (4 * (sgn(c - a) + sgn(c - b) + 2))) & 15;
+            if (cat) v = min(255, max(0, c + q.offset[cat - 1]));
+        }
+    }
+    p.dst[(size_t)y * p.dst_stride + x] = (uint8_t)v;
+}
+
 int check_geom(const char *who, const xmi_sao_geom *g)
 {
     XMI_ARG(g, "%s: null geometry", who);
@@ -140,6 +176,38 @@ int xmi_sao_stats_frame(const xmi_sao_geom *g, const uint8_t *rec_y, const uint8
     rc = xmi_sao_stats_dev(&dg, dr[0], dr[1], dr[2], dorg[0], dorg[1], dorg[2], reinterpret_cast<xmi_sao_stats *>(d + off_stats), nullptr);
     if (rc != XMI_OK) return rc;
     XMI_HIP(hipMemcpy(stats, d + off_stats, nctu * 3 * sizeof(xmi_sao_stats), hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
+
+int xmi_sao_apply_plane_dev(const uint8_t *d_src, int src_stride, uint8_t *d_dst, int dst_stride, int width, int height, int ctu_size,
+                            const xmi_sao_ctu_param *d_params, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(d_src && d_dst && d_params && d_src != d_dst, "xmi_sao_apply_plane_dev: null argument, or source and destination are the same plane");
+    XMI_ARG(width > 0 && height > 0 && src_stride >= width && dst_stride >= width, "xmi_sao_apply_plane_dev: bad geometry %dx%d", width, height);
+    XMI_ARG(ctu_size == 64 || ctu_size == 32, "xmi_sao_apply_plane_dev: CTU size %d (64 for luma, 32 for 4:2:0 chroma)", ctu_size);
+    SaoApplyParams p = { d_src, d_dst, d_params, src_stride, dst_stride, width, height, ctu_size == 64 ? 6 : 5, (width + ctu_size - 1) / ctu_size };
+    hipLaunchKernelGGL(sao_apply_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+int xmi_sao_apply_plane(uint8_t *plane, int stride, int width, int height, int ctu_size, const xmi_sao_ctu_param *params)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(plane && params && width > 0 && height > 0 && stride >= width && (ctu_size == 64 || ctu_size == 32), "xmi_sao_apply_plane: bad argument");
+    const size_t w = (size_t)width, h = (size_t)height, n = w * h;
+    const size_t nctu = ((w + ctu_size - 1) / ctu_size) * ((h + ctu_size - 1) / ctu_size);
+    const size_t off_prm = (2 * n + 15) & ~(size_t)15;
+    uint8_t *d = static_cast<uint8_t *>(xmi::scratch(11, off_prm + nctu * sizeof(xmi_sao_ctu_param)));
+    if (!d) return XMI_ERR_HIP;
+    XMI_HIP(hipMemcpy2D(d, w, plane, (size_t)stride, w, h, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_prm, params, nctu * sizeof(xmi_sao_ctu_param), hipMemcpyHostToDevice));
+    rc = xmi_sao_apply_plane_dev(d, width, d + n, width, width, height, ctu_size, reinterpret_cast<const xmi_sao_ctu_param *>(d + off_prm), nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy2D(plane, (size_t)stride, d + n, w, w, h, hipMemcpyDeviceToHost));
     return XMI_OK;
 }
 
