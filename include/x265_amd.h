@@ -175,6 +175,13 @@ typedef struct xmi_intra_pred_request {
 } xmi_intra_pred_request;
 int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream);
 
+/* ---- picture-border padding --------------------------------------------------------------------------
+ * xFramePadding (src/encode.cpp:2043-2092) for one plane: `pad` samples of border replication on every side (PAD_YSIZE =
+ * 80 for luma, PAD_CSIZE = 40 for chroma in the reference, inc/config.h:52). plane points at sample (0,0); the buffer
+ * holds pad rows above and below and pad columns left and right; stride >= width + 2 pad. */
+int xmi_frame_padding_dev(uint8_t *d_plane, int stride, int width, int height, int pad, void *stream);
+int xmi_frame_padding(uint8_t *plane, int stride, int width, int height, int pad);
+
 /* ---- in-loop deblocking -----------------------------------------------------------------------------
  * xDeblockFrame (src/Deblock.cpp:524-559) for one reconstructed 4:2:0 picture, in place: every vertical edge on the
  * 8-sample grid, then every horizontal edge, each 4-sample segment filtered when the boundary strength the CTU loop

@@ -91,3 +91,25 @@ def test_deblocking_errors(L):
     assert L.xmi_deblock_frame_dev(a.data_ptr(), a.data_ptr(), a.data_ptr(), C.byref(bad), a.data_ptr(), a.data_ptr(), a.data_ptr(), None) == -1
     ok = capi.DeblockParams(16, 16, 16, 8, 0, 0, 0, 0)
     assert L.xmi_deblock_frame_dev(None, a.data_ptr(), a.data_ptr(), C.byref(ok), a.data_ptr(), a.data_ptr(), a.data_ptr(), None) == -1
+
+
+@pytest.mark.parametrize("w,h,pad", [(64, 48, 80), (448, 256, 80), (224, 128, 40), (33, 7, 5)])
+def test_frame_padding_replicates_the_border(L, w, h, pad):
+    """xmi_frame_padding_dev / xmi_frame_padding against numpy's edge replication (what xFramePadding,
+    src/encode.cpp:2043-2092, writes: rows left and right, then whole rows up and down with the corners)."""
+    rng = np.random.default_rng(w + h)
+    pic = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    want = np.pad(pic, pad, mode="edge")
+    stride = w + 2 * pad + 8
+    buf = np.full((h + 2 * pad, stride), 123, np.uint8)
+    buf[pad:pad + h, pad:pad + w] = pic
+    d = torch.from_numpy(buf).cuda()
+    capi.check(L.xmi_frame_padding_dev(d.data_ptr() + pad * stride + pad, stride, w, h, pad, None))
+    torch.cuda.synchronize()
+    got = d.cpu().numpy()
+    np.testing.assert_array_equal(got[:, :w + 2 * pad], want)
+    assert (got[:, w + 2 * pad:] == 123).all()
+    capi.check(L.xmi_frame_padding(O.at(buf, pad, pad), stride, w, h, pad))
+    np.testing.assert_array_equal(buf[:, :w + 2 * pad], want)
+    assert (buf[:, w + 2 * pad:] == 123).all()
+    assert L.xmi_frame_padding_dev(d.data_ptr(), w, w, h, pad, None) == -1

@@ -116,6 +116,11 @@ def load():
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]
         L.xmi_intra_search.restype = i
         L.xmi_intra_search.argtypes = [vp, C.c_uint32, vp, C.POINTER(IntraRequest), C.POINTER(IntraResult)]
+    if hasattr(L, "xmi_frame_padding_dev"):
+        L.xmi_frame_padding_dev.restype = i
+        L.xmi_frame_padding_dev.argtypes = [vp, i, i, i, i, vp]
+        L.xmi_frame_padding.restype = i
+        L.xmi_frame_padding.argtypes = [vp, i, i, i, i]
     if hasattr(L, "xmi_sao_stats_dev"):
         L.xmi_sao_stats_dev.restype = i
         L.xmi_sao_stats_dev.argtypes = [C.POINTER(SaoGeom), vp, vp, vp, vp, vp, vp, vp, vp]
