@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """GPU-side work of one 1080p P picture as ONE captured HIP graph: quarter-pel planes of the previous reconstruction,
 (optionally) the SAD surface, a picture's worth of motion searches, the prediction blocks of every PU (luma + both
-chroma planes) and the transform chains of every TU, all device-resident, requests synthetic. It measures what a host
+chroma planes), the transform chains of every TU, then the in-loop filters on a reconstructed picture (deblocking,
+SAO statistics, SAO offsets) and the border padding, all device-resident, requests and decisions synthetic. It measures what a host
 CTU loop would have to keep fed - the decisions themselves (MVPs, splits, modes) are the host's and are given here.
 Prints one JSON line per variant."""
 import ctypes as C
@@ -80,6 +81,38 @@ lev_c = torch.zeros((2 * npu, 8, 8), dtype=torch.int16, device="cuda")
 rec_c = torch.zeros((2 * npu, 8, 8), dtype=torch.uint8, device="cuda")
 sum_c = torch.zeros(2 * npu, dtype=torch.int32, device="cuda")
 
+# in-loop filters and padding work on a padded reconstruction of their own (the scatter of the TU chains' blocks into
+# it is the host loop's bookkeeping and is not modelled)
+rec_pad = torch.from_numpy(B.pad_frame(f1, PAD)).cuda()
+rec_u = torch.randint(100, 140, (H // 2 + 2 * cpad, W // 2 + 2 * cpad), dtype=torch.uint8, device="cuda")
+rec_v = torch.randint(100, 140, rec_u.shape, dtype=torch.uint8, device="cuda")
+sao_y, sao_u, sao_v = torch.zeros_like(rec_pad), torch.zeros_like(rec_u), torch.zeros_like(rec_v)
+org_u = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda")
+org_v = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda")
+tab = (W // 4) * (H // 4)
+vbs = ((torch.rand(tab, device="cuda") < 0.33) * 1).to(torch.uint8)
+hbs = ((torch.rand(tab, device="cuda") < 0.33) * 1).to(torch.uint8)
+qpt = torch.full((tab,), 32, dtype=torch.uint8, device="cuda")
+dbp = capi.DeblockParams(W, H, stride, cstride, 0, 0, 0, 0)
+sgeo = capi.SaoGeom(W, H, stride, cstride, W, W // 2)
+sao_stats = torch.zeros(nctu * 3 * C.sizeof(capi.SaoStats), dtype=torch.uint8, device="cuda")
+prm_tab = np.zeros((nctu, 8), np.uint8)
+prm_tab[:, 0] = rng.integers(0, 5, nctu)
+prm_tab[:, 2:6] = rng.integers(-2, 3, (nctu, 4)).astype(np.int8).view(np.uint8)
+d_prm = torch.from_numpy(prm_tab).cuda()
+y00, u00, v00 = PAD * stride + PAD, cpad * cstride + cpad, cpad * cstride + cpad
+
+
+def filters(stream):
+    capi.check(L.xmi_deblock_frame_dev(rec_pad.data_ptr() + y00, rec_u.data_ptr() + u00, rec_v.data_ptr() + v00, C.byref(dbp), vbs.data_ptr(),
+                                       hbs.data_ptr(), qpt.data_ptr(), stream))
+    capi.check(L.xmi_sao_stats_dev(C.byref(sgeo), rec_pad.data_ptr() + y00, rec_u.data_ptr() + u00, rec_v.data_ptr() + v00, cur.data_ptr(),
+                                   org_u.data_ptr(), org_v.data_ptr(), sao_stats.data_ptr(), stream))
+    for src, dst, o, st, ww, hh, cs, pd in ((rec_pad, sao_y, y00, stride, W, H, 64, PAD), (rec_u, sao_u, u00, cstride, W // 2, H // 2, 32, cpad),
+                                            (rec_v, sao_v, v00, cstride, W // 2, H // 2, 32, cpad)):
+        capi.check(L.xmi_sao_apply_plane_dev(src.data_ptr() + o, st, dst.data_ptr() + o, st, ww, hh, cs, d_prm.data_ptr(), stream))
+        capi.check(L.xmi_frame_padding_dev(dst.data_ptr() + o, st, ww, hh, pd, stream))
+
 
 def picture(stream, surface):
     capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, rows, stride, planes.data_ptr(), stream))
@@ -102,6 +135,7 @@ def picture(stream, surface):
                                         rec_c.data_ptr(), sum_c.data_ptr(), stream))
     capi.check(L.xmi_tu_chain_batch_dev(8, npu, src_c.data_ptr() + npu * 64, pred_v.data_ptr(), qp_c.data_ptr() + npu, fl_c.data_ptr() + npu,
                                         lev_c.data_ptr() + npu * 128, rec_c.data_ptr() + npu * 64, sum_c.data_ptr() + npu * 4, stream))
+    filters(stream)
 
 
 for surface in (False, True):
@@ -129,6 +163,6 @@ for surface in (False, True):
     torch.cuda.synchronize()
     t_eager = a.elapsed_time(b) / iters
     print(json.dumps({"pipeline": "1080p P picture: planes" + (" + SAD surface (R=64)" if surface else "") + f" + {nreq} motion searches"
-                      + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains",
+                      + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains + deblocking + SAO statistics and offsets + padding",
                       "ms_graph": round(t_graph, 3), "ms_eager": round(t_eager, 3), "pictures_per_s_graph": round(1e3 / t_graph, 1),
                       "coded_levels_nonzero_tus": int((sum_y != 0).sum().item())}))
