@@ -214,6 +214,7 @@ int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_para
     XMI_ARG(prm->width >= 16 && prm->height >= 16 && prm->width % 8 == 0 && prm->height % 8 == 0 && prm->stride_y >= prm->width &&
                 prm->stride_c >= prm->width / 2,
             "xmi_deblock_frame: bad geometry %dx%d, strides %d / %d", prm->width, prm->height, prm->stride_y, prm->stride_c);
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
     const size_t w = (size_t)prm->width, h = (size_t)prm->height, tab = (w / 4) * (h / 4);
     const size_t sy = (w + 3) & ~(size_t)3, sc = w / 2;
     const size_t off_u = sy * h, off_v = off_u + sc * (h / 2), off_vbs = (off_v + sc * (h / 2) + 15) & ~(size_t)15;

@@ -39,6 +39,7 @@ int xmi_frame_padding(uint8_t *plane, int stride, int width, int height, int pad
     int rc = xmi::require_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(plane && width > 0 && height > 0 && pad > 0 && stride >= width + 2 * pad, "xmi_frame_padding: bad argument");
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
     const size_t W = (size_t)width + 2 * pad, H = (size_t)height + 2 * pad;
     uint8_t *d = static_cast<uint8_t *>(xmi::scratch(10, W * H));
     if (!d) return XMI_ERR_HIP;

@@ -160,6 +160,7 @@ int xmi_sao_stats_frame(const xmi_sao_geom *g, const uint8_t *rec_y, const uint8
     rc = check_geom("xmi_sao_stats_frame", g);
     if (rc != XMI_OK) return rc;
     XMI_ARG(rec_y && rec_u && rec_v && org_y && org_u && org_v && stats, "xmi_sao_stats_frame: null argument");
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
     const size_t w = (size_t)g->width, h = (size_t)g->height, luma = w * h, chroma = (w / 2) * (h / 2);
     const size_t nctu = ((w + 63) / 64) * ((h + 63) / 64);
     const size_t off_stats = (2 * (luma + 2 * chroma) + 15) & ~(size_t)15, total = off_stats + nctu * 3 * sizeof(xmi_sao_stats);
@@ -198,6 +199,7 @@ int xmi_sao_apply_plane(uint8_t *plane, int stride, int width, int height, int c
     int rc = xmi::require_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(plane && params && width > 0 && height > 0 && stride >= width && (ctu_size == 64 || ctu_size == 32), "xmi_sao_apply_plane: bad argument");
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
     const size_t w = (size_t)width, h = (size_t)height, n = w * h;
     const size_t nctu = ((w + ctu_size - 1) / ctu_size) * ((h + ctu_size - 1) / ctu_size);
     const size_t off_prm = (2 * n + 15) & ~(size_t)15;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 
@@ -16,6 +17,8 @@ hipStream_t as_stream(void *s);
 
 // scratch device buffer owned by the library, grown on demand (used by the host-pointer entry points)
 void *scratch(int slot, size_t bytes);
+// serialises the picture-level host-pointer entry points (deblocking, SAO, padding), which share scratch slots
+std::mutex &picture_call_mutex();
 
 #define XMI_HIP(call)                                                                    \
     do {                                                                                 \

@@ -59,6 +59,12 @@ int require_device()
     return init_locked(0);
 }
 
+std::mutex &picture_call_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
 void *scratch(int slot, size_t bytes)
 {
     std::lock_guard<std::mutex> lk(g_mu);
