@@ -1,6 +1,8 @@
 /*
  * x265_amd.h - C ABI of libx265_amd.so: the MI355X (gfx950) implementation of the x265-Milestone
- * pixel-primitive hot path (integer-ME SAD, SATD, SSD, forward/inverse transform + quantisation).
+ * pixel-primitive hot path (integer-ME SAD, SATD, SSD, forward/inverse transform + quantisation) and of the
+ * data-parallel stages on either side of it (interpolation, motion and intra mode search, prediction blocks,
+ * in-loop deblocking, SAO statistics and offsets, picture padding).
  *
  * Conventions
  *   - plain C, no C++ or torch types; every buffer is caller-owned.
@@ -11,6 +13,8 @@
  *   - return value: >= 0 success (or the primitive's value), XMI_ERR_* (< 0) on failure;
  *     xmi_last_error() gives the message for the calling thread. There is NO CPU fallback: without a
  *     usable GPU every compute entry point fails with XMI_ERR_NO_DEVICE.
+ *   - threads: *_dev entry points keep no state of their own (one stream per caller); host-pointer entry points
+ *     share library-owned staging buffers and serialise on internal mutexes; a frame session belongs to one thread.
  *
  * Citations name the reference interface each entry point replaces (paths relative to the
  * reference tree).
@@ -48,12 +52,12 @@ const char *xmi_version(void);
  * box xCuMvClip allows, src/encode.cpp:3794-3812) and every square PU of the quad-tree
  * (64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 = 85 per MV) the exact SAD.
  *
- * Output planes: sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32. The layout is tiled so that the
- * GPU writes whole cache lines: per (ctu, dy) one row = R/8 tiles of 16 consecutive dx, each tile
- * holding all blocks of the level ([block slot][dx % 16]), then one short tile with dx = +R alone
- * ([block slot]); sad64 rows are padded to a multiple of 4 elements. ctu is raster order in the
- * frame. Use xmi_sad_surface_index() for the element index of (level, ctu, blk, dy, dx) with blk in
- * raster order inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx; 64x64: 0).
+ * Output planes: sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32, exactly 180 bytes per (CTU, MV) in total. The
+ * layout is tiled so that the GPU writes whole cache lines: main part, dx in [-R, R-1]: per (ctu, dy) one row of R/8
+ * tiles of 16 consecutive dx, each tile holding all blocks of the level ([block slot][dx % 16]); the dx = +R column of
+ * every (ctu, dy) follows after the main part of the same plane ([ctu][dy][block slot]). ctu is raster order in the
+ * frame. Use xmi_sad_surface_index() for the element index of (level, ctu, blk, dy, dx) with blk in raster order
+ * inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx; 64x64: 0).
  * Requirements: width,height multiples of 64; range in {16,32,64,128}; the reference frame must be
  * readable range+4 pixels beyond every edge (the reference encoder pads by 80, inc/config.h:52);
  * d_cur, d_ref_origin and both strides 4-byte aligned; output planes 16-byte aligned. */
