@@ -106,23 +106,43 @@ def cpu_primitives(ref_lib, seconds_per_case=0.25):
 
 def cpu_encoder_fps(frames=6, qp=32):
     """The reference's encoder (its own sources compiled into oracle/_ref/x265_refsse; the 7 NASM-only SATD/SSD entries
-    come from the restatement) on a short 1080p IPPP clip, one thread, wall clock of the whole run."""
+    come from the restatement) on a short 1080p IPPP clip, wall clock of the whole run: one thread, and the reference's
+    own OpenMP row threads (x265_refsse_mt, -t up to its limit of 16) on the host cores this process may use."""
     exe = os.path.join(ROOT, "oracle", "_ref", "x265_refsse")
+    exe_mt = os.path.join(ROOT, "oracle", "_ref", "x265_refsse_mt")
     gen = os.path.join(ROOT, "tools", "gen_yuv.py")
     if not (os.path.exists(exe) and os.path.exists(gen)):
         return None
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores) or cores)))
     with tempfile.TemporaryDirectory() as d:
         yuv, out = os.path.join(d, "in.yuv"), os.path.join(d, "out.265")
         subprocess.run([sys.executable, gen, "1920", "1080", str(frames), "7", yuv], check=True, timeout=300)
-        cmd = [exe, "-i", yuv, "-o", out, "-w", "1920", "-h", "1080", "-f", str(frames), "-q", str(qp), "-ip", "100",
-               "-sceneChange", "0", "-t", "1"]
-        t0 = time.perf_counter()
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        sec = time.perf_counter() - t0
-        if res.returncode != 0 or not os.path.exists(out):
+
+        def run(binary, threads):
+            cmd = [binary, "-i", yuv, "-o", out, "-w", "1920", "-h", "1080", "-f", str(frames), "-q", str(qp), "-ip", "100",
+                   "-sceneChange", "0", "-t", str(threads)]
+            t0 = time.perf_counter()
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            sec = time.perf_counter() - t0
+            if res.returncode != 0 or not os.path.exists(out):
+                return None
+            return round(frames / sec, 3), os.path.getsize(out)
+        one = run(exe, 1)
+        if not one:
             return None
-        return {"fps": round(frames / sec, 3), "frames": frames, "qp": qp, "threads": 1, "bytes": os.path.getsize(out),
-                "what": "1920x1080 synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
+        enc = {"fps": one[0], "frames": frames, "qp": qp, "threads": 1, "bytes": one[1],
+               "what": "1920x1080 synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
+        threads = min(16, cores)
+        if os.path.exists(exe_mt) and threads > 1:
+            many = run(exe_mt, threads)
+            if many and many[1] == one[1]:
+                enc["fps_row_threads"] = many[0]
+                enc["row_threads"] = threads
+        return enc
 
 
 def main():
