@@ -26,6 +26,10 @@
 //     sad64: [ctu][dy][tile][dx % 16]
 //   edge part, dx = +R: appended after the main part of the same plane: [ctu][dy][block slot].
 //   xmi_sad_surface_index() does this arithmetic.
+//
+// Measurement variants (never defined in the library build; tools/build_variant.sh compiles them into separate
+// libraries): XMI_EXP_NOSTORE / XMI_EXP_NOCOMPUTE leave out the stores / the SAD instructions to time the other half,
+// XMI_EXP_NOPEEL and XMI_EXP_NOSCHEDBAR undo two scheduling measures, XMI_EXP_TIMELINE records per-workgroup clocks.
 #include "xmi_common.h"
 
 #include <type_traits>
