@@ -18,10 +18,10 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 pytestmark = pytest.mark.gpu
 
 
-def encode(variant, yuv, out, w, h, frames, qp):
+def encode(variant, yuv, out, w, h, frames, qp, scene_change=0):
     exe = os.path.join(REFDIR, f"x265_{variant}")
     cmd = [exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(frames), "-q", str(qp), "-ip", "100",
-           "-sceneChange", "0", "-t", "1"]
+           "-sceneChange", str(scene_change), "-t", "1"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out)
@@ -137,3 +137,18 @@ def test_gop_segments_on_two_ranks_with_gpu_motion_search():
     from tests.test_segments_gloo import run_segment_encode
     res = run_segment_encode("gpu_me", 2)
     assert res["parity"] == "identical" and res["ranks"] == 2
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_all")), reason="all-GPU encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("variant", ["gpu", "gpu_all"])
+def test_scene_change_detection_on_gpu_sad(tmp_path, variant):
+    """The reference's scene-change detection (sceneChangeDetection, src/preProcess.cpp:104: 32x32 SADs of the source
+    against the previous reconstruction through xSadN[3]) with the GPU's SAD table, on a clip with a scene cut at
+    picture 6: the cut is detected, an I picture is inserted, and the stream is the one the CPU build writes."""
+    w, h, frames, qp = 416, 240, 8, 32
+    yuv = str(tmp_path / "cut.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv, "6"])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))["416x240_f8_q32_cut6_scenechange"]
+    assert hashlib.md5(open(yuv, "rb").read()).hexdigest() == want["input_md5"]
+    got = encode(variant, yuv, str(tmp_path / "c.265"), w, h, frames, qp, scene_change=1)
+    assert got == (want["md5"], want["bytes"])

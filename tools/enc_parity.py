@@ -12,14 +12,15 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "encoder_md5.json")
-CONFIGS = [(416, 240, 8, 32), (416, 240, 3, 22), (416, 240, 8, 27), (416, 240, 8, 37)]
+# (width, height, frames, qp, scene cut at picture | None): with a cut the reference's scene-change detection is switched on
+CONFIGS = [(416, 240, 8, 32, None), (416, 240, 3, 22, None), (416, 240, 8, 27, None), (416, 240, 8, 37, None), (416, 240, 8, 32, 6)]
 
 
-def run(variant, yuv, w, h, f, q, out):
+def run(variant, yuv, w, h, f, q, out, scene_change=0):
     exe = os.path.join(ROOT, "oracle", "_ref", f"x265_{variant}")
     t = time.time()
     subprocess.run([exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(f), "-q", str(q), "-ip", "100",
-                    "-sceneChange", "0", "-t", "1"], check=True, capture_output=True)
+                    "-sceneChange", str(scene_change), "-t", "1"], check=True, capture_output=True)
     return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out), time.time() - t
 
 
@@ -28,11 +29,12 @@ def main():
     variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["refsse", "oracle"]
     gold = {} if write else json.load(open(GOLD))
     with tempfile.TemporaryDirectory() as d:
-        for w, h, f, q in CONFIGS:
+        for w, h, f, q, cut in CONFIGS:
             yuv = os.path.join(d, "in.yuv")
-            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), "1234", yuv])
-            key = f"{w}x{h}_f{f}_q{q}"
-            res = {v: run(v, yuv, w, h, f, q, os.path.join(d, v + ".265")) for v in variants}
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), "1234", yuv]
+                                  + ([str(cut)] if cut is not None else []))
+            key = f"{w}x{h}_f{f}_q{q}" + (f"_cut{cut}_scenechange" if cut is not None else "")
+            res = {v: run(v, yuv, w, h, f, q, os.path.join(d, v + ".265"), 1 if cut is not None else 0) for v in variants}
             for v, (m, n, t) in res.items():
                 print(f"{key:20s} {v:8s} {m} {n:8d} B {t:7.2f} s")
             if write:
