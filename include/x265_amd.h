@@ -99,7 +99,12 @@ int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int rows, int c
  * plane); integer candidates read plane 0. The caller must guarantee what the reference's frame padding
  * guarantees: every block a candidate can address lies at least 4 samples inside the padded buffer.
  * Requests: PU origin and size (8/16/32/64; x0, y0 multiples of 4), the two MV predictors (quarter-pel), bZeroMV,
- * the integer clip box of xCuMvClip (src/encode.cpp:3794) and (UInt32)sqrt(lambda). me_range = ME_RANGE (32). */
+ * the integer clip box of xCuMvClip (src/encode.cpp:3794) and (UInt32)sqrt(lambda). me_range = ME_RANGE (32).
+ * The request table is device memory, so the kernel checks each request before it reads: a size that is no PU
+ * size, a PU outside the picture (rows - 2 pad lines of stride - 2 pad samples), or predictors / a clip box that
+ * reach closer than 8 samples to the edge of the padded buffer (max(|mvp >> 2| + 2, |box| + 6) + 8 > pad) are not
+ * searched; their result is mvp_idx = -1, best_cost = best_sad = 0xffffffff. With the reference's geometry
+ * (pad 80, |MV| <= 64 + 4) no request is refused. */
 typedef struct xmi_me_request {
     int32_t x0, y0, size;
     int16_t mvp[2][2];            /* [candidate][x,y] */

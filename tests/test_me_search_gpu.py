@@ -206,3 +206,46 @@ def test_me_search_empty_and_errors(L):
     bad = capi.SadGeom(100, 64, 100, 200, 64)      # not a CTU multiple
     assert L.xmi_me_search_surface_batch_dev(a.data_ptr(), 8, a.data_ptr(), 8, 8, 0, C.byref(bad), a.data_ptr(), a.data_ptr(), a.data_ptr(),
                                              a.data_ptr(), a.data_ptr(), 1, 32, a.data_ptr(), None) == -1
+
+
+def test_requests_that_would_leave_the_buffers_are_refused(L):
+    """The request table is device memory the host side never sees, so the kernel checks each request: a PU outside the
+    picture, a size that is no PU size, or predictors / a clip box reaching beyond the border are answered with
+    mvp_idx -1 and cost 0xffffffff; the requests around them are served."""
+    w, h = 128, 64
+    cur, ref = make_video(w, h, 4, (1, 1), 2)
+    rows, stride = ref.shape
+    d_ref = torch.from_numpy(ref).cuda()
+    planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_interp_planes_dev(d_ref.data_ptr(), stride, rows, stride, planes.data_ptr(), None))
+    d_cur = torch.from_numpy(cur).cuda()
+    reqs = (capi.MeRequest * 7)()
+    for rq in reqs:
+        rq.size, rq.x0, rq.y0, rq.sqrt_lambda = 16, 32, 16, 4
+        rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+    reqs[1].size = 24                                       # no PU size
+    reqs[2].x0 = w - 8                                      # sticks out of the picture
+    reqs[3].y0 = -16
+    reqs[4].mvp[0][0] = 4 * 300                             # predictor far outside the border
+    reqs[5].mv_max_ipel[1] = 500                            # clip box far outside the border
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    for surface in (None, make_surface(L, d_cur, d_ref, w, h, stride, PAD, 64)):
+        d_res = torch.zeros(7 * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+        search(L, d_cur, cur.strides[0], planes, stride, rows, PAD, d_req, 7, d_res, surface)
+        res = (capi.MeResult * 7).from_buffer_copy(d_res.cpu().numpy().tobytes())
+        for i in (1, 2, 3, 4, 5):
+            assert (res[i].mvp_idx, res[i].best_cost, res[i].best_sad) == (-1, 0xffffffff, 0xffffffff), f"request {i} was served"
+        assert res[0].mvp_idx == 0 and res[0].best_cost < 0x7fffffff
+        assert bytes(res[0]) == bytes(res[6])
+    # the host-table form says which request it refuses
+    f = C.c_void_p()
+    capi.check(L.xmi_frame_create(w, h, PAD, C.byref(f)))
+    try:
+        capi.check(L.xmi_frame_begin(f, O.p(cur), cur.strides[0], O.p(ref), stride))
+        out = (capi.MeResult * 7)()
+        assert L.xmi_frame_me_search(f, reqs, 1, 32, out) == 0
+        assert bytes(out[0]) == bytes(res[0])
+        one = (capi.MeRequest * 1)(reqs[4])
+        assert L.xmi_frame_me_search(f, one, 1, 32, out) == -1 and b"request 0" in L.xmi_last_error()
+    finally:
+        L.xmi_frame_destroy(f)

@@ -88,6 +88,7 @@ int xmi_frame_destroy(xmi_frame *f)
 
 int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint8_t *ref_padded, int ref_stride)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && cur && ref_padded, "xmi_frame_begin: null argument");
     XMI_ARG(cur_stride >= f->width && ref_stride >= f->stride, "xmi_frame_begin: strides %d / %d too small for %dx%d (+%d)", cur_stride,
             ref_stride, f->width, f->height, f->pad);
@@ -105,6 +106,7 @@ int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint
 
 int xmi_frame_sad_surface(xmi_frame *f, int range)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_sad_surface: no picture (call xmi_frame_begin first)");
     XMI_ARG(f->width % 64 == 0 && f->height % 64 == 0, "xmi_frame_sad_surface: %dx%d is not a multiple of the 64x64 CTU", f->width, f->height);
     XMI_ARG(range == 16 || range == 32 || range == 64 || range == 128, "xmi_frame_sad_surface: range %d not in {16,32,64,128}", range);
@@ -132,6 +134,7 @@ int xmi_frame_sad_surface(xmi_frame *f, int range)
 
 int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture && planes, "xmi_frame_planes_host: no picture or null destination");
     XMI_HIP(hipMemcpyAsync(planes, f->d_planes, 16 * (size_t)f->rows * f->stride, hipMemcpyDeviceToHost, f->stream));
     XMI_HIP(hipStreamSynchronize(f->stream));
@@ -140,6 +143,7 @@ int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes)
 
 int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_range, xmi_me_result *res)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_me_search: no picture (call xmi_frame_begin first)");
     XMI_ARG(n >= 0 && (n == 0 || (req && res)), "xmi_frame_me_search: bad request table");
     if (n == 0) return XMI_OK;
@@ -147,6 +151,9 @@ int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_r
         XMI_ARG((req[i].size == 8 || req[i].size == 16 || req[i].size == 32 || req[i].size == 64) && req[i].x0 >= 0 && req[i].y0 >= 0 &&
                     req[i].x0 % 4 == 0 && req[i].x0 + req[i].size <= f->width && req[i].y0 + req[i].size <= f->height,
                 "xmi_frame_me_search: request %d (%d,%d size %d) outside the %dx%d picture", i, req[i].x0, req[i].y0, req[i].size, f->width, f->height);
+    for (int i = 0; i < n; i++)
+        XMI_ARG(xmi::me_request_reach(req[i]) + 8 <= f->pad, "xmi_frame_me_search: request %d can read %d samples away from its PU; the border is %d", i,
+                xmi::me_request_reach(req[i]), f->pad);
     const size_t rq_bytes = align256((size_t)n * sizeof(xmi_me_request)), rs_bytes = (size_t)n * sizeof(xmi_me_result);
     int rc = stage(f, rq_bytes + rs_bytes);
     if (rc != XMI_OK) return rc;
@@ -170,6 +177,7 @@ int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_r
 
 int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_intra_request *req, int n, xmi_intra_result *res)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_intra_search: no picture (call xmi_frame_begin first)");
     XMI_ARG(n >= 0 && (n == 0 || (req && res && ref_samples)), "xmi_frame_intra_search: bad request table");
     if (n == 0) return XMI_OK;
@@ -197,6 +205,7 @@ int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_i
 int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const uint8_t *pred, const uint8_t *qp, const uint8_t *flags,
                        int16_t *level, uint8_t *rec, uint32_t *sum)
 {
+    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f, "xmi_frame_tu_chain: null session");
     XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32, "xmi_frame_tu_chain: transform size %d not in {4,8,16,32}", n);
     XMI_ARG(count >= 0 && (count == 0 || (pix && pred && qp && flags && level && rec && sum)), "xmi_frame_tu_chain: bad arguments");

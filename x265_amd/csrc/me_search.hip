@@ -244,6 +244,22 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     }
 }
 
+// Request tables live in device memory, so the kernel checks what it is about to address: a request is served only
+// if its PU lies in the picture and every block the search can read (xmi::me_request_reach), with the dword
+// over-read of an unaligned load, lies inside the `rows` x `stride` plane buffers.
+template <bool SURF>
+__device__ __forceinline__ bool request_in_bounds(const MeParams &p, const xmi_me_request &rq)
+{
+    const int n = rq.size;
+    if (n != 8 && n != 16 && n != 32 && n != 64) return false;
+    const int reach = xmi::me_request_reach(rq);
+    if (rq.x0 < 0 || rq.y0 < 0 || (rq.x0 & 3) || rq.x0 + n > p.cur_stride || rq.x0 + n + 2 * p.pad > p.stride) return false;
+    if (rq.y0 + n + 2 * p.pad > p.rows) return false;
+    if (reach + 8 > p.pad) return false;
+    if (SURF && (rq.x0 + n > p.surf_wc * 64 || ((rq.y0 + n + 63) >> 6) * p.surf_wc > p.surf_nctu)) return false;
+    return true;
+}
+
 template <bool SURF>
 __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
 {
@@ -251,12 +267,20 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     const int idx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (idx >= p.n) return;
     const xmi_me_request rq = p.req[idx];
+    if (!request_in_bounds<SURF>(p, rq)) {        // refused: marked, so that the caller can tell
+        if (lane == 0) {
+            xmi_me_result out = {};
+            out.best_cost = out.best_sad = 0xffffffffu;
+            out.mvp_idx = -1;
+            p.res[idx] = out;
+        }
+        return;
+    }
     switch (rq.size) {
     case 8: search<8, SURF>(p, rq, idx, lane); break;
     case 16: search<16, SURF>(p, rq, idx, lane); break;
     case 32: search<32, SURF>(p, rq, idx, lane); break;
-    case 64: search<64, SURF>(p, rq, idx, lane); break;
-    default: break;                               // not a PU size: the result entry is left untouched
+    default: search<64, SURF>(p, rq, idx, lane); break;
     }
 }
 

@@ -15,18 +15,16 @@ std::mutex g_call_mu;  // the staging buffers below are shared by all callers
 
 struct Stage {
     uint8_t *dev = nullptr;   // device staging, one allocation, carved by the helpers
-    size_t bytes = 0;
     std::vector<uint8_t> host;
 };
 Stage g_st;
 
 bool ensure(size_t bytes)
 {
-    if (g_st.bytes >= bytes) return true;
+    // asked for on every call: the library's scratch table is the owner and xmi_shutdown() empties it
     void *p = xmi::scratch(7, bytes < 65536 ? 65536 : bytes);
     if (!p) return false;
     g_st.dev = static_cast<uint8_t *>(p);
-    g_st.bytes = bytes < 65536 ? 65536 : bytes;
     return true;
 }
 

@@ -66,6 +66,22 @@ __host__ __device__ inline size_t surface_index(int R, size_t nctu, int level, i
     return row * (size_t)surface_row_elems(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
 }
 
+// Bound on the integer displacement (either axis, either sign) of every block one motion search can read: predictors
+// and start point |mvp >> 2| + 1, diamond points inside the clip box, sub-pel points within 5 of the box after the final
+// clip (which bounds x by the Y maximum, src/encode.cpp:2950-2953); one more for good measure.
+__host__ __device__ inline int me_request_reach(const xmi_me_request &rq)
+{
+    int reach = 0;
+    for (int c = 0; c < 2; c++) {
+        const int v[4] = { (rq.mvp[0][c] >> 2), (rq.mvp[1][c] >> 2), (int)rq.mv_min_ipel[c], (int)rq.mv_max_ipel[c] };
+        for (int k = 0; k < 4; k++) {
+            const int a = (v[k] < 0 ? -v[k] : v[k]) + (k < 2 ? 2 : 6);
+            reach = a > reach ? a : reach;
+        }
+    }
+    return reach;
+}
+
 }  // namespace xmi
 
 #ifdef __HIPCC__
