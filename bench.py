@@ -145,6 +145,33 @@ def cpu_encoder_fps(frames=6, qp=32):
         return enc
 
 
+def satd_rates(L, capi, torch, dev, stream, reps=10):
+    """The other half of the headline metric: block SATD evaluations per second of the batch kernel (one evaluation = one
+    N x N block pair; HM form = xCalcHADs*, x264 form = the xSatdN table entries), 512 Mi pixels per operand resident in
+    HBM (1 GiB per launch, four times the last-level cache), HIP events on the launch stream. Algorithmic bytes per evaluation: 2 N^2 read + 4 written."""
+    out = {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    for metric, name, sizes in ((capi.METRIC_SATD_HM, "hm", (8, 16, 32)), (capi.METRIC_SATD_X264, "x264", (4, 8, 16))):
+        for n in sizes:
+            cnt = (512 << 20) // (n * n)
+            a = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device=dev, generator=g)
+            b = torch.randint(0, 256, (cnt, n, n), dtype=torch.uint8, device=dev, generator=g)
+            res = torch.empty(cnt, dtype=torch.int32, device=dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(reps + 2):
+                if i == 2:
+                    e0.record(stream)
+                capi.check(L.xmi_block_metric_batch_dev(metric, n, cnt, a.data_ptr(), b.data_ptr(), res.data_ptr(), stream.cuda_stream))
+            e1.record(stream)
+            torch.cuda.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / reps
+            gbs = cnt * (2 * n * n + 4) / sec / 1e9
+            out[f"{name} {n}x{n}"] = {"Geval_per_s": round(cnt / sec / 1e9, 2), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            del a, b, res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,6 +293,7 @@ def main():
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),
                          "kernel_ms_min": round(kern_ms[0], 4)},
         }
+        out["satd"] = satd_rates(L, capi, torch, dev, stream)
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(256) intra_pred_kernel(const IntraPredParams p
     const int idx = (int)blockIdx.x * 4 + wave;
     if (idx >= p.n) return;
     const xmi_intra_pred_request rq = p.req[idx];
-    if (rq.size != 4 && rq.size != 8 && rq.size != 16 && rq.size != 32) return;       // not a PU size: nothing is written
+    if ((rq.size != 4 && rq.size != 8 && rq.size != 16 && rq.size != 32) || rq.mode > 34) return;   // no PU size or no mode: nothing is written
     const uint8_t *raw = p.refs + (size_t)idx * XMI_INTRA_REF_PITCH;
     for (int i = lane; i < 4 * rq.size + 1; i += 64) s_ref[wave][i] = raw[i];
     __builtin_amdgcn_wave_barrier();
