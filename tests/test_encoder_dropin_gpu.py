@@ -18,10 +18,10 @@ REFDIR = os.path.join(ROOT, "oracle", "_ref")
 pytestmark = pytest.mark.gpu
 
 
-def encode(variant, yuv, out, w, h, frames, qp, scene_change=0):
+def encode(variant, yuv, out, w, h, frames, qp, scene_change=0, threads=1):
     exe = os.path.join(REFDIR, f"x265_{variant}")
     cmd = [exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(frames), "-q", str(qp), "-ip", "100",
-           "-sceneChange", str(scene_change), "-t", "1"]
+           "-sceneChange", str(scene_change), "-t", str(threads)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out)
@@ -151,4 +151,17 @@ def test_scene_change_detection_on_gpu_sad(tmp_path, variant):
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))["416x240_f8_q32_cut6_scenechange"]
     assert hashlib.md5(open(yuv, "rb").read()).hexdigest() == want["input_md5"]
     got = encode(variant, yuv, str(tmp_path / "c.265"), w, h, frames, qp, scene_change=1)
+    assert got == (want["md5"], want["bytes"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_mt")), reason="threaded GPU encoder not built (make -C oracle enc)")
+def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
+    """The reference's own OpenMP row threads (src/encode.cpp:5865; the build of x265_refsse_mt) calling the GPU per-call
+    primitives concurrently, four rows at a time: the per-call entry points serialise on their staging buffers, and the
+    stream is the single-thread one."""
+    w, h, frames, qp = 416, 240, 8, 32
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_mt", yuv, str(tmp_path / "t.265"), w, h, frames, qp, threads=4)
     assert got == (want["md5"], want["bytes"])

@@ -328,3 +328,55 @@ def test_percall_dropins_match_oracle(L, orc):
             np.testing.assert_array_equal(r2, r3)
     assert L.xmi_quant(O.p(l0), O.p(c0), 64, 52, 8, 8, O.SLICE_P) == -1
     assert L.xmi_sub_dct(O.p(c0), O.p(src), 64, O.p(pred), 64, 64, 0) == -1
+
+
+def test_percall_dropins_from_concurrent_threads(L, orc):
+    """The reference calls its primitives from up to 16 OpenMP row threads at once (inc/config.h:109). Eight host threads,
+    each with its own blocks, interleave the per-call entry points (ctypes releases the interpreter lock during a call):
+    every result is the oracle's for that thread's data, and the error text of one thread does not show in another."""
+    import threading
+    expect, blocks = [], []
+    for t in range(8):
+        rng = np.random.default_rng(500 + t)
+        src = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+        ref = rng.integers(0, 256, (72, 96), dtype=np.uint8)
+        pred = np.clip(src.astype(int) + rng.integers(-12, 13, src.shape), 0, 255).astype(np.uint8)
+        blocks.append((src, ref, pred))
+        e = []
+        for n in (8, 16, 32, 64):
+            e.append(orc.orc_sad(n, O.p(src), 64, O.at(ref, 2, 3), 96))
+            e.append(orc.orc_satd_hm(n, O.p(src), 64, O.at(ref, 2, 3), 96))
+        for n in (4, 8, 16, 32):
+            r, l = np.zeros((64, 80), np.uint8), np.zeros((64, 64), np.int16)
+            s = orc.orc_tu_chain(O.p(src), O.p(pred), O.p(r), O.p(l), n, 64, 80, 27 + t, O.MODE_INVALID, O.SLICE_P)
+            e.append((s, r.tobytes(), l.tobytes()))
+        expect.append(e)
+    failures = []
+
+    def work(t):
+        src, ref, pred = blocks[t]
+        try:
+            for rep in range(6):
+                got = []
+                for n in (8, 16, 32, 64):
+                    got.append(L.xmi_sad(n, O.p(src), 64, O.at(ref, 2, 3), 96))
+                    got.append(L.xmi_satd_hm(n, O.p(src), 64, O.at(ref, 2, 3), 96))
+                for n in (4, 8, 16, 32):
+                    r, l = np.zeros((64, 80), np.uint8), np.zeros((64, 64), np.int16)
+                    s = L.xmi_tu_chain(O.p(src), O.p(pred), O.p(r), O.p(l), n, 64, 80, 27 + t, O.MODE_INVALID, O.SLICE_P)
+                    got.append((s, r.tobytes(), l.tobytes()))
+                if got != expect[t]:
+                    failures.append(f"thread {t} repetition {rep}: results differ from the oracle")
+                if t == 0:          # provoke an error in one thread only
+                    assert L.xmi_satd(64, O.p(src), 64, O.p(ref), 96) == -1
+                elif rep == 5 and b"xSatdN" in L.xmi_last_error():
+                    failures.append(f"thread {t} sees thread 0's error text")
+        except Exception as exc:       # noqa: BLE001 - reported below, from the main thread
+            failures.append(f"thread {t}: {exc!r}")
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not failures, failures[:3]
