@@ -165,3 +165,19 @@ def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
     want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
     got = encode("gpu_mt", yuv, str(tmp_path / "t.265"), w, h, frames, qp, threads=4)
     assert got == (want["md5"], want["bytes"])
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-service encoders not built (make -C oracle trace)")
+@pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock"))])
+def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants):
+    """The geometry the headline metric is quoted on (1920x1080, coded 1920x1088, 510 CTUs; generator seed 7): the
+    reference's encoder with the GPU motion search / quarter-pel planes / deblocking / SAO statistics writes the stream
+    recorded from the CPU build."""
+    w, h = 1920, 1080
+    frames, qp = int(key.split("_")[1][1:]), int(key.split("_")[2][1:])
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "7", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[key]
+    assert hashlib.md5(open(yuv, "rb").read()).hexdigest() == want["input_md5"]
+    for v in variants:
+        assert encode(v, yuv, str(tmp_path / f"{v}.265"), w, h, frames, qp) == (want["md5"], want["bytes"]), f"x265_{v}"

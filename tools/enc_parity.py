@@ -13,7 +13,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "encoder_md5.json")
 # (width, height, frames, qp, scene cut at picture | None): with a cut the reference's scene-change detection is switched on
-CONFIGS = [(416, 240, 8, 32, None), (416, 240, 3, 22, None), (416, 240, 8, 27, None), (416, 240, 8, 37, None), (416, 240, 8, 32, 6)]
+CONFIGS = [(416, 240, 8, 32, None), (416, 240, 3, 22, None), (416, 240, 8, 27, None), (416, 240, 8, 37, None), (416, 240, 8, 32, 6),
+           (1920, 1080, 4, 32, None), (1920, 1080, 3, 22, None)]
+SEED = {416: 1234, 1920: 7}     # generator seeds per picture width (tools/gen_yuv.py)
 
 
 def run(variant, yuv, w, h, f, q, out, scene_change=0):
@@ -31,7 +33,7 @@ def main():
     with tempfile.TemporaryDirectory() as d:
         for w, h, f, q, cut in CONFIGS:
             yuv = os.path.join(d, "in.yuv")
-            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), "1234", yuv]
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), str(SEED[w]), yuv]
                                   + ([str(cut)] if cut is not None else []))
             key = f"{w}x{h}_f{f}_q{q}" + (f"_cut{cut}_scenechange" if cut is not None else "")
             res = {v: run(v, yuv, w, h, f, q, os.path.join(d, v + ".265"), 1 if cut is not None else 0) for v in variants}
