@@ -26,7 +26,7 @@ def gpu_stats(L, rec, org):
     h, w = rec[0].shape
     nctu = ((w + 63) // 64) * ((h + 63) // 64)
     d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in rec + org]
-    out = torch.zeros(nctu * 3 * C.sizeof(capi.SaoStats), dtype=torch.uint8, device="cuda")
+    out = torch.full((nctu * 3 * C.sizeof(capi.SaoStats),), 255, dtype=torch.uint8, device="cuda")     # every entry must be written
     g = capi.SaoGeom(w, h, w, w // 2, w, w // 2)
     capi.check(L.xmi_sao_stats_dev(C.byref(g), *[t.data_ptr() for t in d], out.data_ptr(), None))
     torch.cuda.synchronize()
@@ -55,7 +55,7 @@ def test_sao_statistics_replay_encoder_trace(L):
         assert bytes(res) == got.tobytes()
 
 
-@pytest.mark.parametrize("w,h,seed", [(200, 136, 1), (448, 256, 2), (1920, 1080, 3)])
+@pytest.mark.parametrize("w,h,seed", [(200, 136, 1), (448, 256, 2), (1920, 1080, 3), (150, 72, 4)])   # the last: widths that are no multiple of 4 (sample-by-sample path)
 def test_sao_statistics_match_oracle(L, w, h, seed):
     orc = O.load()
     rng = np.random.default_rng(seed)
@@ -108,7 +108,7 @@ def test_sao_offsets_replay_encoder_trace(L):
             assert (plane[:2] == 77).all() and (plane[:, :4] == 77).all() and (plane[:, 4 + w:] == 77).all()
 
 
-@pytest.mark.parametrize("w,h,ctu,seed", [(200, 136, 64, 1), (100, 68, 32, 2), (1920, 1088, 64, 3)])
+@pytest.mark.parametrize("w,h,ctu,seed", [(200, 136, 64, 1), (100, 68, 32, 2), (1920, 1088, 64, 3), (102, 70, 32, 4), (67, 33, 64, 5)])
 def test_sao_offsets_match_oracle(L, w, h, ctu, seed):
     orc = O.load()
     rng = np.random.default_rng(seed)
