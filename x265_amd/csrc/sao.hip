@@ -24,7 +24,7 @@ constexpr int kBins = 5 * 33;
 constexpr int kEoBins = 4 * 5;                 // histogram rows actually touched: 4 edge types x 5 categories ...
 constexpr int kRows = kEoBins + 32;            // ... and the 32 bands
 
-__device__ __forceinline__ int sgn(int x) { return (x > 0) - (x < 0); }
+__device__ __forceinline__ int sgn(int x) { return min(max(x, -1), 1); }      // one v_med3_i32
 
 // Every lane keeps a histogram of its own in LDS ([row][lane], so a wavefront's accesses to one row fall on distinct
 // banks and nothing is contended, however uniform the picture is). One 32-bit word holds both statistics of a row:
