@@ -210,6 +210,18 @@ int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_de
 int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_params *p, const uint8_t *vertical_bs,
                       const uint8_t *horizontal_bs, const uint8_t *qp_tab);
 
+/* The boundary strengths themselves, for a whole picture at once, from picture-level maps of the decisions: replaces the
+ * per-unit calls of ff_hevc_deblocking_boundary_strengths (src/Deblock.cpp:369-503; called from xEncWriteCU,
+ * src/encode.cpp:4885, 4904) and its boundary_strength (:344-366). A unit is the square the reference makes one call for
+ * (a CU, or one 32x32 quarter of a coded 64x64 CU). unit_log2: log2 of the unit's size, and cbf: its luma cbf flag, at
+ * every 4x4 position (width/4 per row); mv: the motion vector of every 8x8 block (width/8 per row, x then y, quarter-pel;
+ * may be null for an I slice). Both tables are written in full, (width/8)*(height/4) entries each, indexed as
+ * xmi_deblock_frame_dev reads them. */
+int xmi_deblock_strengths_dev(int width, int height, int intra_slice, const uint8_t *d_unit_log2, const uint8_t *d_cbf, const int16_t *d_mv,
+                              uint8_t *d_vertical_bs, uint8_t *d_horizontal_bs, void *stream);
+int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                          uint8_t *vertical_bs, uint8_t *horizontal_bs);
+
 /* ---- SAO statistics -----------------------------------------------------------------------------------
  * calcSaoStatsCu (src/encode.cpp:364-622) for every 64x64 CTU and component of a deblocked 4:2:0 picture in one launch:
  * stats[ctu * 3 + component] holds, per SAO type (0..3 = edge classes EO_0..EO_3, 4 = band offset) and category, the

@@ -10,6 +10,9 @@
 #include "x265.h"
 #include "../include/x265_amd.h"
 
+// defined by bs_gpu_hook.cpp when that hook is linked in: derives the boundary strengths of the finished picture on the GPU
+extern "C" void xmi_hook_fill_strengths(X265_t *) __attribute__((weak));
+
 namespace {
 unsigned long g_pictures = 0;
 void report() { fprintf(stderr, "deblock_gpu_hook: %lu pictures deblocked on the GPU\n", g_pictures); }
@@ -33,6 +36,7 @@ void xDeblockFrame(X265_t *h, CUInt32, CUInt32, Int32, Int32, Int32, Int32)
             fprintf(stderr, "deblock_gpu_hook: per-CTB deblocking parameters are not supported\n");
             abort();
         }
+    if (xmi_hook_fill_strengths) xmi_hook_fill_strengths(h);
     xFrame *f = h->pFrameRec;
     xmi_deblock_params p = { h->sps->pic_width_in_luma_samples, h->sps->pic_height_in_luma_samples, f->iStrideY, f->iStrideC,
                              h->deblock[0].tc_offset, h->deblock[0].beta_offset, h->pps_cb_qp_offset, h->pps_cr_qp_offset };

@@ -842,3 +842,58 @@ void orc_sao_apply_plane(const uint8_t *src, int src_stride, uint8_t *dst, int d
             dst[(ptrdiff_t)y * dst_stride + x] = (uint8_t)v;
         }
 }
+
+/* ---- boundary strengths from picture-level maps (src/Deblock.cpp:344-503) ---- */
+static int orc_bs_pair(int intra_slice, const int16_t *cur_mv, int cur_cbf, const int16_t *nb_mv, int nb_cbf, int unit_edge)
+{
+    if (unit_edge) {                                   /* src/Deblock.cpp:346-353 */
+        if (intra_slice) return 2;
+        if (cur_cbf || nb_cbf) return 1;
+    }
+    if (!intra_slice)                                  /* :355-364, one reference picture */
+        return abs(nb_mv[0] - cur_mv[0]) >= 4 || abs(nb_mv[1] - cur_mv[1]) >= 4;
+    return 0;
+}
+
+void orc_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf,
+                           const int16_t *mv, uint8_t *vertical_bs, uint8_t *horizontal_bs)
+{
+    const int w4 = width >> 2, w8 = width >> 3, bsw = width >> 3;
+    memset(vertical_bs, 0, (size_t)w8 * (height >> 2));
+    memset(horizontal_bs, 0, (size_t)w8 * (height >> 2));
+    /* the reference's order: one call per unit, each writing the edges on its own top and left side and inside it */
+    for (int y4 = 0; y4 < (height >> 2); y4++)
+        for (int x4 = 0; x4 < w4; x4++) {
+            const int lg = unit_log2[y4 * w4 + x4], size = 1 << lg, x0 = x4 * 4, y0 = y4 * 4;
+            if (lg < 2 || (x0 & (size - 1)) || (y0 & (size - 1))) continue;       /* not the top-left 4x4 of a unit */
+            const int16_t *cur_mv = mv + 2 * ((y0 >> 3) * w8 + (x0 >> 3));
+            const int cur_cbf = cbf[y4 * w4 + x4];
+            const int inner = lg > 2 && !intra_slice;                               /* :424, :476 */
+            if ((y0 & 7) == 0 && y0 != 0)                                           /* :393-422 */
+                for (int i = 0; i < size; i += 4) {
+                    const int bs = orc_bs_pair(intra_slice, cur_mv, cur_cbf, mv + 2 * (((y0 >> 3) - 1) * w8 + (x0 >> 3) + (i >> 3)),
+                                               cbf[(y4 - 1) * w4 + x4 + (i >> 2)], 1);
+                    if (bs) horizontal_bs[((x0 + i) + y0 * bsw) >> 2] = (uint8_t)bs;
+                }
+            if (inner)                                                              /* :426-447 */
+                for (int j = 8; j < size; j += 8)
+                    for (int i = 0; i < size; i += 4) {
+                        const int bs = orc_bs_pair(intra_slice, cur_mv, cur_cbf, mv + 2 * (((y0 >> 3) + (j >> 3) - 1) * w8 + (x0 >> 3) + (i >> 3)),
+                                                   cbf[(y4 + (j >> 2) - 1) * w4 + x4 + (i >> 2)], 0);
+                        if (bs) horizontal_bs[((x0 + i) + (y0 + j) * bsw) >> 2] = (uint8_t)bs;
+                    }
+            if ((x0 & 7) == 0 && x0 != 0)                                           /* :449-474 */
+                for (int i = 0; i < size; i += 4) {
+                    const int bs = orc_bs_pair(intra_slice, cur_mv, cur_cbf, mv + 2 * (((y0 >> 3) + (i >> 3)) * w8 + (x0 >> 3) - 1),
+                                               cbf[(y4 + (i >> 2)) * w4 + x4 - 1], 1);
+                    if (bs) vertical_bs[(x0 >> 3) + ((y0 + i) >> 2) * bsw] = (uint8_t)bs;
+                }
+            if (inner)                                                              /* :478-502 */
+                for (int j = 0; j < size; j += 4)
+                    for (int i = 8; i < size; i += 8) {
+                        const int bs = orc_bs_pair(intra_slice, cur_mv, cur_cbf, mv + 2 * (((y0 >> 3) + (j >> 3)) * w8 + (x0 >> 3) + (i >> 3) - 1),
+                                                   cbf[(y4 + (j >> 2)) * w4 + x4 + (i >> 2) - 1], 0);
+                        if (bs) vertical_bs[((x0 + i) >> 3) + ((y0 + j) >> 2) * bsw] = (uint8_t)bs;
+                    }
+        }
+}

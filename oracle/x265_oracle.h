@@ -159,6 +159,18 @@ typedef struct {
 void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_params *p, const uint8_t *vertical_bs,
                        const uint8_t *horizontal_bs, const uint8_t *qp_tab);
 
+/* Boundary strengths of a whole picture from picture-level maps: what the per-unit calls of
+ * ff_hevc_deblocking_boundary_strengths (src/Deblock.cpp:369-503, boundary_strength :344-366; called from xEncWriteCU,
+ * src/encode.cpp:4885, 4904) leave in vertical_bs / horizontal_bs once every CTU is coded. A unit is the square the
+ * reference makes one call for (a CU, or one 32x32 quarter of a coded 64x64 CU); unit_log2 holds its log2 size and cbf
+ * its luma cbf flag at every 4x4 position (width/4 per row), mv the motion vector of every 8x8 block (width/8 per row,
+ * x then y). "Current" is always the unit's top-left entry, as in the reference. Unit edges on the 8x8 grid: 2 in I
+ * slices, else 1 if either side has coefficients, else 1 if the vectors differ by 4 or more in a component; edges inside
+ * a unit (every 8 samples, P slices only): the vector test alone; nothing on the picture's top and left border.
+ * Both arrays are written in full: (width/8) * (height/4) entries each, indexed as orc_deblock_frame reads them. */
+void orc_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf,
+                           const int16_t *mv, uint8_t *vertical_bs, uint8_t *horizontal_bs);
+
 /* calcSaoStatsCu (src/encode.cpp:364-622) for one CTU of one component plane: per SAO type (0..3 = edge offset
  * classes EO_0..EO_3, 4 = band offset) and category, the number of samples and the sum of (original - reconstructed)
  * over the CTU's window: the bottom 4 (chroma 2) rows and the right 5 (chroma 3) columns are left out unless the CTU

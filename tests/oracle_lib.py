@@ -65,6 +65,8 @@ def load():
     lib.orc_sao_apply_plane.argtypes = [vp, i, vp, i, i, i, i, vp]
     lib.orc_sao_stats_ctu.restype = None
     lib.orc_sao_stats_ctu.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, vp]
+    lib.orc_deblock_strengths.restype = None
+    lib.orc_deblock_strengths.argtypes = [i, i, i, vp, vp, vp, vp, vp]
     lib.orc_deblock_frame.restype = None
     lib.orc_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(OrcDeblockParams), vp, vp, vp]
     lib.orc_pred_inter_chroma.restype = None

@@ -113,3 +113,69 @@ def test_frame_padding_replicates_the_border(L, w, h, pad):
     np.testing.assert_array_equal(buf[:, :w + 2 * pad], want)
     assert (buf[:, w + 2 * pad:] == 123).all()
     assert L.xmi_frame_padding_dev(d.data_ptr(), w, w, h, pad, None) == -1
+
+
+def test_boundary_strengths_replay_encoder_trace(L):
+    """xmi_deblock_strengths_dev / xmi_deblock_strengths from the picture-level maps recorded in bit-identical encodes
+    (tests/golden/bs_trace.npz): the vertical_bs / horizontal_bs arrays the reference's per-unit calls had filled."""
+    g = np.load(os.path.join(GOLDEN, "bs_trace.npz"))
+    for t in g["tags"]:
+        w, h, slice_ = (int(v) for v in g[f"{t}_meta"])
+        intra = int(slice_ == 2)
+        lg, cbf, mv = (np.ascontiguousarray(g[f"{t}_{k}"]) for k in ("unit_log2", "cbf", "mv"))
+        n = (w // 8) * (h // 4)
+        d_lg, d_cbf, d_mv = (torch.from_numpy(a).cuda() for a in (lg, cbf, mv))
+        d_v = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        d_h = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        capi.check(L.xmi_deblock_strengths_dev(w, h, intra, d_lg.data_ptr(), d_cbf.data_ptr(), None if intra else d_mv.data_ptr(), d_v.data_ptr(),
+                                               d_h.data_ptr(), None))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(d_v.cpu().numpy(), g[f"{t}_vbs"], err_msg=f"{t}: vertical edges")
+        np.testing.assert_array_equal(d_h.cpu().numpy(), g[f"{t}_hbs"], err_msg=f"{t}: horizontal edges")
+        vbs, hbs = np.full(n, 9, np.uint8), np.full(n, 9, np.uint8)
+        capi.check(L.xmi_deblock_strengths(w, h, intra, O.p(lg), O.p(cbf), O.p(mv), O.p(vbs), O.p(hbs)))
+        np.testing.assert_array_equal(vbs, g[f"{t}_vbs"])
+        np.testing.assert_array_equal(hbs, g[f"{t}_hbs"])
+
+
+@pytest.mark.parametrize("w,h,intra,seed", [(1920, 1088, 0, 1), (1920, 1088, 1, 2), (200, 72, 0, 3)])
+def test_boundary_strengths_match_oracle(L, w, h, intra, seed):
+    """Random quad-tree partitions (units of 4..64 aligned to their size, 32x32 quarters included), random cbf flags and a
+    motion field with small and large steps between units, and inside units too (which the reference's decisions never
+    produce but its code handles), against orc_deblock_strengths; picture sizes off the CTU grid included."""
+    orc = O.load()
+    rng = np.random.default_rng(seed)
+    lg = np.zeros((h // 4, w // 4), np.uint8)
+    mv = np.zeros((h // 8, w // 8, 2), np.int16)
+
+    def split(x0, y0, size):
+        if size > 4 and (x0 + size > w or y0 + size > h or (size > (4 if intra else 8) and rng.random() < 0.55)):
+            for dy in (0, size // 2):
+                for dx in (0, size // 2):
+                    if x0 + dx < w and y0 + dy < h:
+                        split(x0 + dx, y0 + dy, size // 2)
+            return
+        lg[y0 // 4:(y0 + size) // 4, x0 // 4:(x0 + size) // 4] = int(np.log2(size))
+        if size >= 8:
+            base = rng.integers(-40, 41, 2)
+            mv[y0 // 8:(y0 + size) // 8, x0 // 8:(x0 + size) // 8] = base
+            if size >= 16 and rng.random() < 0.3:         # a step inside the unit
+                mv[y0 // 8 + 1:(y0 + size) // 8, x0 // 8 + 1:(x0 + size) // 8] += rng.integers(-6, 7, 2).astype(np.int16)
+    for y0 in range(0, h, 64):
+        for x0 in range(0, w, 64):
+            split(x0, y0, 64)
+    assert lg.min() >= 2
+    cbf = (rng.random(lg.shape) < 0.3).astype(np.uint8)
+    n = (w // 8) * (h // 4)
+    want_v, want_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    orc.orc_deblock_strengths(w, h, intra, O.p(lg), O.p(cbf), O.p(mv), O.p(want_v), O.p(want_h))
+    if not intra:
+        assert (want_v == 1).sum() > n // 50 and (want_v == 0).sum() > n // 50
+    d_lg, d_cbf, d_mv = (torch.from_numpy(a).cuda() for a in (lg, cbf, mv))
+    d_v, d_h = torch.full((n,), 9, dtype=torch.uint8, device="cuda"), torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_deblock_strengths_dev(w, h, intra, d_lg.data_ptr(), d_cbf.data_ptr(), d_mv.data_ptr(), d_v.data_ptr(), d_h.data_ptr(), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_v.cpu().numpy(), want_v)
+    np.testing.assert_array_equal(d_h.cpu().numpy(), want_h)
+    assert L.xmi_deblock_strengths_dev(w + 4, h, intra, d_lg.data_ptr(), d_cbf.data_ptr(), d_mv.data_ptr(), d_v.data_ptr(), d_h.data_ptr(), None) == -1
+    assert L.xmi_deblock_strengths_dev(w, h, 0, d_lg.data_ptr(), d_cbf.data_ptr(), None, d_v.data_ptr(), d_h.data_ptr(), None) == -1

@@ -82,6 +82,21 @@ def test_bitstream_identical_with_gpu_deblocking(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_bs")), reason="GPU boundary-strength encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_boundary_strengths(tmp_path, qp, frames):
+    """The reference's encoder with ff_hevc_deblocking_boundary_strengths replaced by a recorder of picture-level maps and
+    one xmi_deblock_strengths per picture (oracle/bs_gpu_hook.cpp; the original is never called, the arrays are poisoned
+    before the library fills them): the reference's own filter then reads GPU-derived strengths, and the stream with its
+    reconstruction hashes is the recorded one."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    got = encode("gpu_bs", yuv, str(tmp_path / "b.265"), w, h, frames, qp)
+    assert got == (want["md5"], want["bytes"])
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_sao")), reason="GPU-SAO encoder not built (make -C oracle trace)")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_sao_statistics(tmp_path, qp, frames):
@@ -168,7 +183,7 @@ def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-service encoders not built (make -C oracle trace)")
-@pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock"))])
+@pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao", "gpu_bs")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock"))])
 def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants):
     """The geometry the headline metric is quoted on (1920x1080, coded 1920x1088, 510 CTUs; generator seed 7): the
     reference's encoder with the GPU motion search / quarter-pel planes / deblocking / SAO statistics writes the stream

@@ -326,3 +326,21 @@ def test_intra_search_replays_encoder_trace(lib, golden_dir, n):
         src, raw = np.ascontiguousarray(g[t + "src"][i]), np.ascontiguousarray(g[t + "raw"][i])
         lib.orc_intra_search(O.p(src), n, O.p(raw), n, int(g[t + "valids"][i]), int(g[t + "strong"][i]), O.p(mpm), 4.7, C.byref(out))
         np.testing.assert_array_equal(np.array(out.satd[:], np.uint32), g[t + "satd"][i], err_msg=f"{n}x{n} search {i}")
+
+
+def test_deblock_strengths_reproduce_encoder_arrays(lib, golden_dir):
+    """orc_deblock_strengths from the picture-level maps recorded in bit-identical encodes (tests/golden/bs_trace.npz,
+    oracle/gen_bs_trace.py: unit sizes incl. 4x4 and 64x64, I and P pictures, QP 32 and 22): the vertical_bs /
+    horizontal_bs arrays the reference's per-unit calls had filled when the picture was complete."""
+    g = np.load(os.path.join(golden_dir, "bs_trace.npz"))
+    seen = set()
+    for t in g["tags"]:
+        w, h, slice_ = (int(v) for v in g[f"{t}_meta"])
+        lg, cbf, mv = (np.ascontiguousarray(g[f"{t}_{k}"]) for k in ("unit_log2", "cbf", "mv"))
+        n = (w // 8) * (h // 4)
+        vbs, hbs = np.full(n, 9, np.uint8), np.full(n, 9, np.uint8)
+        lib.orc_deblock_strengths(w, h, int(slice_ == 2), O.p(lg), O.p(cbf), O.p(mv), O.p(vbs), O.p(hbs))
+        np.testing.assert_array_equal(vbs, g[f"{t}_vbs"], err_msg=f"{t}: vertical edges")
+        np.testing.assert_array_equal(hbs, g[f"{t}_hbs"], err_msg=f"{t}: horizontal edges")
+        seen |= set(int(v) for v in np.unique(lg)) | {10 + int(v) for v in np.unique(vbs)}
+    assert {2, 3, 4, 5, 6, 10, 11, 12} <= seen        # every unit size and every strength occurs

@@ -191,6 +191,18 @@ for label, dens, val in (("I picture, strength 2 on every edge segment", 1.0, 2)
     print(json.dumps({"kernel": f"deblock 1080p ({label})", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
                       "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
 
+# ---- boundary strengths of a 1080p P picture from picture-level maps (16x16 units, a third with coefficients, a motion
+# field with steps): reads unit size and cbf per 4x4 and a vector per 8x8, writes both strength tables ----
+lgm = torch.full((H // 4, W // 4), 4, dtype=torch.uint8, device="cuda")
+cbm = (torch.rand((H // 16, W // 16), device="cuda", generator=g) < 0.33).to(torch.uint8).repeat_interleave(4, 0).repeat_interleave(4, 1).contiguous()
+mvm = torch.randint(-8, 9, (H // 16, W // 16, 2), device="cuda", generator=g).to(torch.int16).repeat_interleave(2, 0).repeat_interleave(2, 1).contiguous()
+nbs = (W // 8) * (H // 4)
+vb2, hb2 = torch.empty(nbs, dtype=torch.uint8, device="cuda"), torch.empty(nbs, dtype=torch.uint8, device="cuda")
+t = timeit(lambda: capi.check(L.xmi_deblock_strengths_dev(W, H, 0, lgm.data_ptr(), cbm.data_ptr(), mvm.data_ptr(), vb2.data_ptr(), hb2.data_ptr(), s)))
+by = 2 * (W // 4) * (H // 4) + 4 * (W // 8) * (H // 8) + 2 * nbs
+print(json.dumps({"kernel": "deblock_strengths 1080p (P picture)", "ms": round(t * 1e3, 4), "GBps": round(by / t / 1e9, 1),
+                  "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+
 # ---- SAO statistics of a 1080p picture (every CTU and component, five types) ----
 recs = [torch.from_numpy(f0).cuda(), torch.randint(0, 256, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g),
         torch.randint(0, 256, (H // 2, W // 2), dtype=torch.uint8, device="cuda", generator=g)]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU-side work of one 1080p P picture as ONE captured HIP graph: quarter-pel planes of the previous reconstruction,
 (optionally) the SAD surface, a picture's worth of motion searches, the prediction blocks of every PU (luma + both
-chroma planes), the transform chains of every TU, then the in-loop filters on a reconstructed picture (deblocking,
+chroma planes), the transform chains of every TU, then the in-loop filters on a reconstructed picture (boundary strengths from decision maps, deblocking,
 SAO statistics, SAO offsets) and the border padding, all device-resident, requests and decisions synthetic. It measures what a host
 CTU loop would have to keep fed - the decisions themselves (MVPs, splits, modes) are the host's and are given here.
 Prints one JSON line per variant."""
@@ -90,8 +90,11 @@ sao_y, sao_u, sao_v = torch.zeros_like(rec_pad), torch.zeros_like(rec_u), torch.
 org_u = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda")
 org_v = torch.randint(100, 140, (H // 2, W // 2), dtype=torch.uint8, device="cuda")
 tab = (W // 4) * (H // 4)
-vbs = ((torch.rand(tab, device="cuda") < 0.33) * 1).to(torch.uint8)
-hbs = ((torch.rand(tab, device="cuda") < 0.33) * 1).to(torch.uint8)
+vbs, hbs = torch.zeros(tab, dtype=torch.uint8, device="cuda"), torch.zeros(tab, dtype=torch.uint8, device="cuda")
+# decision maps the boundary strengths are derived from: 16x16 units, a third with coefficients, a motion field with steps
+unit_map = torch.full((H // 4, W // 4), 4, dtype=torch.uint8, device="cuda")
+cbf_map = (torch.rand((H // 16, W // 16), device="cuda") < 0.33).to(torch.uint8).repeat_interleave(4, 0).repeat_interleave(4, 1).contiguous()
+mv_map = torch.randint(-8, 9, (H // 16, W // 16, 2), device="cuda").to(torch.int16).repeat_interleave(2, 0).repeat_interleave(2, 1).contiguous()
 qpt = torch.full((tab,), 32, dtype=torch.uint8, device="cuda")
 dbp = capi.DeblockParams(W, H, stride, cstride, 0, 0, 0, 0)
 sgeo = capi.SaoGeom(W, H, stride, cstride, W, W // 2)
@@ -104,6 +107,7 @@ y00, u00, v00 = PAD * stride + PAD, cpad * cstride + cpad, cpad * cstride + cpad
 
 
 def filters(stream):
+    capi.check(L.xmi_deblock_strengths_dev(W, H, 0, unit_map.data_ptr(), cbf_map.data_ptr(), mv_map.data_ptr(), vbs.data_ptr(), hbs.data_ptr(), stream))
     capi.check(L.xmi_deblock_frame_dev(rec_pad.data_ptr() + y00, rec_u.data_ptr() + u00, rec_v.data_ptr() + v00, C.byref(dbp), vbs.data_ptr(),
                                        hbs.data_ptr(), qpt.data_ptr(), stream))
     capi.check(L.xmi_sao_stats_dev(C.byref(sgeo), rec_pad.data_ptr() + y00, rec_u.data_ptr() + u00, rec_v.data_ptr() + v00, cur.data_ptr(),
@@ -163,6 +167,6 @@ for surface in (False, True):
     torch.cuda.synchronize()
     t_eager = a.elapsed_time(b) / iters
     print(json.dumps({"pipeline": "1080p P picture: planes" + (" + SAD surface (R=64)" if surface else "") + f" + {nreq} motion searches"
-                      + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains + deblocking + SAO statistics and offsets + padding",
+                      + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains + boundary strengths + deblocking + SAO statistics and offsets + padding",
                       "ms_graph": round(t_graph, 3), "ms_eager": round(t_eager, 3), "pictures_per_s_graph": round(1e3 / t_graph, 1),
                       "coded_levels_nonzero_tus": int((sum_y != 0).sum().item())}))

@@ -135,6 +135,11 @@ def load():
         L.xmi_deblock_frame_dev.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp, vp]
         L.xmi_deblock_frame.restype = i
         L.xmi_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp]
+    if hasattr(L, "xmi_deblock_strengths_dev"):
+        L.xmi_deblock_strengths_dev.restype = i
+        L.xmi_deblock_strengths_dev.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
+        L.xmi_deblock_strengths.restype = i
+        L.xmi_deblock_strengths.argtypes = [i, i, i, vp, vp, vp, vp, vp]
     if hasattr(L, "xmi_pred_inter_batch_dev"):
         L.xmi_pred_inter_batch_dev.restype = i
         L.xmi_pred_inter_batch_dev.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp]

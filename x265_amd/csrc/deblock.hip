@@ -180,9 +180,90 @@ __global__ void __launch_bounds__(256) deblock_horizontal_kernel(const DbParams 
     }
 }
 
+// ---- boundary strengths of a picture from picture-level maps ----
+// What the reference's per-unit calls of ff_hevc_deblocking_boundary_strengths (src/Deblock.cpp:369-503) leave in
+// vertical_bs / horizontal_bs, computed per edge segment instead of per unit: the segment looks up the unit it lies in
+// (units are aligned to their size), takes that unit's top-left motion vector and cbf as "current" (as the reference
+// does, :403, :409) and the 8x8 / 4x4 entry across the edge as neighbour. boundary_strength (:344-366): on a unit edge 2
+// in I slices, else 1 if either cbf is set; otherwise (and on the 8-sample grid inside a unit, P slices only) 1 if the
+// vectors differ by 4 or more in a component. Nothing on the picture's left and top border.
+struct BsParams {
+    const uint8_t *unit_log2, *cbf;
+    const short2 *mv;
+    uint8_t *vbs, *hbs;
+    int width, height, intra;
+};
+
+__global__ void __launch_bounds__(256) deblock_strengths_kernel(const BsParams p)
+{
+    const int w4 = p.width >> 2, w8 = p.width >> 3;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= w8 * (p.height >> 2)) return;
+    const bool vertical = blockIdx.y == 0;
+    // vertical: entry ex + sy * w8 is the segment at x = 8 ex, y = 4 sy; horizontal: entry x4 + ey * w4 at x = 4 x4, y = 8 ey
+    const int x = vertical ? 8 * (t % w8) : 4 * (t % w4), y = vertical ? 4 * (t / w8) : 8 * (t / w4);
+    int bs = 0;
+    const int lg = p.unit_log2[(y >> 2) * w4 + (x >> 2)];
+    if ((vertical ? x : y) > 0 && lg >= 2) {
+        const int size = 1 << min(lg, 30), x0 = x & ~(size - 1), y0 = y & ~(size - 1);
+        const bool unit_edge = vertical ? x == x0 : y == y0;
+        if (unit_edge || (lg > 2 && !p.intra)) {
+            const int cur_cbf = p.cbf[(y0 >> 2) * w4 + (x0 >> 2)];
+            const int nb_cbf = vertical ? p.cbf[(y >> 2) * w4 + (x >> 2) - 1] : p.cbf[((y >> 2) - 1) * w4 + (x >> 2)];
+            if (unit_edge && p.intra) bs = 2;
+            else if (unit_edge && (cur_cbf || nb_cbf)) bs = 1;
+            else if (!p.intra) {
+                const short2 cur = p.mv[(y0 >> 3) * w8 + (x0 >> 3)];
+                const short2 nb = vertical ? p.mv[(y >> 3) * w8 + (x >> 3) - 1] : p.mv[((y >> 3) - 1) * w8 + (x >> 3)];
+                bs = abs(nb.x - cur.x) >= 4 || abs(nb.y - cur.y) >= 4;
+            }
+        }
+    }
+    (vertical ? p.vbs : p.hbs)[t] = (uint8_t)bs;
+}
+
 }  // namespace
 
 extern "C" {
+
+int xmi_deblock_strengths_dev(int width, int height, int intra_slice, const uint8_t *d_unit_log2, const uint8_t *d_cbf, const int16_t *d_mv,
+                              uint8_t *d_vertical_bs, uint8_t *d_horizontal_bs, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(width >= 16 && height >= 16 && width % 8 == 0 && height % 8 == 0, "xmi_deblock_strengths_dev: picture %dx%d must be a multiple of 8, at least 16x16",
+            width, height);
+    XMI_ARG(d_unit_log2 && d_cbf && d_vertical_bs && d_horizontal_bs && (intra_slice || d_mv), "xmi_deblock_strengths_dev: null argument");
+    XMI_ARG(((uintptr_t)d_mv & 3) == 0, "xmi_deblock_strengths_dev: motion vectors must be 4-byte aligned");
+    BsParams p = { d_unit_log2, d_cbf, reinterpret_cast<const short2 *>(d_mv), d_vertical_bs, d_horizontal_bs, width, height, intra_slice ? 1 : 0 };
+    const int n = (width / 8) * (height / 4);
+    hipLaunchKernelGGL(deblock_strengths_kernel, dim3((n + 255) / 256, 2), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
+int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                          uint8_t *vertical_bs, uint8_t *horizontal_bs)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(width >= 16 && height >= 16 && width % 8 == 0 && height % 8 == 0, "xmi_deblock_strengths: picture %dx%d must be a multiple of 8, at least 16x16", width,
+            height);
+    XMI_ARG(unit_log2 && cbf && vertical_bs && horizontal_bs && (intra_slice || mv), "xmi_deblock_strengths: null argument");
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
+    const size_t n4 = (size_t)(width / 4) * (height / 4), n8 = (size_t)(width / 8) * (height / 8), nbs = (size_t)(width / 8) * (height / 4);
+    const size_t off_cbf = n4, off_mv = (2 * n4 + 15) & ~(size_t)15, off_v = off_mv + 4 * n8, off_h = off_v + nbs;
+    uint8_t *d = static_cast<uint8_t *>(xmi::scratch(10, off_h + nbs));
+    if (!d) return XMI_ERR_HIP;
+    XMI_HIP(hipMemcpy(d, unit_log2, n4, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_cbf, cbf, n4, hipMemcpyHostToDevice));
+    if (!intra_slice) XMI_HIP(hipMemcpy(d + off_mv, mv, 4 * n8, hipMemcpyHostToDevice));
+    rc = xmi_deblock_strengths_dev(width, height, intra_slice, d, d + off_cbf, reinterpret_cast<const int16_t *>(d + off_mv), d + off_v, d + off_h, nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy(vertical_bs, d + off_v, nbs, hipMemcpyDeviceToHost));
+    XMI_HIP(hipMemcpy(horizontal_bs, d + off_h, nbs, hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
 
 int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_deblock_params *prm, const uint8_t *d_vertical_bs,
                           const uint8_t *d_horizontal_bs, const uint8_t *d_qp_tab, void *stream)
