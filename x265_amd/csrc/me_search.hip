@@ -24,6 +24,7 @@
 namespace {
 
 typedef unsigned int u32;
+struct __attribute__((aligned(4))) dword_pair { u32 x, y; };      // an 8-byte access that is only dword-aligned
 
 struct MeParams {
     const uint8_t *cur;
@@ -58,15 +59,32 @@ __device__ __forceinline__ u32 wave_sum(u32 x)
     return (u32)__builtin_amdgcn_readlane(v, 63);
 }
 
+// sum over each aligned group of 16 lanes (a DPP row), returned in every lane of the group: quad butterflies, then the
+// half-row and row mirrors. Only lanes of the own row are read, so rows may be in different branches of the search.
+__device__ __forceinline__ u32 row_sum(u32 x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);     // quad_perm:[1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);     // quad_perm:[2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);    // row_mirror
+    return (u32)v;
+}
+
 // One search. The reference evaluates its candidates one after the other, but inside each stage they do not
 // depend on each other (only the comparisons do), so a stage's SADs are computed together - all loads of a
 // stage are in flight at once - and the comparisons are then applied in the reference's order.
-template <int N, bool SURF>
-__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int lane)
+// PACK (8x8 only): the block's 16 dwords occupy a quarter of the wavefront, so four searches share one - each row of 16
+// lanes runs its own request (idx, rq and everything derived from them differ per row; the rows diverge where their
+// searches do), and SADs are summed per row.
+template <int N, bool SURF, bool PACK = false>
+__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane)
 {
+    static_assert(!PACK || N == 8, "only 8x8 blocks fit four to a wavefront");
     constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
     constexpr int J = DW < 64 ? 1 : DW / 64;         // block dwords per lane
     constexpr int KC = J == 1 ? 9 : J == 4 ? 4 : 1;  // candidates evaluated together (bounds the registers)
+    const int lane = PACK ? (wave_lane & 15) : wave_lane;
     const bool live = DW >= 64 || lane < DW;
     const size_t plane_bytes = (size_t)p.rows * p.stride;
     const uint8_t *ref0 = p.planes + (size_t)(p.pad + rq.y0) * p.stride + p.pad + rq.x0;   // integer plane at the PU origin
@@ -91,8 +109,9 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
                 const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3) + off0;
 #pragma unroll
                 for (int j = 0; j < J; j++) {
-                    lo[k][j] = live ? *reinterpret_cast<const u32 *>(al + (ptrdiff_t)j * joff) : 0u;
-                    hi[k][j] = (live && sh[k]) ? *reinterpret_cast<const u32 *>(al + (ptrdiff_t)j * joff + 4) : 0u;
+                    const dword_pair w = live ? *reinterpret_cast<const dword_pair *>(al + (ptrdiff_t)j * joff) : dword_pair{ 0u, 0u };
+                    lo[k][j] = w.x;
+                    hi[k][j] = w.y;
                 }
             }
 #pragma unroll
@@ -101,7 +120,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
                 u32 s = 0;
 #pragma unroll
                 for (int j = 0; j < J; j++) s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi[k][j], lo[k][j], sh[k]), cur[j], s);
-                out[k0 + k] = wave_sum(s);
+                out[k0 + k] = PACK ? row_sum(s) : wave_sum(s);
             }
         }
     };
@@ -260,27 +279,55 @@ __device__ __forceinline__ bool request_in_bounds(const MeParams &p, const xmi_m
     return true;
 }
 
+__device__ __forceinline__ int nth_set_bit(unsigned mask, int k)
+{
+    for (int i = 0; i < k; i++) mask &= mask - 1;
+    return __ffs(mask) - 1;
+}
+
+// The grid has two parts. In the first, wavefront i answers request i unless it is an 8x8 search: a refused request
+// is marked, a 16x16 .. 64x64 search runs on the whole wavefront. In the second, a workgroup looks at 16 consecutive
+// requests and packs their 8x8 searches four to a wavefront (one per row of 16 lanes); wavefronts left without work
+// leave at once. A search is a chain of dependent memory round trips, so the time of a batch is set by how many
+// wavefronts it keeps busy, and most requests of a picture are 8x8.
 template <bool SURF>
 __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
 {
-    const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (idx >= p.n) return;
-    const xmi_me_request rq = p.req[idx];
-    if (!request_in_bounds<SURF>(p, rq)) {        // refused: marked, so that the caller can tell
-        if (lane == 0) {
-            xmi_me_result out = {};
-            out.best_cost = out.best_sad = 0xffffffffu;
-            out.mvp_idx = -1;
-            p.res[idx] = out;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int single_blocks = (p.n + 3) >> 2;
+    if ((int)blockIdx.x < single_blocks) {
+        const int idx = blockIdx.x * 4 + wave;
+        if (idx >= p.n) return;
+        const xmi_me_request rq = p.req[idx];
+        if (!request_in_bounds<SURF>(p, rq)) {        // refused: marked, so that the caller can tell
+            if (lane == 0) {
+                xmi_me_result out = {};
+                out.best_cost = out.best_sad = 0xffffffffu;
+                out.mvp_idx = -1;
+                p.res[idx] = out;
+            }
+            return;
+        }
+        switch (rq.size) {
+        case 8: break;                                // second part of the grid
+        case 16: search<16, SURF>(p, rq, idx, lane); break;
+        case 32: search<32, SURF>(p, rq, idx, lane); break;
+        default: search<64, SURF>(p, rq, idx, lane); break;
         }
         return;
     }
-    switch (rq.size) {
-    case 8: search<8, SURF>(p, rq, idx, lane); break;
-    case 16: search<16, SURF>(p, rq, idx, lane); break;
-    case 32: search<32, SURF>(p, rq, idx, lane); break;
-    default: search<64, SURF>(p, rq, idx, lane); break;
+    const int base = ((int)blockIdx.x - single_blocks) * 16;
+    bool is8 = false;
+    if (lane < 16 && base + lane < p.n) {
+        const xmi_me_request rq = p.req[base + lane];
+        is8 = rq.size == 8 && request_in_bounds<SURF>(p, rq);
+    }
+    const unsigned m8 = (unsigned)__ballot(is8);
+    const int n8 = __popc(m8), mine = 4 * wave + (lane >> 4);      // the row's request among the 8x8 ones of the 16
+    if (mine < n8) {
+        const int idx = base + nth_set_bit(m8, mine);
+        const xmi_me_request rq = p.req[idx];
+        search<8, SURF, true>(p, rq, idx, lane);
     }
 }
 
@@ -307,7 +354,7 @@ extern "C" int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, con
     rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, pad, d_req, me_range, d_res);
     if (rc != XMI_OK) return rc;
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
-    hipLaunchKernelGGL(me_search_kernel<false>, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(me_search_kernel<false>, dim3((n + 3) / 4 + (n + 15) / 16), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
@@ -330,7 +377,7 @@ extern "C" int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_str
             g->height, g->range);
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, d_sad8, d_sad16, d_sad32, d_sad64,
                    g->range, g->width / 64, (g->width / 64) * (g->height / 64) };
-    hipLaunchKernelGGL(me_search_kernel<true>, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(me_search_kernel<true>, dim3((n + 3) / 4 + (n + 15) / 16), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
