@@ -1,0 +1,43 @@
+import ctypes as C, json, math, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench as B
+from x265_amd import capi
+L = capi.load(); capi.check(L.xmi_init(0))
+W, H, PAD = 1920, 1088, 80
+f0, f1 = B.synth_frame(W, H, 0, 7), B.synth_frame(W, H, 1, 7)
+ref = torch.from_numpy(B.pad_frame(f0, PAD)).cuda(); cur = torch.from_numpy(f1).cuda()
+rows, stride = ref.shape
+planes = torch.zeros((16, rows, stride), dtype=torch.uint8, device="cuda")
+s = torch.cuda.current_stream().cuda_stream
+capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, rows, stride, planes.data_ptr(), s))
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3
+rng = np.random.default_rng(3)
+CASES = ((8, 28000), (8, 7000), (8, 1000), (8, 64), (64, 600), (64, 16), (16, 9500))
+if os.environ.get('ME_PROBE_ONLY'): CASES = (CASES[int(os.environ['ME_PROBE_ONLY'])],)
+for size, nreq in CASES:
+    reqs = (capi.MeRequest * nreq)()
+    for i in range(nreq):
+        rq = reqs[i]; n = size; rq.size = n
+        rq.x0 = int(rng.integers(0, (W - n) // 8 + 1)) * 8; rq.y0 = int(rng.integers(0, (H - n) // 8 + 1)) * 8
+        rq.mvp[0][0], rq.mvp[0][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+        rq.mvp[1][0], rq.mvp[1][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
+        rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+        rq.sqrt_lambda = int(math.sqrt(0.578 * 2 ** ((22 - 12) / 3.0)))
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+    out = {}
+    for mr in (32, 4, 0):
+        out[f"us_range{mr}"] = round(timeit(lambda: capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_req.data_ptr(), nreq, mr, d_res.data_ptr(), s))), 1)
+    capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_req.data_ptr(), nreq, 32, d_res.data_ptr(), s)); torch.cuda.synchronize()
+    res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
+    ni = np.array([r.n_int_sads for r in res])
+    print(json.dumps({"size": size, "n": nreq, **out, "int_sads_mean": round(float(ni.mean()), 1), "int_sads_max": int(ni.max()), "p99": int(np.percentile(ni, 99))}))
+empty = torch.zeros(1, device="cuda")
+print("empty-kernel us", round(timeit(lambda: empty.add_(1)), 1))

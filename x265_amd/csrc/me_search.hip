@@ -1,6 +1,6 @@
 // Batched replay of the reference's xMotionSearch (src/encode.cpp:2815-3003) on gfx950.
 //
-// One wavefront per search request. The control flow is the reference's, statement for statement (MV_CLIP = 1,
+// One wavefront per 16x16 .. 64x64 search request, four 8x8 requests per wavefront. The control flow is the reference's, statement for statement (MV_CLIP = 1,
 // MVD_COST_BY_TABLE = 0, SATD_FOR_FRAC_ME = 0): pick the better of two MV predictors by the SAD of its
 // interpolated block; test (0,0) unless the caller already did; test the predictor's integer position; walk a
 // small diamond for at most ME_RANGE steps with first-improvement-wins order, stopping when nothing improves
@@ -11,7 +11,12 @@
 // with v_alignbyte_b32, DPP wavefront reduction); sub-pel predictions are lookups in the interpolation planes
 // (interp_planes.hip), which hold exactly what xPredInterLumaBlk would compute. The SADs of one stage (the two
 // predictors + (0,0) + both possible start points; the 4 diamond points; the 9 sub-pel points) are independent
-// and are evaluated together, so a search is about 8 dependent memory round trips instead of 28.
+// and are evaluated together, so a search is about 8 dependent memory round trips instead of 28; the diamond walk
+// reads a window of the reference that it keeps in LDS.
+// What a batch costs (measured with the hardware counters on 28 000 8x8 searches): the wavefronts issue vector
+// instructions a quarter of the time and the chip holds about one wavefront per SIMD on average - the time goes with
+// the cache lines the candidates pull in. A candidate row of 8..64 samples is one 128-byte line, the 9 sub-pel
+// candidates of a round lie in up to 9 different planes, so a search touches ~180 lines for 1.5 KB of samples.
 //
 // With a resident SAD surface of the picture pair (sad_surface.hip) the integer candidates are not computed at
 // all: SAD(PU, integer MV) is element [ctu][blk][dy][dx] of the surface, because the surface's windows are
@@ -78,7 +83,7 @@ __device__ __forceinline__ u32 row_sum(u32 x)
 // lanes runs its own request (idx, rq and everything derived from them differ per row; the rows diverge where their
 // searches do), and SADs are summed per row.
 template <int N, bool SURF, bool PACK = false>
-__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane)
+__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win)
 {
     static_assert(!PACK || N == 8, "only 8x8 blocks fit four to a wavefront");
     constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
@@ -87,7 +92,6 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     const int lane = PACK ? (wave_lane & 15) : wave_lane;
     const bool live = DW >= 64 || lane < DW;
     const size_t plane_bytes = (size_t)p.rows * p.stride;
-    const uint8_t *ref0 = p.planes + (size_t)(p.pad + rq.y0) * p.stride + p.pad + rq.x0;   // integer plane at the PU origin
     u32 cur[J];
     // the lane's dwords: d = lane + 64 j -> row lane / DPR + j * (64 / DPR), column dword lane % DPR
     const int row0 = live ? lane / DPR : 0, c40 = live ? lane % DPR : 0;
@@ -96,7 +100,8 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     for (int j = 0; j < J; j++)
         cur[j] = live ? *reinterpret_cast<const u32 *>(p.cur + (size_t)(rq.y0 + row0 + j * (64 / DPR)) * p.cur_stride + rq.x0 + c40 * 4) : 0u;
     // SADs of COUNT candidate blocks (top-left pointers, any byte alignment) against the current block
-    auto eval = [&](auto count_tag, const uint8_t *const *cand, u32 *out) {
+    // (candidates are byte offsets into the plane buffer: 32-bit arithmetic, and loads of the form uniform base + lane offset)
+    auto eval = [&](auto count_tag, const u32 *cand, u32 *out) {
         constexpr int COUNT = decltype(count_tag)::value;
 #pragma unroll
         for (int k0 = 0; k0 < COUNT; k0 += KC) {
@@ -104,12 +109,12 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
 #pragma unroll
             for (int k = 0; k < KC; k++) {
                 if (k0 + k >= COUNT) continue;
-                const uintptr_t a = reinterpret_cast<uintptr_t>(cand[k0 + k]);
-                sh[k] = (u32)(a & 3);
-                const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3) + off0;
+                const u32 a = cand[k0 + k];
+                sh[k] = a & 3u;
+                const u32 al = (a & ~3u) + (u32)off0;
 #pragma unroll
                 for (int j = 0; j < J; j++) {
-                    const dword_pair w = live ? *reinterpret_cast<const dword_pair *>(al + (ptrdiff_t)j * joff) : dword_pair{ 0u, 0u };
+                    const dword_pair w = live ? *reinterpret_cast<const dword_pair *>(p.planes + (al + (u32)(j * joff))) : dword_pair{ 0u, 0u };
                     lo[k][j] = w.x;
                     hi[k][j] = w.y;
                 }
@@ -124,8 +129,46 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
             }
         }
     };
-    auto qpel = [&](int mx, int my) { return ref0 + ((my & 3) * 4 + (mx & 3)) * plane_bytes + (ptrdiff_t)(my >> 2) * p.stride + (mx >> 2); };
-    auto ipel = [&](int x, int y) { return ref0 + (ptrdiff_t)y * p.stride + x; };
+    const u32 ref_off = (u32)((p.pad + rq.y0) * p.stride + p.pad + rq.x0), plane_u32 = (u32)plane_bytes;
+    auto qpel = [&](int mx, int my) { return ref_off + (u32)((my & 3) * 4 + (mx & 3)) * plane_u32 + (u32)((my >> 2) * p.stride + (mx >> 2)); };
+    auto ipel = [&](int x, int y) { return ref_off + (u32)(y * p.stride + x); };
+    // ---- reference window in LDS for the diamond walk (kernels without a SAD surface) ----
+    // A walk is a chain of up to me_range dependent steps, and read from memory every step is a round trip. The window
+    // holds the (N + 2 WR)^2 samples around a centre, enough for WR steps in any direction; steps inside it cost LDS
+    // reads only, and the walk reloads it around its current position when it reaches the rim. Rows are WP bytes apart
+    // and start at the dword that holds the window's first sample (offset win_sh into it); dwords outside the plane
+    // buffer are not read (no candidate lies there).
+    constexpr int WR = 8, WH = N + 2 * WR, WP = N + 2 * WR + 8, WPD = WP / 4, GL = PACK ? 16 : 64;
+    int win_cx = 0, win_cy = 0, win_sh = 0;
+    bool win_ok = false;
+    auto win_load = [&](int cx, int cy) {
+        const int gy0 = p.pad + rq.y0 + cy - WR, gx = p.pad + rq.x0 + cx - WR, gxb = gx & ~3;
+        __builtin_amdgcn_wave_barrier();      // reads of the previous window are done
+        for (int e = lane; e < WH * WPD; e += GL) {
+            const int r = e / WPD, c = e - r * WPD, y = gy0 + r, x = gxb + 4 * c;
+            u32 v = 0;
+            if (y >= 0 && y < p.rows && x >= 0 && x + 4 <= p.stride) v = *reinterpret_cast<const u32 *>(p.planes + (size_t)y * p.stride + x);
+            reinterpret_cast<u32 *>(s_win)[e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        win_cx = cx;
+        win_cy = cy;
+        win_sh = gx & 3;
+        win_ok = true;
+    };
+    auto win_has = [&](int cx, int cy, int x, int y) { return abs(x - cx) <= WR && abs(y - cy) <= WR; };
+    auto win_sad = [&](int x, int y) -> u32 {
+        const int bo = x - win_cx + WR + win_sh, d0 = (bo >> 2) + c40;
+        const u32 sh = (u32)(bo & 3);
+        const u32 *row = reinterpret_cast<const u32 *>(s_win) + (y - win_cy + WR + row0) * WPD + d0;
+        u32 acc = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const u32 *q = row + j * (64 / DPR) * WPD;
+            acc = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(q[1], q[0], sh), cur[j], acc);
+        }
+        return PACK ? row_sum(acc) : wave_sum(acc);
+    };
     const u32 lam = rq.sqrt_lambda;
     // surface coordinates of this PU (wave-uniform)
     constexpr int LEVEL = N == 8 ? 0 : N == 16 ? 1 : N == 32 ? 2 : 3;
@@ -143,7 +186,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     u32 s5[5];
     {
         const int ax = rq.mvp[0][0] >> 2, ay = rq.mvp[0][1] >> 2, bx = rq.mvp[1][0] >> 2, by = rq.mvp[1][1] >> 2;
-        const uint8_t *c[5] = { qpel(rq.mvp[0][0], rq.mvp[0][1]), qpel(rq.mvp[1][0], rq.mvp[1][1]), ipel(0, 0), ipel(ax, ay), ipel(bx, by) };
+        const u32 c[5] = { qpel(rq.mvp[0][0], rq.mvp[0][1]), qpel(rq.mvp[1][0], rq.mvp[1][1]), ipel(0, 0), ipel(ax, ay), ipel(bx, by) };
         if (on_tree && in_window(ax, ay) && in_window(bx, by)) {
             eval(std::integral_constant<int, 2>{}, c, s5);
             s5[2] = surf(0, 0);
@@ -182,7 +225,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     const int dia4x[4] = { 0, 0, -1, 1 }, dia4y[4] = { -1, 1, 0, 0 };
     for (int i = 0; i < p.me_range; i++) {
         int tx[4], ty[4];
-        const uint8_t *c[4];
+        u32 c[4];
         u32 s4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -193,8 +236,19 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         if (on_tree && in_window(tx[0], ty[0]) && in_window(tx[1], ty[1]) && in_window(tx[2], ty[2]) && in_window(tx[3], ty[3])) {
 #pragma unroll
             for (int k = 0; k < 4; k++) s4[k] = surf(tx[k], ty[k]);
-        } else {
+        } else if (SURF) {
             eval(std::integral_constant<int, 4>{}, c, s4);
+        } else {
+            auto all_in = [&](int cx, int cy) {
+                return win_has(cx, cy, tx[0], ty[0]) && win_has(cx, cy, tx[1], ty[1]) && win_has(cx, cy, tx[2], ty[2]) && win_has(cx, cy, tx[3], ty[3]);
+            };
+            if (!(win_ok && all_in(win_cx, win_cy)) && all_in(omx, omy)) win_load(omx, omy);
+            if (win_ok && all_in(win_cx, win_cy)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) s4[k] = win_sad(tx[k], ty[k]);
+            } else {      // the clip box keeps the candidates away from the walk's position
+                eval(std::integral_constant<int, 4>{}, c, s4);
+            }
         }
         bool changed = false;
 #pragma unroll
@@ -225,7 +279,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     int step = 2;
     for (int i = 0; i < 2; i++) {
         int tx[9], ty[9];
-        const uint8_t *c[9];
+        u32 c[9];
         u32 s9[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
@@ -293,7 +347,11 @@ __device__ __forceinline__ int nth_set_bit(unsigned mask, int k)
 template <bool SURF>
 __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
 {
+    // reference windows of the diamond walks: one per wavefront, or four small ones (one per row of 16 lanes)
+    constexpr int kWinBytes = (64 + 16) * (64 + 24);
+    __shared__ __align__(16) uint8_t s_win[SURF ? 1 : 4][SURF ? 16 : kWinBytes];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t *win = s_win[SURF ? 0 : wave];
     const int single_blocks = (p.n + 3) >> 2;
     if ((int)blockIdx.x < single_blocks) {
         const int idx = blockIdx.x * 4 + wave;
@@ -310,9 +368,9 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
         }
         switch (rq.size) {
         case 8: break;                                // second part of the grid
-        case 16: search<16, SURF>(p, rq, idx, lane); break;
-        case 32: search<32, SURF>(p, rq, idx, lane); break;
-        default: search<64, SURF>(p, rq, idx, lane); break;
+        case 16: search<16, SURF>(p, rq, idx, lane, win); break;
+        case 32: search<32, SURF>(p, rq, idx, lane, win); break;
+        default: search<64, SURF>(p, rq, idx, lane, win); break;
         }
         return;
     }
@@ -327,17 +385,19 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     if (mine < n8) {
         const int idx = base + nth_set_bit(m8, mine);
         const xmi_me_request rq = p.req[idx];
-        search<8, SURF, true>(p, rq, idx, lane);
+        search<8, SURF, true>(p, rq, idx, lane, win + (SURF ? 0 : (lane >> 4) * ((8 + 16) * (8 + 24))));
     }
 }
 
-int check_common(const char *who, const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int pad,
+int check_common(const char *who, const uint8_t *d_cur, int cur_stride, const uint8_t *d_planes, int stride, int rows, int pad,
                  const xmi_me_request *d_req, int me_range, xmi_me_result *d_res)
 {
     XMI_ARG(d_cur && d_planes && d_req && d_res, "%s: null argument", who);
     XMI_ARG(cur_stride % 4 == 0 && ((uintptr_t)d_cur & 3) == 0, "%s: current frame must be 4-byte aligned", who);
     XMI_ARG(stride % 4 == 0 && ((uintptr_t)d_planes & 3) == 0 && pad % 4 == 0, "%s: planes, stride and pad must be multiples of 4", who);
     XMI_ARG(me_range >= 0 && me_range <= 1024, "%s: me_range %d out of range", who, me_range);
+    XMI_ARG(rows > 0 && stride > 0 && (unsigned long long)rows * (unsigned long long)stride * 16ull < (1ull << 31),
+            "%s: 16 planes of %d x %d bytes exceed the 2 GiB the kernel's 32-bit offsets cover", who, rows, stride);
     return XMI_OK;
 }
 
@@ -351,7 +411,7 @@ extern "C" int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, con
     if (rc != XMI_OK) return rc;
     XMI_ARG(n >= 0, "xmi_me_search_batch_dev: negative request count");
     if (n == 0) return XMI_OK;
-    rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, pad, d_req, me_range, d_res);
+    rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, rows, pad, d_req, me_range, d_res);
     if (rc != XMI_OK) return rc;
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
     hipLaunchKernelGGL(me_search_kernel<false>, dim3((n + 3) / 4 + (n + 15) / 16), dim3(256), 0, xmi::as_stream(stream), p);
@@ -368,7 +428,7 @@ extern "C" int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_str
     if (rc != XMI_OK) return rc;
     XMI_ARG(n >= 0, "xmi_me_search_surface_batch_dev: negative request count");
     if (n == 0) return XMI_OK;
-    rc = check_common("xmi_me_search_surface_batch_dev", d_cur, cur_stride, d_planes, stride, pad, d_req, me_range, d_res);
+    rc = check_common("xmi_me_search_surface_batch_dev", d_cur, cur_stride, d_planes, stride, rows, pad, d_req, me_range, d_res);
     if (rc != XMI_OK) return rc;
     XMI_ARG(g && d_sad8 && d_sad16 && d_sad32 && d_sad64, "xmi_me_search_surface_batch_dev: null surface");
     XMI_ARG(g->width > 0 && g->height > 0 && g->width % 64 == 0 && g->height % 64 == 0 &&
