@@ -165,7 +165,10 @@ int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8
  * (src/pixel.cpp:9657-9703, 4-tap, the same MV numbers read as eighth-pel) write for one PU, for a batch of PUs
  * straight from the padded reconstruction on the device (d_ref_* = pixel (0,0) of each plane). Blocks are written
  * packed (rows `size` resp. `size`/2 bytes apart) at the byte offsets the request names, ready to be the `pred`
- * input of xmi_tu_chain_batch_dev. A null d_pred_y skips luma, null d_pred_u / d_pred_v skip that chroma plane. */
+ * input of xmi_tu_chain_batch_dev. A null d_pred_y skips luma, null d_pred_u / d_pred_v skip that chroma plane.
+ * A block's filter window is the samples the reference's filters read (none beyond the block when a fraction is 0);
+ * with strides that are multiples of 4 it is fetched as the aligned dwords that contain it, i.e. up to 3 bytes more on
+ * either side of every window row. */
 typedef struct xmi_inter_pred_request {
     int32_t x0, y0, size;         /* luma PU origin and size (8/16/32/64); chroma blocks are size/2 at (x0/2, y0/2) */
     int16_t mv[2];                /* quarter-pel luma MV */

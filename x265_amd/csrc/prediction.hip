@@ -1,7 +1,7 @@
 // Inter prediction blocks for gfx950: xPredInterLumaBlk (src/pixel.cpp:8745-8795) and xPredInterChromaBlk
 // (src/pixel.cpp:9657-9703) for a batch of PUs, computed from the reconstruction planes on the device.
 //
-// One workgroup per (request, plane). The block's filter window is staged in LDS; then
+// One wavefront per (request, plane). The block's filter window is staged in LDS; then
 //   no fraction:        copy
 //   x fraction only:    clip((sum_h + 32) >> 6)                    src/pixel.cpp:7705 (luma), :8982 (chroma)
 //   y fraction only:    clip((sum_v + 32) >> 6)                    :8137, :9257
@@ -33,37 +33,63 @@ struct PredParams {
     int stride_y, stride_c, n;
 };
 
-constexpr int kMaxWin = 64 + 7;
+// One wavefront per block and plane: a picture has tens of thousands of small blocks, and a 16x16 luma block (an 8x8
+// chroma block) does not feed more lanes than that. Two instances share the requests by size - MAXBS 16 takes the
+// 8x8 and 16x16 PUs, MAXBS 64 the 32x32 and 64x64 ones - because the LDS a workgroup reserves decides how many of these
+// short-lived workgroups a CU holds at once: 15 KB for a 64x64 window against 1.4 KB for a 16x16 one (a 1080p picture
+// of 16x16 PUs: 27 us with one 256-thread, 15 KB workgroup per block, 15 us this way).
+constexpr int kPredThreads = 64;
 
 __device__ __forceinline__ int clip8(int v) { return min(255, max(0, v)); }
 
+template <int MAXBS>
+struct PredLds {
+    static constexpr int kRows = MAXBS + 7;                          // window rows: block + 7 (8-tap filter)
+    static constexpr int kPitch = (MAXBS + 7 + 3 + 3) & ~3;          // bytes per window row: samples + alignment, a multiple of 4
+    uint8_t win[kRows + 1][kPitch];
+    int16_t h[kRows][MAXBS];
+};
+
 // TAPS = 8 (luma, quarter-pel) or 4 (chroma, eighth-pel)
-template <int TAPS>
-__device__ void predict_block(const uint8_t *ref, int stride, uint8_t *dst, int bs, int xf, int yf, uint8_t (*s_win)[kMaxWin + 1],
-                              int16_t (*s_h)[64])
+template <int TAPS, int MAXBS>
+__device__ void predict_block(const uint8_t *ref, int stride, uint8_t *dst, int bs, int xf, int yf, PredLds<MAXBS> &lds)
 {
     constexpr int B = TAPS / 2 - 1;                     // samples before the block the filter reaches
+    constexpr int PITCH = PredLds<MAXBS>::kPitch;
     const int (*filt)[8] = TAPS == 8 ? k_luma : k_chroma;
     const int tid = threadIdx.x;
     const int c0 = xf ? -B : 0, c1 = xf ? bs + TAPS / 2 : bs;     // window columns [c0, c1) relative to the block
     const int r0 = yf ? -B : 0, r1 = yf ? bs + TAPS / 2 : bs;
     const int wc = c1 - c0, wr = r1 - r0;
-    for (int e = tid; e < wc * wr; e += 256) {
-        const int r = e / wc, c = e - r * wc;
-        s_win[r][c] = ref[(ptrdiff_t)(r0 + r) * stride + c0 + c];
+    const uint8_t *org = ref + (ptrdiff_t)r0 * stride + c0;          // first sample of the window
+    const int sh = (int)(reinterpret_cast<uintptr_t>(org) & 3);
+    if ((stride & 3) == 0) {
+        // the window as aligned dwords: every row starts sh bytes before its first sample (rows stay aligned because the
+        // stride is a multiple of 4); the row pitch in LDS is a multiple of 4 as well
+        const int wd = (wc + sh + 3) >> 2;
+        for (int e = tid; e < wd * wr; e += kPredThreads) {
+            const int r = e / wd, d = e - r * wd;
+            *reinterpret_cast<unsigned *>(&lds.win[r][4 * d]) = *reinterpret_cast<const unsigned *>(org - sh + (ptrdiff_t)r * stride + 4 * d);
+        }
+    } else {
+        for (int e = tid; e < wc * wr; e += kPredThreads) {
+            const int r = e / wc, c = e - r * wc;
+            lds.win[r][sh + c] = org[(ptrdiff_t)r * stride + c];
+        }
     }
     __syncthreads();
+    const uint8_t (*s_win)[PITCH] = reinterpret_cast<const uint8_t (*)[PITCH]>(&lds.win[0][sh]);      // samples start at column sh
     if (xf && yf) {
-        for (int e = tid; e < wr * bs; e += 256) {
+        for (int e = tid; e < wr * bs; e += kPredThreads) {
             const int r = e / bs, x = e - r * bs;
             int s = 0;
 #pragma unroll
             for (int t = 0; t < TAPS; t++) s += (int)s_win[r][x + t] * filt[xf][t];
-            s_h[r][x] = (int16_t)s;
+            lds.h[r][x] = (int16_t)s;
         }
         __syncthreads();
     }
-    for (int e = tid; e < bs * bs; e += 256) {
+    for (int e = tid; e < bs * bs; e += kPredThreads) {
         const int y = e / bs, x = e - y * bs;
         int v;
         if (!xf && !yf) {
@@ -81,28 +107,35 @@ __device__ void predict_block(const uint8_t *ref, int stride, uint8_t *dst, int 
         } else {
             int s = 0;
 #pragma unroll
-            for (int t = 0; t < TAPS; t++) s += (int)s_h[y + t][x] * filt[yf][t];
+            for (int t = 0; t < TAPS; t++) s += (int)lds.h[y + t][x] * filt[yf][t];
             v = clip8((s + 2048) >> 12);
         }
         dst[e] = (uint8_t)v;
     }
 }
 
-__global__ void __launch_bounds__(256) inter_pred_kernel(const PredParams p)
+template <int MAXBS>
+__global__ void __launch_bounds__(kPredThreads) inter_pred_kernel(const PredParams p)
 {
-    __shared__ uint8_t s_win[kMaxWin][kMaxWin + 1];
-    __shared__ int16_t s_h[kMaxWin][64];
+    __shared__ __align__(16) PredLds<MAXBS> lds;
     const int plane = blockIdx.y;
     if (!p.pred[plane]) return;                         // uniform per workgroup
     const xmi_inter_pred_request rq = p.req[blockIdx.x];
-    if (rq.size != 8 && rq.size != 16 && rq.size != 32 && rq.size != 64) return;     // not a PU size: nothing is written
+    // this instance's sizes; anything that is no PU size is written by neither
+    if (MAXBS == 16 ? (rq.size != 8 && rq.size != 16) : (rq.size != 32 && rq.size != 64)) return;
     if (plane == 0) {
         const uint8_t *ref = p.ref[0] + (ptrdiff_t)(rq.y0 + (rq.mv[1] >> 2)) * p.stride_y + rq.x0 + (rq.mv[0] >> 2);
-        predict_block<8>(ref, p.stride_y, p.pred[0] + rq.out_y, rq.size, rq.mv[0] & 3, rq.mv[1] & 3, s_win, s_h);
+        predict_block<8, MAXBS>(ref, p.stride_y, p.pred[0] + rq.out_y, rq.size, rq.mv[0] & 3, rq.mv[1] & 3, lds);
     } else {
         const uint8_t *ref = p.ref[plane] + (ptrdiff_t)((rq.y0 >> 1) + (rq.mv[1] >> 3)) * p.stride_c + (rq.x0 >> 1) + (rq.mv[0] >> 3);
-        predict_block<4>(ref, p.stride_c, p.pred[plane] + rq.out_c, rq.size >> 1, rq.mv[0] & 7, rq.mv[1] & 7, s_win, s_h);
+        predict_block<4, MAXBS>(ref, p.stride_c, p.pred[plane] + rq.out_c, rq.size >> 1, rq.mv[0] & 7, rq.mv[1] & 7, lds);
     }
+}
+
+void launch_pred(const PredParams &p, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(inter_pred_kernel<16>, dim3(n, 3), dim3(kPredThreads), 0, st, p);
+    hipLaunchKernelGGL(inter_pred_kernel<64>, dim3(n, 3), dim3(kPredThreads), 0, st, p);
 }
 
 std::mutex g_mu;   // the per-call forms share one staging area
@@ -143,7 +176,7 @@ int percall(const char *who, bool chroma, const uint8_t *ref, uint8_t *pred, uin
     p.req = reinterpret_cast<const xmi_inter_pred_request *>(dev + rq_off);
     p.stride_y = p.stride_c = W;
     p.n = 1;
-    hipLaunchKernelGGL(inter_pred_kernel, dim3(1, 3), dim3(256), 0, nullptr, p);
+    launch_pred(p, 1, nullptr);
     XMI_HIP(hipGetLastError());
     static std::vector<uint8_t> out;
     out.resize(blk);
@@ -181,7 +214,7 @@ int xmi_pred_inter_batch_dev(const uint8_t *d_ref_y, int stride_y, const uint8_t
     p.stride_y = stride_y;
     p.stride_c = stride_c;
     p.n = n;
-    hipLaunchKernelGGL(inter_pred_kernel, dim3(n, 3), dim3(256), 0, xmi::as_stream(stream), p);
+    launch_pred(p, n, xmi::as_stream(stream));
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
