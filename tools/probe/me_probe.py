@@ -19,12 +19,22 @@ def timeit(fn, iters=10):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
 rng = np.random.default_rng(3)
-CASES = ((8, 28000), (8, 7000), (8, 1000), (8, 64), (64, 600), (64, 16), (16, 9500))
+CASES = ((8, 28000), (8, 7000), (8, 1000), (8, 64), (64, 600), (64, 16), (16, 9500), (32, 2400), (0, 39000), (-1, 0))
 if os.environ.get('ME_PROBE_ONLY'): CASES = (CASES[int(os.environ['ME_PROBE_ONLY'])],)
 for size, nreq in CASES:
+    if size == -1:       # the per-picture mix in raster order per size, predictors near the true motion
+        plist = [(x, y, n) for n, frac in ((64, 1.0), (32, 1.0), (16, 1.0), (8, 0.85)) for y in range(0, H, n) for x in range(0, W, n) if rng.random() < frac]
+        nreq = len(plist)
     reqs = (capi.MeRequest * nreq)()
     for i in range(nreq):
-        rq = reqs[i]; n = size; rq.size = n
+        rq = reqs[i]; n = size if size > 0 else int(rng.choice([8, 8, 8, 8, 8, 8, 16, 16, 32, 64])); rq.size = n
+        if size == -1:
+            rq.x0, rq.y0, rq.size = plist[i]
+            rq.mvp[0][0], rq.mvp[0][1] = -12 + int(rng.integers(-4, 5)), -8 + int(rng.integers(-4, 5))
+            rq.mvp[1][0], rq.mvp[1][1] = -12 + int(rng.integers(-4, 5)), -8 + int(rng.integers(-4, 5))
+            rq.mv_min_ipel[0], rq.mv_min_ipel[1], rq.mv_max_ipel[0], rq.mv_max_ipel[1] = -64, -64, 64, 64
+            rq.sqrt_lambda = 7
+            continue
         rq.x0 = int(rng.integers(0, (W - n) // 8 + 1)) * 8; rq.y0 = int(rng.integers(0, (H - n) // 8 + 1)) * 8
         rq.mvp[0][0], rq.mvp[0][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
         rq.mvp[1][0], rq.mvp[1][1] = int(rng.integers(-24, 25)), int(rng.integers(-24, 25))
@@ -38,6 +48,7 @@ for size, nreq in CASES:
     capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_req.data_ptr(), nreq, 32, d_res.data_ptr(), s)); torch.cuda.synchronize()
     res = (capi.MeResult * nreq).from_buffer_copy(d_res.cpu().numpy().tobytes())
     ni = np.array([r.n_int_sads for r in res])
-    print(json.dumps({"size": size, "n": nreq, **out, "int_sads_mean": round(float(ni.mean()), 1), "int_sads_max": int(ni.max()), "p99": int(np.percentile(ni, 99))}))
+    chk = sum((r.mv[0] * 31 + r.mv[1] * 17 + r.best_cost + r.best_sad * 3 + r.mvp_idx) & 0xffffffff for r in res) & 0xffffffff
+    print(json.dumps({"size": size, "n": nreq, "checksum": chk, **out, "int_sads_mean": round(float(ni.mean()), 1), "int_sads_max": int(ni.max()), "p99": int(np.percentile(ni, 99))}))
 empty = torch.zeros(1, device="cuda")
 print("empty-kernel us", round(timeit(lambda: empty.add_(1)), 1))
