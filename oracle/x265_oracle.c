@@ -897,3 +897,29 @@ void orc_deblock_strengths(int width, int height, int intra_slice, const uint8_t
                     }
         }
 }
+
+/* ---- intra chroma mode search (src/encode.cpp:4326-4365) ---- */
+void orc_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, int src_stride, const uint8_t *ref_u, const uint8_t *ref_v,
+                             int size, int luma_mode, orc_chroma_result *out)
+{
+    const int cand[5] = { 0, 26, 10, 1, luma_mode };            /* nMostModeC, :4260-4263, :4327 */
+    const int lg = size == 4 ? 2 : size == 8 ? 3 : size == 16 ? 4 : 5;
+    uint8_t pred[2][32 * 32];
+    uint32_t best = 0xffffffffu;                                /* MAX_SAD */
+    out->best_idx = 0;
+    for (int m = 0; m < 5; m++) {
+        int mode = cand[m];
+        if (m < 4 && mode == luma_mode) mode = 34;               /* :4333 */
+        out->modes[m] = mode;
+        orc_intra_pred(pred[0], ref_u, size, mode, size, 0);
+        orc_intra_pred(pred[1], ref_v, size, mode, size, 0);
+        out->satd_u[m] = orc_satd_table(lg - 2, src_u, src_stride, pred[0], size);
+        out->satd_v[m] = orc_satd_table(lg - 2, src_v, src_stride, pred[1], size);
+        const uint32_t sum = out->satd_u[m] + out->satd_v[m];
+        if (sum < best) {                                        /* :4357, strict */
+            best = sum;
+            out->best_idx = m;
+        }
+    }
+    out->best_mode = out->modes[out->best_idx];
+}

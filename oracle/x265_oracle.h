@@ -145,6 +145,20 @@ typedef struct {
 void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw, int size, unsigned valids,
                       int strong_smoothing, const uint8_t mpm[3], double sqrt_lambda, orc_intra_result *out);
 
+/* Intra chroma mode search of xEncodeChromaCU (src/encode.cpp:4326-4365) for one CU: candidates planar, vertical (26),
+ * horizontal (10), DC (1) and the luma mode, a candidate among the first four that equals the luma mode replaced by 34;
+ * U and V predicted without the luma edge filters from their padded neighbouring samples (ref_u, ref_v: 4*size+1 bytes
+ * each, layout as above), measured with the entry bound in xSatdN[log2(size)-2]; the first candidate with the smallest
+ * U + V sum wins. size = 4, 8 or 16 (32 for the chroma of a 64x64 CU). */
+typedef struct {
+    int best_idx;         /* nBestModeC: index into the candidate list */
+    int best_mode;        /* the prediction mode it stands for (realModeC) */
+    int modes[5];         /* the candidate modes tried */
+    uint32_t satd_u[5], satd_v[5];
+} orc_chroma_result;
+void orc_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, int src_stride, const uint8_t *ref_u, const uint8_t *ref_v,
+                             int size, int luma_mode, orc_chroma_result *out);
+
 /* In-loop deblocking of one reconstructed picture, xDeblockFrame (src/Deblock.cpp:524-559): every 64x64 CTB once in
  * raster order through ff_hevc_deblocking_filter_CTB (:244-342) - its vertical edges, then its horizontal edges
  * shifted 8 samples to the left - with the luma / chroma segment filters of :61-168, tc and beta tables :195-207,

@@ -20,6 +20,10 @@ class OrcMEResult(C.Structure):
                 ("mvp_idx", C.c_int), ("n_int_sads", C.c_int), ("n_sub_sads", C.c_int)]
 
 
+class OrcChromaResult(C.Structure):
+    _fields_ = [("best_idx", C.c_int), ("best_mode", C.c_int), ("modes", C.c_int * 5), ("satd_u", C.c_uint32 * 5), ("satd_v", C.c_uint32 * 5)]
+
+
 class OrcDeblockParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "stride_y", "stride_c", "tc_offset", "beta_offset", "cb_qp_offset", "cr_qp_offset")]
 
@@ -65,6 +69,8 @@ def load():
     lib.orc_sao_apply_plane.argtypes = [vp, i, vp, i, i, i, i, vp]
     lib.orc_sao_stats_ctu.restype = None
     lib.orc_sao_stats_ctu.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, vp]
+    lib.orc_intra_chroma_search.restype = None
+    lib.orc_intra_chroma_search.argtypes = [vp, vp, i, vp, vp, i, i, C.POINTER(OrcChromaResult)]
     lib.orc_deblock_strengths.restype = None
     lib.orc_deblock_strengths.argtypes = [i, i, i, vp, vp, vp, vp, vp]
     lib.orc_deblock_frame.restype = None

@@ -1,5 +1,6 @@
 """CPU: the oracle (oracle/x265_oracle.c) against golden vectors produced by the reference's own
 compiled pixel.cpp (oracle/gen_golden.py). Bit-exact."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -344,3 +345,20 @@ def test_deblock_strengths_reproduce_encoder_arrays(lib, golden_dir):
         np.testing.assert_array_equal(hbs, g[f"{t}_hbs"], err_msg=f"{t}: horizontal edges")
         seen |= set(int(v) for v in np.unique(lg)) | {10 + int(v) for v in np.unique(vbs)}
     assert {2, 3, 4, 5, 6, 10, 11, 12} <= seen        # every unit size and every strength occurs
+
+
+@pytest.mark.parametrize("n", [4, 8, 16])
+def test_intra_chroma_search_reproduces_encoder_trace(lib, golden_dir, n):
+    """orc_intra_chroma_search on the searches xEncodeChromaCU made in bit-identical encodes (tests/golden/chroma_trace.npz,
+    oracle/gen_chroma_trace.py): the candidate modes, the ten SATDs the reference's bound functions returned, and the
+    candidate the encoder kept (read back from its flag array)."""
+    g = np.load(os.path.join(golden_dir, "chroma_trace.npz"))
+    bm = g[f"n{n}_best_modes"]
+    for k in range(len(bm)):
+        su, sv = np.ascontiguousarray(g[f"n{n}_src_u"][k]), np.ascontiguousarray(g[f"n{n}_src_v"][k])
+        ru, rv = np.ascontiguousarray(g[f"n{n}_ref_u"][k]), np.ascontiguousarray(g[f"n{n}_ref_v"][k])
+        out = O.OrcChromaResult()
+        lib.orc_intra_chroma_search(O.p(su), O.p(sv), n, O.p(ru), O.p(rv), n, int(bm[k, 5]), C.byref(out))
+        assert list(out.modes) == [int(v) for v in bm[k, 1:6]], f"search {k}: candidate modes"
+        assert list(out.satd_u) == [int(v) for v in g[f"n{n}_satd_u"][k]] and list(out.satd_v) == [int(v) for v in g[f"n{n}_satd_v"][k]], f"search {k}: SATDs"
+        assert out.best_idx == int(bm[k, 0]) and out.best_mode == int(bm[k, 1 + out.best_idx]), f"search {k}: decision"
