@@ -160,6 +160,27 @@ typedef struct xmi_intra_result {
 int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
 
+/* ---- intra chroma mode search --------------------------------------------------------------------
+ * The candidate loop of xEncodeChromaCU (src/encode.cpp:4326-4365) for a batch of CUs: candidates planar, vertical (26),
+ * horizontal (10), DC (1) and the luma mode - one of the first four that equals the luma mode is replaced by 34 -, U and
+ * V predicted by xEncIntraPred without the luma edge filters, each measured with the SATD the reference binds in
+ * xSatdN[log2(size) - 2] (src/encode.cpp:4353), the first candidate with the smallest U + V sum kept. Request i: the
+ * CU's origin in the chroma planes (x0 a multiple of 4), its chroma size (4, 8 or 16) and luma mode; its neighbouring
+ * samples AFTER xPaddingRef (src/encode.cpp:4322), layout as for the luma search, U at d_ref_samples + 2 i *
+ * XMI_INTRA_REF_PITCH and V one pitch further. A request the kernel cannot serve (other sizes, mode above 34, bad
+ * origin) gets best_idx = best_mode = -1. */
+typedef struct xmi_chroma_request {
+    int32_t x0, y0;
+    uint8_t size, luma_mode, reserved[2];
+} xmi_chroma_request;
+typedef struct xmi_chroma_result {
+    int32_t best_idx;             /* nBestModeC: index into the candidate list */
+    int32_t best_mode;            /* the prediction mode it stands for */
+    uint32_t satd_u[5], satd_v[5];
+} xmi_chroma_result;
+int xmi_intra_chroma_search_batch_dev(const uint8_t *d_src_u, const uint8_t *d_src_v, int src_stride, const uint8_t *d_ref_samples,
+                                      const xmi_chroma_request *d_req, int n, xmi_chroma_result *d_res, void *stream);
+
 /* ---- prediction blocks -------------------------------------------------------------------------------
  * Inter: what xPredInterLumaBlk (src/pixel.cpp:8745-8795, 8-tap, quarter-pel) and xPredInterChromaBlk
  * (src/pixel.cpp:9657-9703, 4-tap, the same MV numbers read as eighth-pel) write for one PU, for a batch of PUs

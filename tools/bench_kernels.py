@@ -174,6 +174,21 @@ for n in (4, 8, 16, 32):
     print(json.dumps({"kernel": f"intra_search {n}x{n}", "requests": nreq, "ms": round(t * 1e3, 3),
                       "Msearch_per_s": round(nreq / t / 1e6, 2), "Gpixel_modes_per_s": round(nreq * n * n * 35 / t / 1e9, 1)}))
 
+# ---- intra chroma mode search: every 8x8 chroma CU (16x16 luma) of a 1080p I picture ----
+cw, chh = W // 2, H // 2
+pu_ = torch.randint(0, 256, (chh, cw), dtype=torch.uint8, device="cuda", generator=g)
+pv_ = torch.randint(0, 256, (chh, cw), dtype=torch.uint8, device="cuda", generator=g)
+ncu = (cw // 8) * (chh // 8)
+creq = (capi.ChromaRequest * ncu)()
+for i in range(ncu):
+    creq[i].x0, creq[i].y0, creq[i].size, creq[i].luma_mode = (i % (cw // 8)) * 8, (i // (cw // 8)) * 8, 8, int(rng.integers(0, 35))
+d_creq = torch.frombuffer(bytearray(bytes(creq)), dtype=torch.uint8).cuda()
+d_cref = torch.randint(0, 256, (ncu, 2, capi.INTRA_REF_PITCH), dtype=torch.uint8, device="cuda", generator=g)
+d_cres = torch.zeros(ncu * C.sizeof(capi.ChromaResult), dtype=torch.uint8, device="cuda")
+t = timeit(lambda: capi.check(L.xmi_intra_chroma_search_batch_dev(pu_.data_ptr(), pv_.data_ptr(), cw, d_cref.data_ptr(), d_creq.data_ptr(), ncu,
+                                                                  d_cres.data_ptr(), s)))
+print(json.dumps({"kernel": "intra_chroma_search 8x8", "requests": ncu, "ms": round(t * 1e3, 4), "Msearch_per_s": round(ncu / t / 1e6, 2)}))
+
 # ---- in-loop deblocking of a 1080p picture: strengths as an I picture has them (2 on the 8x8 transform grid) and as a
 # P picture has them (1 on a third of the segments) ----
 for label, dens, val in (("I picture, strength 2 on every edge segment", 1.0, 2), ("P picture, strength 1 on a third of the segments", 0.33, 1)):

@@ -50,6 +50,14 @@ class SaoStats(C.Structure):
     _fields_ = [("count", C.c_int32 * 33 * 5), ("offset_org", C.c_int32 * 33 * 5)]
 
 
+class ChromaRequest(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_uint8), ("luma_mode", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class ChromaResult(C.Structure):
+    _fields_ = [("best_idx", C.c_int32), ("best_mode", C.c_int32), ("satd_u", C.c_uint32 * 5), ("satd_v", C.c_uint32 * 5)]
+
+
 class DeblockParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("width", "height", "stride_y", "stride_c", "tc_offset", "beta_offset", "cb_qp_offset", "cr_qp_offset")]
 
@@ -135,6 +143,9 @@ def load():
         L.xmi_deblock_frame_dev.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp, vp]
         L.xmi_deblock_frame.restype = i
         L.xmi_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp]
+    if hasattr(L, "xmi_intra_chroma_search_batch_dev"):
+        L.xmi_intra_chroma_search_batch_dev.restype = i
+        L.xmi_intra_chroma_search_batch_dev.argtypes = [vp, vp, i, vp, vp, i, vp, vp]
     if hasattr(L, "xmi_deblock_strengths_dev"):
         L.xmi_deblock_strengths_dev.restype = i
         L.xmi_deblock_strengths_dev.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]

@@ -294,6 +294,113 @@ __global__ void __launch_bounds__(256) intra_pred_kernel(const IntraPredParams p
     }
 }
 
+// ---- intra chroma mode search: one wavefront per CU ----
+// xEncodeChromaCU (src/encode.cpp:4326-4365): candidates planar, vertical, horizontal, DC and the luma mode (one of the
+// first four that equals the luma mode becomes 34), U and V predicted without the luma edge filters, each measured with
+// the x264-form SATD the reference binds for 4x4 .. 16x16, first smallest U + V sum kept. The 10 (candidate, plane)
+// blocks are cut into 4x4 transform tiles; a lane takes one tile per pass, tile sums meet through the segmented DPP
+// reduction of the luma search.
+struct ChromaParams {
+    const uint8_t *src_u, *src_v, *refs;
+    const xmi_chroma_request *req;
+    xmi_chroma_result *res;
+    int src_stride, n;
+};
+
+template <int N>
+__device__ __forceinline__ void chroma_search(const ChromaParams &p, const xmi_chroma_request &rq, int idx, uint8_t (*s_ref)[136], uint8_t (*s_src)[256],
+                                              u32 *s_satd, int lane)
+{
+    constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : 4;
+    constexpr int T = (N / 4) * (N / 4);             // 4x4 tiles per block
+    const uint8_t *raw = p.refs + (size_t)idx * 2 * XMI_INTRA_REF_PITCH;
+    for (int i = lane; i < 2 * (4 * N + 1); i += 64) {
+        const int pl = i >= 4 * N + 1, k = i - pl * (4 * N + 1);
+        s_ref[pl][k] = raw[pl * XMI_INTRA_REF_PITCH + k];
+    }
+    for (int e = lane; e < 2 * N * N / 4; e += 64) {
+        const int pl = e >= N * N / 4, k = e - pl * (N * N / 4), y = k / (N / 4), x4 = k % (N / 4);
+        const uint8_t *src = (pl ? p.src_v : p.src_u) + (size_t)(rq.y0 + y) * p.src_stride + rq.x0 + 4 * x4;
+        reinterpret_cast<u32 *>(s_src[pl])[k] = *reinterpret_cast<const u32 *>(src);
+    }
+    __builtin_amdgcn_wave_barrier();
+    int dc[2];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        int sum = 0;
+        for (int i = lane; i < 2 * N; i += 64) sum += i < N ? s_ref[pl][2 * N - 1 - i] : s_ref[pl][2 * N + 1 + (i - N)];
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) sum += __shfl_xor(sum, k);
+        dc[pl] = (sum + N) >> (LG + 1);
+    }
+    const int luma = rq.luma_mode;
+    const int cand[5] = { 0, 26, 10, 1, luma };
+    for (int item0 = 0; item0 < 10 * T; item0 += 64) {
+        const int item = item0 + lane, combo = item / T, tile = item % T;
+        int sum = 0;
+        if (combo < 10) {
+            const int m = combo >> 1, pl = combo & 1;
+            int mode = cand[m];
+            if (m < 4 && mode == luma) mode = 34;
+            const int ty = (tile / (N / 4)) * 4, tx = (tile % (N / 4)) * 4;
+            xmi::s16x2 d[4][2];
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x += 2) {
+                    d[y][x / 2].x = (short)((int)s_src[pl][(ty + y) * N + tx + x] - pred_sample<N>(s_ref[pl], mode, ty + y, tx + x, dc[pl], false));
+                    d[y][x / 2].y = (short)((int)s_src[pl][(ty + y) * N + tx + x + 1] - pred_sample<N>(s_ref[pl], mode, ty + y, tx + x + 1, dc[pl], false));
+                }
+            sum = (int)xmi::hadamard_abs_sum_packed<4>(d);
+        }
+        sum = group_sum_to_last_lane<T>(sum);
+        if (combo < 10 && tile == T - 1) s_satd[combo] = (u32)sum >> 1;      // x264 form: halved once per block
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        xmi_chroma_result out;
+        u32 best = 0xffffffffu;
+        out.best_idx = 0;
+        for (int m = 0; m < 5; m++) {
+            out.satd_u[m] = s_satd[2 * m];
+            out.satd_v[m] = s_satd[2 * m + 1];
+            const u32 both = out.satd_u[m] + out.satd_v[m];
+            if (both < best) {
+                best = both;
+                out.best_idx = m;
+            }
+        }
+        const int bm = cand[out.best_idx];
+        out.best_mode = (out.best_idx < 4 && bm == luma) ? 34 : bm;
+        p.res[idx] = out;
+    }
+}
+
+__global__ void __launch_bounds__(256) intra_chroma_search_kernel(const ChromaParams p)
+{
+    __shared__ __align__(16) uint8_t s_ref[4][2][136];
+    __shared__ __align__(16) uint8_t s_src[4][2][256];
+    __shared__ u32 s_satd[4][10];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = (int)blockIdx.x * 4 + wave;
+    if (idx >= p.n) return;
+    const xmi_chroma_request rq = p.req[idx];
+    const bool ok = (rq.size == 4 || rq.size == 8 || rq.size == 16) && rq.luma_mode < 35 && rq.x0 >= 0 && rq.y0 >= 0 && (rq.x0 & 3) == 0;
+    if (!ok) {                   // marked, so that the caller can tell
+        if (lane == 0) {
+            xmi_chroma_result out = {};
+            out.best_idx = out.best_mode = -1;
+            p.res[idx] = out;
+        }
+        return;
+    }
+    switch (rq.size) {
+    case 4: chroma_search<4>(p, rq, idx, s_ref[wave], s_src[wave], s_satd[wave], lane); break;
+    case 8: chroma_search<8>(p, rq, idx, s_ref[wave], s_src[wave], s_satd[wave], lane); break;
+    default: chroma_search<16>(p, rq, idx, s_ref[wave], s_src[wave], s_satd[wave], lane); break;
+    }
+}
+
 std::mutex g_pred_mu;   // the per-call form shares one staging area
 
 // one kernel per PU size present in `sizes` (bit mask of 4, 8, 16, 32) over the whole request array
@@ -391,4 +498,20 @@ extern "C" int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, 
     XMI_ARG(d_src && d_ref_samples && d_req && d_res, "xmi_intra_search_batch_dev: null argument");
     XMI_ARG(src_stride % 4 == 0 && ((uintptr_t)d_src & 3) == 0, "xmi_intra_search_batch_dev: source frame must be 4-byte aligned");
     return launch_search(d_src, src_stride, d_ref_samples, d_req, n, d_res, 4 | 8 | 16 | 32, stream);
+}
+
+extern "C" int xmi_intra_chroma_search_batch_dev(const uint8_t *d_src_u, const uint8_t *d_src_v, int src_stride, const uint8_t *d_ref_samples,
+                                                 const xmi_chroma_request *d_req, int n, xmi_chroma_result *d_res, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_intra_chroma_search_batch_dev: negative request count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(d_src_u && d_src_v && d_ref_samples && d_req && d_res, "xmi_intra_chroma_search_batch_dev: null argument");
+    XMI_ARG(src_stride > 0 && src_stride % 4 == 0 && (((uintptr_t)d_src_u | (uintptr_t)d_src_v) & 3) == 0,
+            "xmi_intra_chroma_search_batch_dev: chroma planes must be 4-byte aligned");
+    ChromaParams p = { d_src_u, d_src_v, d_ref_samples, d_req, d_res, src_stride, n };
+    hipLaunchKernelGGL(intra_chroma_search_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
 }
