@@ -180,6 +180,9 @@ typedef struct xmi_chroma_result {
 } xmi_chroma_result;
 int xmi_intra_chroma_search_batch_dev(const uint8_t *d_src_u, const uint8_t *d_src_v, int src_stride, const uint8_t *d_ref_samples,
                                       const xmi_chroma_request *d_req, int n, xmi_chroma_result *d_res, void *stream);
+/* one CU with host pointers: the U and V source blocks (rows src_stride apart) and their padded samples */
+int xmi_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, uint32_t src_stride, const uint8_t *ref_u, const uint8_t *ref_v,
+                            int size, int luma_mode, xmi_chroma_result *res);
 
 /* ---- prediction blocks -------------------------------------------------------------------------------
  * Inter: what xPredInterLumaBlk (src/pixel.cpp:8745-8795, 8-tap, quarter-pel) and xPredInterChromaBlk

@@ -196,3 +196,24 @@ def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants)
     assert hashlib.md5(open(yuv, "rb").read()).hexdigest() == want["input_md5"]
     for v in variants:
         assert encode(v, yuv, str(tmp_path / f"{v}.265"), w, h, frames, qp) == (want["md5"], want["bytes"]), f"x265_{v}"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_chroma")), reason="GPU chroma-search encoder not built (make -C oracle trace)")
+@pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
+def test_bitstream_identical_with_gpu_chroma_search(tmp_path, qp, frames):
+    """The reference's encoder with every intra chroma mode search answered by the GPU (oracle/chroma_gpu_hook.cpp: the ten
+    SATD calls of a search return the numbers of one xmi_intra_chroma_search; the reference's SATD code does not run for
+    them): the recorded bitstream, i.e. the same SATDs in every search."""
+    w, h = 416, 240
+    yuv = str(tmp_path / "in.yuv")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), "1234", yuv])
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))[f"416x240_f{frames}_q{qp}"]
+    exe = os.path.join(REFDIR, "x265_gpu_chroma")
+    out = str(tmp_path / "c.265")
+    res = subprocess.run([exe, "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(frames), "-q", str(qp), "-ip", "100",
+                          "-sceneChange", "0", "-t", "1"], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-1000:]
+    assert (hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out)) == (want["md5"], want["bytes"])
+    import re
+    m = re.search(r"chroma_gpu_hook: (\d+) searches on the GPU", res.stderr)
+    assert m and int(m.group(1)) >= 200, res.stderr[-500:]

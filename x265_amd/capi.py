@@ -146,6 +146,8 @@ def load():
     if hasattr(L, "xmi_intra_chroma_search_batch_dev"):
         L.xmi_intra_chroma_search_batch_dev.restype = i
         L.xmi_intra_chroma_search_batch_dev.argtypes = [vp, vp, i, vp, vp, i, vp, vp]
+        L.xmi_intra_chroma_search.restype = i
+        L.xmi_intra_chroma_search.argtypes = [vp, vp, C.c_uint32, vp, vp, i, i, vp]
     if hasattr(L, "xmi_deblock_strengths_dev"):
         L.xmi_deblock_strengths_dev.restype = i
         L.xmi_deblock_strengths_dev.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]

@@ -515,3 +515,35 @@ extern "C" int xmi_intra_chroma_search_batch_dev(const uint8_t *d_src_u, const u
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
+
+extern "C" int xmi_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, uint32_t src_stride, const uint8_t *ref_u, const uint8_t *ref_v,
+                                       int size, int luma_mode, xmi_chroma_result *res)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(src_u && src_v && ref_u && ref_v && res, "xmi_intra_chroma_search: null argument");
+    XMI_ARG(size == 4 || size == 8 || size == 16, "xmi_intra_chroma_search: size %d not in {4,8,16}", size);
+    XMI_ARG(luma_mode >= 0 && luma_mode < 35, "xmi_intra_chroma_search: luma mode %d", luma_mode);
+    std::lock_guard<std::mutex> lk(g_pred_mu);
+    // staging: U block | V block (rows `size` apart) | U samples | V samples | request | result
+    const size_t blk = (size_t)size * size, off_ref = 512, off_req = off_ref + 2 * XMI_INTRA_REF_PITCH, off_res = off_req + 16;
+    static_assert(sizeof(xmi_chroma_request) <= 16 && 512 + 2 * XMI_INTRA_REF_PITCH + 16 + sizeof(xmi_chroma_result) <= 2048, "staging layout");
+    uint8_t *dev = static_cast<uint8_t *>(xmi::scratch(9, 2048));
+    if (!dev) return XMI_ERR_HIP;
+    uint8_t host[512 + 2 * XMI_INTRA_REF_PITCH + 16];
+    memset(host, 0, sizeof host);
+    for (int y = 0; y < size; y++) {
+        memcpy(host + (size_t)y * size, src_u + (size_t)y * src_stride, (size_t)size);
+        memcpy(host + blk + (size_t)y * size, src_v + (size_t)y * src_stride, (size_t)size);
+    }
+    memcpy(host + off_ref, ref_u, (size_t)(4 * size + 1));
+    memcpy(host + off_ref + XMI_INTRA_REF_PITCH, ref_v, (size_t)(4 * size + 1));
+    xmi_chroma_request rq = { 0, 0, (uint8_t)size, (uint8_t)luma_mode, { 0, 0 } };
+    memcpy(host + off_req, &rq, sizeof rq);
+    XMI_HIP(hipMemcpy(dev, host, sizeof host, hipMemcpyHostToDevice));
+    rc = xmi_intra_chroma_search_batch_dev(dev, dev + blk, size, dev + off_ref, reinterpret_cast<const xmi_chroma_request *>(dev + off_req), 1,
+                                           reinterpret_cast<xmi_chroma_result *>(dev + off_res), nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy(res, dev + off_res, sizeof(xmi_chroma_result), hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
