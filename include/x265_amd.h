@@ -131,6 +131,26 @@ int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_stride, const 
                                     const uint32_t *d_sad32, const uint32_t *d_sad64, const xmi_me_request *d_req, int n,
                                     int me_range, xmi_me_result *d_res, void *stream);
 
+/* ---- MV predictor and merge candidates ----------------------------------------------------------
+ * xFillMvpCand (src/encode.cpp:2703-2809) for a batch of PUs, from picture-level maps instead of the CTU-local caches:
+ * d_valid one byte per 4x4 block, non-zero where the reference's mode cache would not read MODE_INVALID (the block is
+ * coded), d_mv one vector per 8x8 block (x then y, quarter-pel); width/4 resp. width/8 entries per row; everything outside
+ * the picture counts as not coded. Request: PU origin and size in luma samples (multiples of 8, 8..64), pu_mode 0 = 2Nx2N,
+ * 1 = 2NxN, 2 = Nx2N, pu_idx the PU's index in its CU. Result: the two AMVP candidates (the sMVP of xMotionSearch and
+ * the mvp of xmi_me_request), the merge candidates and their number (entries past it are zero; -1 marks a request that
+ * is no PU of the picture). */
+typedef struct xmi_mvp_request {
+    int32_t x0, y0;
+    uint8_t size_x, size_y, pu_mode, pu_idx;
+} xmi_mvp_request;
+typedef struct xmi_mvp_result {
+    int16_t amvp[2][2];
+    int16_t merge[5][2];
+    int32_t merge_count;
+} xmi_mvp_result;
+int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const int16_t *d_mv, const xmi_mvp_request *d_req, int n,
+                           xmi_mvp_result *d_res, void *stream);
+
 /* ---- intra luma mode search ---------------------------------------------------------------------
  * The 35-mode SATD search of xEncDecideCU_Intra (src/encode.cpp:4005-4081) for a batch of PUs, one request per
  * PU, with what the reference has at that point of its CTU loop: the PU's source pixels (taken from the

@@ -489,11 +489,66 @@ def gen_intra_chroma():
     print("wrote intra_pred_flags.npz")
 
 
+def gen_mvp():
+    """MV predictor and merge candidate lists: the reference's compiled xFillMvpCand (src/encode.cpp:2703-2809) on seeded
+    picture-level maps. For every request the CTU-cache neighbourhoods the function reads (mode flags with pitch MAX_PU_XY + 2,
+    motion vectors with pitch MAX_MV_XY + 2) are cut out of a map of coded 4x4 blocks and of one motion vector per 8x8 block;
+    stored: the maps, the requests, the two AMVP candidates, the merge candidates and their number."""
+    lib = C.CDLL(LIB_ME)
+    f = lib._Z12xFillMvpCandP3xMVPKhPKS_jjjj
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint32, C.c_uint32]
+    rng = np.random.default_rng(41)
+    W, H = 256, 128
+    valid = (rng.random((H // 4, W // 4)) < 0.8).astype(np.uint8)
+    valid[:, : W // 16] = 1                                   # a fully coded region
+    valid[H // 8:, W // 8 * 3: W // 8 * 5] = 0                  # a region not coded yet
+    palette = rng.integers(-40, 41, (5, 2)).astype(np.int16)  # few distinct vectors: the pruning comparisons fire
+    palette[0] = 0
+    mv = palette[rng.integers(0, 5, (H // 8, W // 8))]
+    nreq = 600
+    req = np.zeros((nreq, 6), np.int32)                       # x0 y0 size_x size_y pu_mode pu_idx
+    res = np.zeros((nreq, 7, 2), np.int16)
+    cnt = np.zeros(nreq, np.int32)
+    for i in range(nreq):
+        n = int(rng.choice([8, 16, 32, 64]))
+        mode = int(rng.choice([0, 0, 0, 1, 2]))               # SIZE_2Nx2N, SIZE_2NxN, SIZE_Nx2N
+        idx = int(rng.integers(0, 2)) if mode else 0
+        sx, sy = (n, n) if mode == 0 or n == 8 else ((n, n // 2) if mode == 1 else (n // 2, n))
+        if n == 8:
+            mode = idx = 0
+        x0 = int(rng.integers(0, (W - n) // 8 + 1)) * 8 + (sx if (mode == 2 and idx == 1) else 0)
+        y0 = int(rng.integers(0, (H - n) // 8 + 1)) * 8 + (sy if (mode == 1 and idx == 1) else 0)
+        req[i] = (x0, y0, sx, sy, mode, idx)
+        modes = np.full((18, 18), 255, np.uint8)              # origin at [1][1]: rows / columns -1 .. 16 in 4x4 units
+        for r in range(-1, 17):
+            for c in range(-1, 17):
+                yy, xx = y0 // 4 + r, x0 // 4 + c
+                if 0 <= yy < H // 4 and 0 <= xx < W // 4 and valid[yy, xx]:
+                    modes[r + 1, c + 1] = 0
+        mvs = np.zeros((10, 10, 2), np.int16)                  # origin at [1][1]: -1 .. 8 in 8x8 units
+        for r in range(-1, 9):
+            for c in range(-1, 9):
+                yy, xx = y0 // 8 + r, x0 // 8 + c
+                if 0 <= yy < H // 8 and 0 <= xx < W // 8:
+                    mvs[r + 1, c + 1] = mv[yy, xx]
+        out = np.full((7, 2), 0x7777, np.int16)
+        cnt[i] = f(ptr(out), C.c_void_p(modes.ctypes.data + 18 + 1), C.c_void_p(mvs.ctypes.data + (10 + 1) * 4), sx, sy, mode, idx)
+        out[2 + cnt[i]:] = 0                                   # entries past the count are not written by the reference
+        res[i] = out
+    print("mvp: merge count histogram", np.bincount(cnt, minlength=6), "AMVP second candidate zero in", int((res[:, 1] == 0).all(axis=1).sum()))
+    np.savez_compressed(os.path.join(OUT, "mvp_cand.npz"), valid=valid, mv=mv, req=req, cand=res, count=cnt, size=np.array([W, H], np.int32))
+    print("wrote mvp_cand.npz")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "chroma":
+    if len(sys.argv) > 1 and sys.argv[1] == "mvp":
+        gen_mvp()
+    elif len(sys.argv) > 1 and sys.argv[1] == "chroma":
         gen_chroma()
         gen_intra_chroma()
     else:
         main()
         gen_chroma()
         gen_intra_chroma()
+        gen_mvp()

@@ -923,3 +923,63 @@ void orc_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, int src
     }
     out->best_mode = out->modes[out->best_idx];
 }
+
+/* ---- MV predictor and merge candidates (src/encode.cpp:2703-2809) ---- */
+typedef struct { int ok; int16_t x, y; } orc_nb;
+
+static orc_nb orc_mvp_neighbour(int width, int height, const uint8_t *valid, const int16_t *mv, int px, int py)
+{
+    /* px, py: luma position of the 4x4 block the mode flag is read for; the vector is that of its 8x8 block */
+    orc_nb n = { 0, 0, 0 };
+    if (px < 0 || py < 0 || px >= width || py >= height) return n;
+    n.ok = valid[(py >> 2) * (width >> 2) + (px >> 2)] != 0;
+    n.x = mv[2 * ((py >> 3) * (width >> 3) + (px >> 3))];
+    n.y = mv[2 * ((py >> 3) * (width >> 3) + (px >> 3)) + 1];
+    return n;
+}
+
+int orc_fill_mvp_cand(int width, int height, const uint8_t *valid, const int16_t *mv, int x0, int y0, int size_x, int size_y,
+                      int pu_mode, int pu_idx, int16_t out[7][2])
+{
+    const int no_b1 = pu_mode == 1 && pu_idx == 1, no_a1 = pu_mode == 2 && pu_idx == 1;        /* :2713-2714 */
+    /* the flag of a neighbour is read at 4x4 precision, its vector at 8x8 precision, both relative to the PU (:2721-2732):
+     * vector row size_y/8 (or size_y/8 - 1) of the cache is the 8x8 row of luma line y0 + 8 (size_y/8) (- 8) */
+    const orc_nb fbl = orc_mvp_neighbour(width, height, valid, mv, x0 - 1, y0 + size_y);
+    const orc_nb fl = orc_mvp_neighbour(width, height, valid, mv, x0 - 1, y0 + size_y - 4);
+    const orc_nb ftr = orc_mvp_neighbour(width, height, valid, mv, x0 + size_x, y0 - 1);
+    const orc_nb ft = orc_mvp_neighbour(width, height, valid, mv, x0 + size_x - 4, y0 - 1);
+    const orc_nb ftl = orc_mvp_neighbour(width, height, valid, mv, x0 - 1, y0 - 1);
+    orc_nb bl = orc_mvp_neighbour(width, height, valid, mv, x0 - 1, y0 + 8 * (size_y / 8));
+    orc_nb l = orc_mvp_neighbour(width, height, valid, mv, x0 - 1, y0 + 8 * (size_y / 8 - 1));
+    orc_nb tr = orc_mvp_neighbour(width, height, valid, mv, x0 + 8 * (size_x / 8), y0 - 1);
+    orc_nb t = orc_mvp_neighbour(width, height, valid, mv, x0 + 8 * (size_x / 8 - 1), y0 - 1);
+    orc_nb tl = ftl;
+    bl.ok = fbl.ok; l.ok = fl.ok; tr.ok = ftr.ok; t.ok = ft.ok;
+    memset(out, 0, 7 * 2 * sizeof(int16_t));
+    int n = 0;
+    const int grp_l = bl.ok || l.ok, grp_t = tr.ok || t.ok || tl.ok;
+    if (grp_l) { const orc_nb c = bl.ok ? bl : l; out[n][0] = c.x; out[n][1] = c.y; n++; }
+    if (grp_t) { const orc_nb c = tr.ok ? tr : t.ok ? t : tl; out[n][0] = c.x; out[n][1] = c.y; n++; }
+    if (grp_l && grp_t && out[0][0] == out[1][0] && out[0][1] == out[1][1]) out[1][0] = out[1][1] = 0;       /* :2748-2752 */
+    if (n < 2) out[1][0] = out[1][1] = 0;                                                                      /* :2756-2758 */
+    int16_t (*mrg)[2] = out + 2;
+    n = 0;
+#define ORC_PUSH(c) do { mrg[n][0] = (c).x; mrg[n][1] = (c).y; n++; } while (0)
+#define ORC_DIFF(a, b) ((a).x != (b).x || (a).y != (b).y)
+    if (!no_a1 && l.ok) ORC_PUSH(l);
+    if (!no_b1 && t.ok && (!l.ok || no_a1 || ORC_DIFF(l, t))) ORC_PUSH(t);
+    if (tr.ok && (!t.ok || no_b1 || ORC_DIFF(t, tr))) ORC_PUSH(tr);
+    if (bl.ok && (!l.ok || no_a1 || ORC_DIFF(l, bl))) ORC_PUSH(bl);
+    if (n < 4) {
+        if (tl.ok && (!l.ok || no_a1 || ORC_DIFF(l, tl)) && (!t.ok || no_b1 || ORC_DIFF(t, tl))) {
+            ORC_PUSH(tl);
+        } else {                                               /* a zero vector unless one is in the list already, :2794-2805 */
+            int zero = 0;
+            for (int i = 0; i < n; i++) zero += mrg[i][0] == 0 && mrg[i][1] == 0;
+            if (!zero) { mrg[n][0] = mrg[n][1] = 0; n++; }
+        }
+    }
+#undef ORC_PUSH
+#undef ORC_DIFF
+    return n;
+}

@@ -145,6 +145,16 @@ typedef struct {
 void orc_intra_search(const uint8_t *src, int src_stride, const uint8_t *ref_raw, int size, unsigned valids,
                       int strong_smoothing, const uint8_t mpm[3], double sqrt_lambda, orc_intra_result *out);
 
+/* xFillMvpCand (src/encode.cpp:2703-2809) on picture-level maps: the two AMVP candidates and the merge candidates of one
+ * PU (origin x0,y0, size_x x size_y luma samples, pu_mode 0 = 2Nx2N, 1 = 2NxN, 2 = Nx2N, pu_idx the PU's index in its CU).
+ * valid: one byte per 4x4 block, non-zero where the reference's mode cache would not read MODE_INVALID (coded already);
+ * mv: one vector per 8x8 block (x then y); width/4 resp. width/8 entries per row; everything outside the picture is
+ * invalid. Neighbours: below-left and left beside the PU's bottom-left corner, above-right, above and above-left at its
+ * top edge, exactly the cache entries the reference addresses (:2721-2732). out: amvp[2], then up to 5 merge candidates
+ * (entries past the returned count are zeroed here; the reference leaves them untouched). */
+int orc_fill_mvp_cand(int width, int height, const uint8_t *valid, const int16_t *mv, int x0, int y0, int size_x, int size_y,
+                      int pu_mode, int pu_idx, int16_t out[7][2]);
+
 /* Intra chroma mode search of xEncodeChromaCU (src/encode.cpp:4326-4365) for one CU: candidates planar, vertical (26),
  * horizontal (10), DC (1) and the luma mode, a candidate among the first four that equals the luma mode replaced by 34;
  * U and V predicted without the luma edge filters from their padded neighbouring samples (ref_u, ref_v: 4*size+1 bytes

@@ -69,6 +69,8 @@ def load():
     lib.orc_sao_apply_plane.argtypes = [vp, i, vp, i, i, i, i, vp]
     lib.orc_sao_stats_ctu.restype = None
     lib.orc_sao_stats_ctu.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, vp]
+    lib.orc_fill_mvp_cand.restype = i
+    lib.orc_fill_mvp_cand.argtypes = [i, i, vp, vp, i, i, i, i, i, i, vp]
     lib.orc_intra_chroma_search.restype = None
     lib.orc_intra_chroma_search.argtypes = [vp, vp, i, vp, vp, i, i, C.POINTER(OrcChromaResult)]
     lib.orc_deblock_strengths.restype = None

@@ -1,0 +1,80 @@
+"""GPU: MV predictor and merge candidate lists (xFillMvpCand) through the C ABI against the reference's compiled function
+(tests/golden/mvp_cand.npz) and against the oracle on a larger seeded picture."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from x265_amd import capi
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    lib = capi.load()
+    capi.check(lib.xmi_init(0))
+    return lib
+
+
+def run(L, w, h, valid, mv, reqs):
+    n = len(reqs)
+    d_valid, d_mv = torch.from_numpy(valid).cuda(), torch.from_numpy(mv).cuda()
+    d_req = torch.frombuffer(bytearray(bytes(reqs)), dtype=torch.uint8).cuda()
+    d_res = torch.full((n * C.sizeof(capi.MvpResult),), 0x5a, dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_mvp_candidates_dev(w, h, d_valid.data_ptr(), d_mv.data_ptr(), d_req.data_ptr(), n, d_res.data_ptr(), None))
+    torch.cuda.synchronize()
+    return (capi.MvpResult * n).from_buffer_copy(d_res.cpu().numpy().tobytes())
+
+
+def as_rows(r):
+    return [[r.amvp[0][0], r.amvp[0][1]], [r.amvp[1][0], r.amvp[1][1]]] + [[r.merge[k][0], r.merge[k][1]] for k in range(5)]
+
+
+def test_mvp_candidates_match_reference_golden(L):
+    g = np.load(os.path.join(GOLDEN, "mvp_cand.npz"))
+    w, h = (int(v) for v in g["size"])
+    req = g["req"]
+    reqs = (capi.MvpRequest * len(req))()
+    for k, r in enumerate(req):
+        reqs[k].x0, reqs[k].y0, reqs[k].size_x, reqs[k].size_y, reqs[k].pu_mode, reqs[k].pu_idx = (int(v) for v in r)
+    res = run(L, w, h, np.ascontiguousarray(g["valid"]), np.ascontiguousarray(g["mv"]), reqs)
+    for k in range(len(req)):
+        assert res[k].merge_count == int(g["count"][k]), f"PU {k}: merge count"
+        assert as_rows(res[k]) == g["cand"][k].tolist(), f"PU {k}"
+
+
+def test_mvp_candidates_match_oracle_and_mark_bad_requests(L):
+    orc = O.load()
+    rng = np.random.default_rng(12)
+    w, h = 1920, 1088
+    valid = (rng.random((h // 4, w // 4)) < 0.7).astype(np.uint8)
+    palette = rng.integers(-64, 65, (6, 2)).astype(np.int16)
+    palette[0] = 0
+    mv = np.ascontiguousarray(palette[rng.integers(0, 6, (h // 8, w // 8))])
+    n = 3000
+    reqs = (capi.MvpRequest * n)()
+    for k in range(n):
+        s = int(rng.choice([8, 16, 32, 64]))
+        mode = int(rng.integers(0, 3)) if s > 8 else 0
+        idx = int(rng.integers(0, 2)) if mode else 0
+        sx, sy = (s, s) if mode == 0 else ((s, s // 2) if mode == 1 else (s // 2, s))
+        reqs[k].size_x, reqs[k].size_y, reqs[k].pu_mode, reqs[k].pu_idx = sx, sy, mode, idx
+        reqs[k].x0 = int(rng.integers(0, (w - s) // 8 + 1)) * 8 + (sx if (mode == 2 and idx) else 0)
+        reqs[k].y0 = int(rng.integers(0, (h - s) // 8 + 1)) * 8 + (sy if (mode == 1 and idx) else 0)
+    reqs[5].x0, reqs[6].size_x, reqs[7].y0 = -8, 4, h
+    res = run(L, w, h, valid, mv, reqs)
+    for k in range(n):
+        if k in (5, 6, 7):
+            assert res[k].merge_count == -1
+            continue
+        out = np.zeros((7, 2), np.int16)
+        cnt = orc.orc_fill_mvp_cand(w, h, O.p(valid), O.p(mv), reqs[k].x0, reqs[k].y0, reqs[k].size_x, reqs[k].size_y, reqs[k].pu_mode,
+                                    reqs[k].pu_idx, O.p(out))
+        assert res[k].merge_count == cnt and as_rows(res[k]) == out.tolist(), f"PU {k}"
+    assert L.xmi_mvp_candidates_dev(w, h, None, None, None, 0, None, None) == 0
+    assert L.xmi_mvp_candidates_dev(w + 4, h, None, None, None, 1, None, None) == -1

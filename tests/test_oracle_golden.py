@@ -362,3 +362,17 @@ def test_intra_chroma_search_reproduces_encoder_trace(lib, golden_dir, n):
         assert list(out.modes) == [int(v) for v in bm[k, 1:6]], f"search {k}: candidate modes"
         assert list(out.satd_u) == [int(v) for v in g[f"n{n}_satd_u"][k]] and list(out.satd_v) == [int(v) for v in g[f"n{n}_satd_v"][k]], f"search {k}: SATDs"
         assert out.best_idx == int(bm[k, 0]) and out.best_mode == int(bm[k, 1 + out.best_idx]), f"search {k}: decision"
+
+
+def test_mvp_candidates_match_reference_golden(lib, golden_dir):
+    """orc_fill_mvp_cand on picture-level maps against the reference's compiled xFillMvpCand called on the cache
+    neighbourhoods cut out of the same maps (tests/golden/mvp_cand.npz: 600 PUs, 2Nx2N / 2NxN / Nx2N, coded and uncoded
+    neighbours, few distinct vectors so that the pruning comparisons fire)."""
+    g = np.load(os.path.join(golden_dir, "mvp_cand.npz"))
+    w, h = (int(v) for v in g["size"])
+    valid, mv = np.ascontiguousarray(g["valid"]), np.ascontiguousarray(g["mv"])
+    for k, (r, want, cnt) in enumerate(zip(g["req"], g["cand"], g["count"])):
+        out = np.full((7, 2), 99, np.int16)
+        n = lib.orc_fill_mvp_cand(w, h, O.p(valid), O.p(mv), *(int(v) for v in r), O.p(out))
+        assert n == int(cnt), f"PU {k}: merge count"
+        np.testing.assert_array_equal(out, want, err_msg=f"PU {k}")

@@ -50,6 +50,14 @@ class SaoStats(C.Structure):
     _fields_ = [("count", C.c_int32 * 33 * 5), ("offset_org", C.c_int32 * 33 * 5)]
 
 
+class MvpRequest(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size_x", C.c_uint8), ("size_y", C.c_uint8), ("pu_mode", C.c_uint8), ("pu_idx", C.c_uint8)]
+
+
+class MvpResult(C.Structure):
+    _fields_ = [("amvp", (C.c_int16 * 2) * 2), ("merge", (C.c_int16 * 2) * 5), ("merge_count", C.c_int32)]
+
+
 class ChromaRequest(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("size", C.c_uint8), ("luma_mode", C.c_uint8), ("reserved", C.c_uint8 * 2)]
 
@@ -143,6 +151,9 @@ def load():
         L.xmi_deblock_frame_dev.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp, vp]
         L.xmi_deblock_frame.restype = i
         L.xmi_deblock_frame.argtypes = [vp, vp, vp, C.POINTER(DeblockParams), vp, vp, vp]
+    if hasattr(L, "xmi_mvp_candidates_dev"):
+        L.xmi_mvp_candidates_dev.restype = i
+        L.xmi_mvp_candidates_dev.argtypes = [i, i, vp, vp, vp, i, vp, vp]
     if hasattr(L, "xmi_intra_chroma_search_batch_dev"):
         L.xmi_intra_chroma_search_batch_dev.restype = i
         L.xmi_intra_chroma_search_batch_dev.argtypes = [vp, vp, i, vp, vp, i, vp, vp]

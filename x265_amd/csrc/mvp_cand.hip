@@ -1,0 +1,108 @@
+// MV predictor and merge candidate lists for gfx950: xFillMvpCand (src/encode.cpp:2703-2809) for a batch of PUs.
+//
+// The reference derives, per PU, two AMVP candidates (what xMotionSearch is given as sMVP) and up to five merge
+// candidates from five neighbours - below-left, left, above-right, above, above-left - whose mode flags (one per 4x4
+// block, MODE_INVALID = not coded or outside) and motion vectors (one per 8x8 block) it reads from the CTU-local caches.
+// Here the flags and vectors are picture-level maps in device memory, so the PUs of a whole anti-diagonal of CTUs (or any
+// other set whose neighbours are final) are served by one launch: one thread per request, the reference's statements in
+// order. Entries of the merge list past the returned count are zero.
+#include "xmi_common.h"
+
+namespace {
+
+struct MvpParams {
+    const uint8_t *valid;
+    const short2 *mv;
+    const xmi_mvp_request *req;
+    xmi_mvp_result *res;
+    int width, height, n;
+};
+
+struct Nb {
+    bool ok;
+    short2 v;
+};
+
+// flag of the 4x4 block at luma position (fx, fy), vector of the 8x8 block at (vx, vy); both outside the picture: invalid
+__device__ __forceinline__ Nb neighbour(const MvpParams &p, int fx, int fy, int vx, int vy)
+{
+    Nb n = { false, make_short2(0, 0) };
+    if (fx >= 0 && fy >= 0 && fx < p.width && fy < p.height) n.ok = p.valid[(fy >> 2) * (p.width >> 2) + (fx >> 2)] != 0;
+    if (vx >= 0 && vy >= 0 && vx < p.width && vy < p.height) n.v = p.mv[(vy >> 3) * (p.width >> 3) + (vx >> 3)];
+    return n;
+}
+
+__device__ __forceinline__ bool differ(const Nb &a, const Nb &b) { return a.v.x != b.v.x || a.v.y != b.v.y; }
+
+__global__ void __launch_bounds__(256) mvp_cand_kernel(const MvpParams p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const xmi_mvp_request rq = p.req[i];
+    const int x0 = rq.x0, y0 = rq.y0, sx = rq.size_x, sy = rq.size_y;
+    xmi_mvp_result out = {};
+    if (x0 < 0 || y0 < 0 || sx < 8 || sy < 8 || sx > 64 || sy > 64 || x0 + sx > p.width || y0 + sy > p.height) {
+        out.merge_count = -1;                          // no PU of this picture: marked, so that the caller can tell
+        p.res[i] = out;
+        return;
+    }
+    const bool no_b1 = rq.pu_mode == 1 && rq.pu_idx == 1, no_a1 = rq.pu_mode == 2 && rq.pu_idx == 1;      // :2713-2714
+    // the cache entries of :2721-2732: flags at 4x4, vectors at 8x8 granularity relative to the PU
+    const Nb bl = neighbour(p, x0 - 1, y0 + sy, x0 - 1, y0 + 8 * (sy / 8));
+    const Nb l = neighbour(p, x0 - 1, y0 + sy - 4, x0 - 1, y0 + 8 * (sy / 8 - 1));
+    const Nb tr = neighbour(p, x0 + sx, y0 - 1, x0 + 8 * (sx / 8), y0 - 1);
+    const Nb t = neighbour(p, x0 + sx - 4, y0 - 1, x0 + 8 * (sx / 8 - 1), y0 - 1);
+    const Nb tl = neighbour(p, x0 - 1, y0 - 1, x0 - 1, y0 - 1);
+    int n = 0;
+    const bool grp_l = bl.ok || l.ok, grp_t = tr.ok || t.ok || tl.ok;
+    short2 a[2] = { make_short2(0, 0), make_short2(0, 0) };
+    if (grp_l) a[n++] = bl.ok ? bl.v : l.v;
+    if (grp_t) {
+        const short2 c = tr.ok ? tr.v : t.ok ? t.v : tl.v;
+        if (n == 0) a[0] = c; else a[1] = c;
+        n++;
+    }
+    if (grp_l && grp_t && a[0].x == a[1].x && a[0].y == a[1].y) a[1] = make_short2(0, 0);      // :2748-2752
+    if (n < 2) a[1] = make_short2(0, 0);                                                         // :2756-2758
+    out.amvp[0][0] = a[0].x; out.amvp[0][1] = a[0].y;
+    out.amvp[1][0] = a[1].x; out.amvp[1][1] = a[1].y;
+    n = 0;
+    auto push = [&](short2 v) {
+        out.merge[n][0] = v.x;
+        out.merge[n][1] = v.y;
+        n++;
+    };
+    if (!no_a1 && l.ok) push(l.v);
+    if (!no_b1 && t.ok && (!l.ok || no_a1 || differ(l, t))) push(t.v);
+    if (tr.ok && (!t.ok || no_b1 || differ(t, tr))) push(tr.v);
+    if (bl.ok && (!l.ok || no_a1 || differ(l, bl))) push(bl.v);
+    if (n < 4) {
+        if (tl.ok && (!l.ok || no_a1 || differ(l, tl)) && (!t.ok || no_b1 || differ(t, tl))) {
+            push(tl.v);
+        } else {                                       // a zero vector unless the list holds one already, :2794-2805
+            bool zero = false;
+            for (int k = 0; k < n; k++) zero |= out.merge[k][0] == 0 && out.merge[k][1] == 0;
+            if (!zero) push(make_short2(0, 0));
+        }
+    }
+    out.merge_count = n;
+    p.res[i] = out;
+}
+
+}  // namespace
+
+extern "C" int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const int16_t *d_mv, const xmi_mvp_request *d_req, int n,
+                                      xmi_mvp_result *d_res, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_mvp_candidates_dev: negative request count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(width >= 8 && height >= 8 && width % 8 == 0 && height % 8 == 0, "xmi_mvp_candidates_dev: picture %dx%d must be a multiple of 8", width, height);
+    XMI_ARG(d_valid && d_mv && d_req && d_res, "xmi_mvp_candidates_dev: null argument");
+    XMI_ARG(((uintptr_t)d_mv & 3) == 0, "xmi_mvp_candidates_dev: motion vectors must be 4-byte aligned");
+    MvpParams p = { d_valid, reinterpret_cast<const short2 *>(d_mv), d_req, d_res, width, height, n };
+    hipLaunchKernelGGL(mvp_cand_kernel, dim3((n + 255) / 256), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
