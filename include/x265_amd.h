@@ -151,6 +151,10 @@ typedef struct xmi_mvp_result {
 int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const int16_t *d_mv, const xmi_mvp_request *d_req, int n,
                            xmi_mvp_result *d_res, void *stream);
 
+/* xCuMvClip (src/encode.cpp:3794-3812): the integer clip box (mv_min_ipel / mv_max_ipel of xmi_me_request) of the searches
+ * in CTU (ctu_x, ctu_y) of a picture of ctus_w x ctus_h CTUs. Host arithmetic; needs no device. */
+int xmi_cu_mv_clip(int ctu_x, int ctu_y, int ctus_w, int ctus_h, int16_t mv_min_ipel[2], int16_t mv_max_ipel[2]);
+
 /* ---- intra luma mode search ---------------------------------------------------------------------
  * The 35-mode SATD search of xEncDecideCU_Intra (src/encode.cpp:4005-4081) for a batch of PUs, one request per
  * PU, with what the reference has at that point of its CTU loop: the PU's source pixels (taken from the

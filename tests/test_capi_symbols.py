@@ -91,3 +91,22 @@ def test_reference_library_binds_to_the_dropin():
     allowed["_Z13xEncIntraPredPhS_jjjj"].add("x265_gpu_all")
     wrong = {k: v for k, v in bound.items() if v not in allowed[k]}
     assert not wrong, f"bound to the reference's own definitions: {wrong}"
+
+
+def test_cu_mv_clip_reproduces_the_boxes_of_a_real_encode():
+    """xmi_cu_mv_clip (host arithmetic, no device) against the clip boxes the reference's encoder handed to its motion
+    searches (tests/golden/me_trace.npz: every request of three P pictures of the 448x256 coded clip carries its box)."""
+    import ctypes as C
+    import numpy as np
+    from x265_amd import capi
+    L = capi.load()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "me_trace.npz"))
+    seen = set()
+    for poc in g["pocs"]:
+        for r in g[f"p{poc}_req"]:
+            mn, mx = (C.c_int16 * 2)(), (C.c_int16 * 2)()
+            assert L.xmi_cu_mv_clip(int(r[0]) // 64, int(r[1]) // 64, 7, 4, mn, mx) == 0
+            assert (mn[0], mn[1], mx[0], mx[1]) == tuple(int(v) for v in r[8:12]), f"CTU {int(r[0]) // 64},{int(r[1]) // 64}"
+            seen.add((int(r[0]) // 64, int(r[1]) // 64))
+    assert len(seen) >= 10 and {c[0] for c in seen} >= {0, 6} and {c[1] for c in seen} >= {0, 3}      # both picture edges in both directions
+    assert L.xmi_cu_mv_clip(7, 0, 7, 4, mn, mx) == -1

@@ -106,3 +106,19 @@ extern "C" int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_va
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
+
+// xCuMvClip (src/encode.cpp:3794-3812): the integer clip box of every search in CTU (ctu_x, ctu_y) of a picture of
+// ctus_w x ctus_h CTUs, with the reference's constants (MAX_IMV_VAL 64, MAX_CU_SIZE 64, PAD_YSIZE 80). The reference
+// refreshes the y range only at ctu_x == 0, which gives every CTU of a row the row's range. Host arithmetic, no device.
+extern "C" int xmi_cu_mv_clip(int ctu_x, int ctu_y, int ctus_w, int ctus_h, int16_t mv_min_ipel[2], int16_t mv_max_ipel[2])
+{
+    XMI_ARG(mv_min_ipel && mv_max_ipel, "xmi_cu_mv_clip: null argument");
+    XMI_ARG(ctus_w > 0 && ctus_h > 0 && ctu_x >= 0 && ctu_y >= 0 && ctu_x < ctus_w && ctu_y < ctus_h, "xmi_cu_mv_clip: CTU %d,%d of %dx%d", ctu_x, ctu_y,
+            ctus_w, ctus_h);
+    auto clip = [](int v) { return v < -64 ? -64 : v > 64 ? 64 : v; };
+    mv_min_ipel[0] = (int16_t)clip(-64 * ctu_x - (80 - 16));
+    mv_max_ipel[0] = (int16_t)clip(64 * (ctus_w - ctu_x) + (80 - 64) - 16);
+    mv_min_ipel[1] = (int16_t)clip(-64 * ctu_y - (80 - 16));
+    mv_max_ipel[1] = (int16_t)clip(64 * (ctus_h - ctu_y) + (80 - 64) - 16);
+    return XMI_OK;
+}
