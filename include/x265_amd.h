@@ -151,6 +151,12 @@ typedef struct xmi_mvp_result {
 int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const int16_t *d_mv, const xmi_mvp_request *d_req, int n,
                            xmi_mvp_result *d_res, void *stream);
 
+/* xFillMvpCand with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of
+ * the CTU-local caches (MAX_PU_XY + 2 = 18 flags per row with MODE_INVALID = 255, MAX_MV_XY + 2 = 10 vectors per row).
+ * Writes mvp[0], mvp[1] and mvp[2 .. 2 + count) and returns count (< 0 on error); runs the batch kernel on one request. */
+int xmi_fill_mvp_cand(int16_t (*mvp)[2], const uint8_t *mode_y, const int16_t (*mv)[2], uint32_t size_x, uint32_t size_y, uint32_t pu_mode,
+                      uint32_t pu_idx);
+
 /* xCuMvClip (src/encode.cpp:3794-3812): the integer clip box (mv_min_ipel / mv_max_ipel of xmi_me_request) of the searches
  * in CTU (ctu_x, ctu_y) of a picture of ctus_w x ctus_h CTUs. Host arithmetic; needs no device. */
 int xmi_cu_mv_clip(int ctu_x, int ctu_y, int ctus_w, int ctus_h, int16_t mv_min_ipel[2], int16_t mv_max_ipel[2]);

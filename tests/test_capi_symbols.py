@@ -46,7 +46,8 @@ def test_dropin_exports_the_reference_primitive_interface():
     # mangled names are the ones an object compiled from the reference's encode.cpp imports
     want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "xSatd_AMP", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType",
             "_Z8xDeQuantPsS_jjii", "_Z8xIDctAddPhjPsjS_S0_S0_ij", "xmi_install_primitives",
-            "_Z17xPredInterLumaBlkPKhPhjjj3xMVPs", "_Z19xPredInterChromaBlkPKhPhjjj3xMVPs", "_Z13xEncIntraPredPhS_jjjj"}
+            "_Z17xPredInterLumaBlkPKhPhjjj3xMVPs", "_Z19xPredInterChromaBlkPKhPhjjj3xMVPs", "_Z13xEncIntraPredPhS_jjjj",
+            "_Z12xFillMvpCandP3xMVPKhPKS_jjjj"}
     assert want <= exported(DROPIN)
 
 
@@ -79,7 +80,7 @@ def test_reference_library_binds_to_the_dropin():
     log = subprocess.run([GPU_ALL], env=env, capture_output=True, text=True, timeout=60).stderr
     want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType", "_Z8xDeQuantPsS_jjii",
             "_Z8xIDctAddPhjPsjS_S0_S0_ij", "_Z17xPredInterLumaBlkPKhPhjjj3xMVPs", "_Z19xPredInterChromaBlkPKhPhjjj3xMVPs",
-            "_Z13xEncIntraPredPhS_jjjj"}
+            "_Z13xEncIntraPredPhS_jjjj", "_Z12xFillMvpCandP3xMVPKhPKS_jjjj"}
     bound = {}
     for line in log.splitlines():
         m = re.search(r"binding file \S*libx265ref_me\.so \[0\] to (\S+) \[0\]: normal symbol `([^']+)'", line)

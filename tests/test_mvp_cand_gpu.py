@@ -78,3 +78,31 @@ def test_mvp_candidates_match_oracle_and_mark_bad_requests(L):
         assert res[k].merge_count == cnt and as_rows(res[k]) == out.tolist(), f"PU {k}"
     assert L.xmi_mvp_candidates_dev(w, h, None, None, None, 0, None, None) == 0
     assert L.xmi_mvp_candidates_dev(w + 4, h, None, None, None, 1, None, None) == -1
+
+
+def test_percall_form_on_cache_neighbourhoods(L):
+    """xmi_fill_mvp_cand with the reference's arguments: the cache neighbourhoods of the golden PUs, rebuilt as
+    oracle/gen_golden.py cut them; entries past the count stay as they were."""
+    g = np.load(os.path.join(GOLDEN, "mvp_cand.npz"))
+    w, h = (int(v) for v in g["size"])
+    valid, mv = g["valid"], g["mv"]
+    for k in range(0, len(g["req"]), 3):
+        x0, y0, sx, sy, mode, idx = (int(v) for v in g["req"][k])
+        modes = np.full((18, 18), 255, np.uint8)
+        mvs = np.zeros((10, 10, 2), np.int16)
+        for r in range(-1, 17):
+            for c in range(-1, 17):
+                yy, xx = y0 // 4 + r, x0 // 4 + c
+                if 0 <= yy < h // 4 and 0 <= xx < w // 4 and valid[yy, xx]:
+                    modes[r + 1, c + 1] = 0
+        for r in range(-1, 9):
+            for c in range(-1, 9):
+                yy, xx = y0 // 8 + r, x0 // 8 + c
+                if 0 <= yy < h // 8 and 0 <= xx < w // 8:
+                    mvs[r + 1, c + 1] = mv[yy, xx]
+        out = np.full((7, 2), 0x7777, np.int16)
+        cnt = L.xmi_fill_mvp_cand(O.p(out), O.at(modes, 1, 1), C.c_void_p(mvs.ctypes.data + 11 * 4), sx, sy, mode, idx)
+        assert cnt == int(g["count"][k]), f"PU {k}"
+        np.testing.assert_array_equal(out[:2 + cnt], g["cand"][k][:2 + cnt], err_msg=f"PU {k}")
+        assert (out[2 + cnt:] == 0x7777).all()
+    assert L.xmi_fill_mvp_cand(O.p(out), O.at(modes, 1, 1), C.c_void_p(mvs.ctypes.data + 11 * 4), 4, 8, 0, 0) == -1

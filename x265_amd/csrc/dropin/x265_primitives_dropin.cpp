@@ -5,7 +5,7 @@
 // function pointers plus free functions: xSubDct, xQuant, xDeQuant, xIDctAdd (inc/x265.h:650-670, defined in
 // src/pixel.cpp:529-542, 711-717, 810-816, 833-857, 1054, 1244, 3446, 5938) and the prediction functions
 // xPredInterLumaBlk, xPredInterChromaBlk, xEncIntraPred (declared in src/encode.cpp:38, 60-79, defined in
-// src/pixel.cpp:8745, 9657, 7338). This file defines exactly those symbols, so that
+// src/pixel.cpp:8745, 9657, 7338), plus xFillMvpCand of src/encode.cpp:2703. This file defines exactly those symbols, so that
 //   (a) an encoder build that links this object INSTEAD of its own definitions uses the GPU, or
 //   (b) an unmodified encoder calls xmi_install_primitives() once to overwrite the entries of its own
 //       tables (they are non-const globals) and wraps the four free functions at link time.
@@ -115,6 +115,13 @@ void xPredInterLumaBlk(CUInt8 *pucRef, UInt8 *pucPred, CUInt32 nRefStride, CUInt
 void xPredInterChromaBlk(CUInt8 *pucRefC, UInt8 *pucPredC, CUInt32 nRefStrideC, CUInt nSizeCX, CUInt nSizeCY, xMV bmv, Int16 *)
 {
     must(xmi_pred_inter_chroma(pucRefC, pucPredC, nRefStrideC, nSizeCX, nSizeCY, bmv.x, bmv.y), "xPredInterChromaBlk");
+}
+
+// src/encode.cpp:2703: MV predictor and merge candidates of one PU from the CTU-local caches
+Int xFillMvpCand(xMV *psMVP, CUInt8 *pucModeY, const xMV *psMV, CUInt nSizeX, CUInt nSizeY, CUInt32 ePUMode, CUInt32 nPUIdx)
+{
+    return (Int)must(xmi_fill_mvp_cand(reinterpret_cast<int16_t (*)[2]>(psMVP), pucModeY, reinterpret_cast<const int16_t (*)[2]>(psMV), nSizeX, nSizeY,
+                                       ePUMode, nPUIdx), "xFillMvpCand");
 }
 
 void xEncIntraPred(UInt8 *pucDstY, UInt8 *pucRefY, UInt nStride, UInt nMode, UInt nSize, UInt bIsLuma)

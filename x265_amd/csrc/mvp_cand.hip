@@ -8,6 +8,9 @@
 // order. Entries of the merge list past the returned count are zero.
 #include "xmi_common.h"
 
+#include <cstring>
+#include <mutex>
+
 namespace {
 
 struct MvpParams {
@@ -105,6 +108,53 @@ extern "C" int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_va
     hipLaunchKernelGGL(mvp_cand_kernel, dim3((n + 255) / 256), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
+}
+
+// Per-call form with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of the
+// CTU-local caches (pitch 18 flags per 4x4 row, MODE_INVALID = 255; pitch 10 vectors per 8x8 row). The five flag and
+// five vector entries the function addresses are copied into a small picture of their own - the PU at (8, 8), one 4x4
+// block of border around it - and the batch kernel runs on one request. Returns the merge count; writes mvp[0], mvp[1]
+// and mvp[2 .. 2 + count), nothing beyond, as the reference.
+extern "C" int xmi_fill_mvp_cand(int16_t (*mvp)[2], const uint8_t *mode_y, const int16_t (*mv)[2], uint32_t size_x, uint32_t size_y, uint32_t pu_mode,
+                                 uint32_t pu_idx)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(mvp && mode_y && mv, "xmi_fill_mvp_cand: null argument");
+    XMI_ARG(size_x >= 8 && size_y >= 8 && size_x <= 64 && size_y <= 64 && size_x % 8 == 0 && size_y % 8 == 0, "xmi_fill_mvp_cand: PU %ux%u", size_x, size_y);
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    constexpr int W = 8 + 64 + 8, W4 = W / 4, W8 = W / 8;         // PU at (8, 8) of an 80 x 80 picture
+    const int bx = (int)size_x / 4, by = (int)size_y / 4, mx = (int)size_x / 8, my = (int)size_y / 8;
+    // staging: valid map | vector map | request | result
+    const size_t off_mv = 512, off_req = off_mv + (size_t)W8 * W8 * 4, off_res = off_req + 16, total = off_res + sizeof(xmi_mvp_result);
+    static_assert((size_t)W4 * W4 <= 512 && sizeof(xmi_mvp_request) <= 16, "staging layout");
+    uint8_t host[512 + W8 * W8 * 4 + 16];
+    memset(host, 0, sizeof host);
+    uint8_t *valid = host;
+    int16_t *vec = reinterpret_cast<int16_t *>(host + off_mv);
+    auto flag = [&](int r, int c) { valid[(2 + r) * W4 + 2 + c] = mode_y[r * 18 + c] != 255; };        // 4x4 units relative to the PU
+    auto vect = [&](int r, int c) {                                                                   // 8x8 units relative to the PU
+        vec[2 * ((1 + r) * W8 + 1 + c)] = mv[r * 10 + c][0];
+        vec[2 * ((1 + r) * W8 + 1 + c) + 1] = mv[r * 10 + c][1];
+    };
+    flag(by, -1); flag(by - 1, -1); flag(-1, bx); flag(-1, bx - 1); flag(-1, -1);
+    vect(my, -1); vect(my - 1, -1); vect(-1, mx); vect(-1, mx - 1); vect(-1, -1);
+    xmi_mvp_request rq = { 8, 8, (uint8_t)size_x, (uint8_t)size_y, (uint8_t)pu_mode, (uint8_t)pu_idx };
+    memcpy(host + off_req, &rq, sizeof rq);
+    uint8_t *dev = static_cast<uint8_t *>(xmi::scratch(6, total));
+    if (!dev) return XMI_ERR_HIP;
+    XMI_HIP(hipMemcpy(dev, host, sizeof host, hipMemcpyHostToDevice));
+    // the picture is 80 x 80 only when the PU is 64 x 64; a smaller PU leaves the rest of the maps unused (all zero, i.e. not coded)
+    rc = xmi_mvp_candidates_dev(W, W, dev, reinterpret_cast<const int16_t *>(dev + off_mv), reinterpret_cast<const xmi_mvp_request *>(dev + off_req), 1,
+                                reinterpret_cast<xmi_mvp_result *>(dev + off_res), nullptr);
+    if (rc != XMI_OK) return rc;
+    xmi_mvp_result res;
+    XMI_HIP(hipMemcpy(&res, dev + off_res, sizeof res, hipMemcpyDeviceToHost));
+    XMI_ARG(res.merge_count >= 0, "xmi_fill_mvp_cand: request refused");
+    memcpy(mvp, res.amvp, sizeof res.amvp);
+    memcpy(mvp + 2, res.merge, (size_t)res.merge_count * 4);
+    return res.merge_count;
 }
 
 // xCuMvClip (src/encode.cpp:3794-3812): the integer clip box of every search in CTU (ctu_x, ctu_y) of a picture of
