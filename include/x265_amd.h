@@ -151,6 +151,13 @@ typedef struct xmi_mvp_result {
 int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const int16_t *d_mv, const xmi_mvp_request *d_req, int n,
                            xmi_mvp_result *d_res, void *stream);
 
+/* Search requests from candidate lists, on the device: d_req[i] gets PU i's origin and size (square PUs), its AMVP pair as
+ * mvp, d_zero_mv_tested[i] (0 when the array is null), the clip box of its CTU (as xmi_cu_mv_clip) and sqrt_lambda - what
+ * xEncDecideCU_Inter assembles before it calls xMotionSearch (src/encode.cpp:3379). A PU that xmi_mvp_candidates_dev
+ * refused or that is not square becomes a request with size 0, which the search refuses in turn. */
+int xmi_me_requests_from_candidates_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_mvp_result *d_cand,
+                                        const uint8_t *d_zero_mv_tested, int n, uint32_t sqrt_lambda, xmi_me_request *d_req, void *stream);
+
 /* xFillMvpCand with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of
  * the CTU-local caches (MAX_PU_XY + 2 = 18 flags per row with MODE_INVALID = 255, MAX_MV_XY + 2 = 10 vectors per row).
  * Writes mvp[0], mvp[1] and mvp[2 .. 2 + count) and returns count (< 0 on error); runs the batch kernel on one request. */

@@ -106,3 +106,43 @@ def test_percall_form_on_cache_neighbourhoods(L):
         np.testing.assert_array_equal(out[:2 + cnt], g["cand"][k][:2 + cnt], err_msg=f"PU {k}")
         assert (out[2 + cnt:] == 0x7777).all()
     assert L.xmi_fill_mvp_cand(O.p(out), O.at(modes, 1, 1), C.c_void_p(mvs.ctypes.data + 11 * 4), 4, 8, 0, 0) == -1
+
+
+def test_search_requests_built_on_the_device(L):
+    """maps -> xmi_mvp_candidates_dev -> xmi_me_requests_from_candidates_dev: every request equals the one put together on the
+    host from the candidate kernel's result and xmi_cu_mv_clip; refused or non-square PUs become size-0 requests."""
+    rng = np.random.default_rng(5)
+    w, h = 448, 256
+    valid = (rng.random((h // 4, w // 4)) < 0.75).astype(np.uint8)
+    mv = rng.integers(-80, 81, (h // 8, w // 8, 2)).astype(np.int16)
+    n = 500
+    pus = (capi.MvpRequest * n)()
+    for k in range(n):
+        s = int(rng.choice([8, 16, 32, 64]))
+        pus[k].size_x = pus[k].size_y = s
+        pus[k].x0, pus[k].y0 = int(rng.integers(0, (w - s) // 8 + 1)) * 8, int(rng.integers(0, (h - s) // 8 + 1)) * 8
+    pus[3].size_y, pus[3].pu_mode = pus[3].size_x // 2 if pus[3].size_x > 8 else 8, 1
+    pus[4].x0 = w            # outside: refused by the candidate kernel
+    zero = rng.integers(0, 2, n).astype(np.uint8)
+    d_valid, d_mv, d_zero = torch.from_numpy(valid).cuda(), torch.from_numpy(mv).cuda(), torch.from_numpy(zero).cuda()
+    d_pu = torch.frombuffer(bytearray(bytes(pus)), dtype=torch.uint8).cuda()
+    d_cand = torch.zeros(n * C.sizeof(capi.MvpResult), dtype=torch.uint8, device="cuda")
+    d_req = torch.full((n * C.sizeof(capi.MeRequest),), 0x5a, dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_mvp_candidates_dev(w, h, d_valid.data_ptr(), d_mv.data_ptr(), d_pu.data_ptr(), n, d_cand.data_ptr(), None))
+    capi.check(L.xmi_me_requests_from_candidates_dev(w, h, d_pu.data_ptr(), d_cand.data_ptr(), d_zero.data_ptr(), n, 9, d_req.data_ptr(), None))
+    torch.cuda.synchronize()
+    cand = (capi.MvpResult * n).from_buffer_copy(d_cand.cpu().numpy().tobytes())
+    req = (capi.MeRequest * n).from_buffer_copy(d_req.cpu().numpy().tobytes())
+    for k in range(n):
+        r = req[k]
+        if k == 4 or pus[k].size_x != pus[k].size_y:
+            assert r.size == 0, f"PU {k}"
+            continue
+        mn, mx = (C.c_int16 * 2)(), (C.c_int16 * 2)()
+        capi.check(L.xmi_cu_mv_clip(pus[k].x0 // 64, pus[k].y0 // 64, w // 64, h // 64, mn, mx))
+        got = (r.x0, r.y0, r.size, r.mvp[0][0], r.mvp[0][1], r.mvp[1][0], r.mvp[1][1], r.zero_mv_tested, r.mv_min_ipel[0], r.mv_min_ipel[1],
+               r.mv_max_ipel[0], r.mv_max_ipel[1], r.sqrt_lambda)
+        want = (pus[k].x0, pus[k].y0, pus[k].size_x, cand[k].amvp[0][0], cand[k].amvp[0][1], cand[k].amvp[1][0], cand[k].amvp[1][1], int(zero[k]),
+                mn[0], mn[1], mx[0], mx[1], 9)
+        assert got == want, f"PU {k}"
+    assert L.xmi_me_requests_from_candidates_dev(100, h, d_pu.data_ptr(), d_cand.data_ptr(), None, n, 9, d_req.data_ptr(), None) == -1

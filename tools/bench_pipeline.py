@@ -53,6 +53,16 @@ for i, (x, y, n) in enumerate(reqs):
     rq.sqrt_lambda = int(math.sqrt(0.578 * 2 ** ((32 - 12) / 3.0)))
 d_me = torch.frombuffer(bytearray(bytes(me)), dtype=torch.uint8).cuda()
 d_me_res = torch.zeros(nreq * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+# the same searches derived on the device: a motion field near the true motion and a map of coded blocks stand for the
+# neighbours' decisions; candidates (xFillMvpCand) and request table are then built by two small kernels per picture
+mv_field = torch.from_numpy((np.array([-12, -8]) + rng.integers(-4, 5, (H // 8, W // 8, 2))).astype(np.int16)).cuda()
+coded = torch.ones((H // 4, W // 4), dtype=torch.uint8, device="cuda")
+pus = (capi.MvpRequest * nreq)()
+for i, (x, y, n) in enumerate(reqs):
+    pus[i].x0, pus[i].y0, pus[i].size_x, pus[i].size_y = x, y, n, n
+d_pus = torch.frombuffer(bytearray(bytes(pus)), dtype=torch.uint8).cuda()
+d_cand = torch.zeros(nreq * C.sizeof(capi.MvpResult), dtype=torch.uint8, device="cuda")
+d_me_built = torch.zeros(nreq * C.sizeof(capi.MeRequest), dtype=torch.uint8, device="cuda")
 
 # final partition for prediction + transform: 16x16 PUs over the whole picture, one 16x16 luma TU and two 8x8 chroma TUs each
 pus = [(x, y) for y in range(0, H, 16) for x in range(0, W, 16)]
@@ -120,14 +130,17 @@ def filters(stream):
 
 def picture(stream, surface):
     capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, rows, stride, planes.data_ptr(), stream))
+    capi.check(L.xmi_mvp_candidates_dev(W, H, coded.data_ptr(), mv_field.data_ptr(), d_pus.data_ptr(), nreq, d_cand.data_ptr(), stream))
+    capi.check(L.xmi_me_requests_from_candidates_dev(W, H, d_pus.data_ptr(), d_cand.data_ptr(), None, nreq, int(math.sqrt(0.578 * 2 ** ((32 - 12) / 3.0))),
+                                                     d_me_built.data_ptr(), stream))
     if surface:
         capi.check(L.xmi_sad_surface_dev(C.byref(geom), cur.data_ptr(), ref.data_ptr() + PAD * stride + PAD, sp[0].data_ptr(), sp[1].data_ptr(),
                                          sp[2].data_ptr(), sp[3].data_ptr(), 0, nctu, stream))
         capi.check(L.xmi_me_search_surface_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, C.byref(geom), sp[0].data_ptr(),
-                                                     sp[1].data_ptr(), sp[2].data_ptr(), sp[3].data_ptr(), d_me.data_ptr(), nreq, 32,
+                                                     sp[1].data_ptr(), sp[2].data_ptr(), sp[3].data_ptr(), d_me_built.data_ptr(), nreq, 32,
                                                      d_me_res.data_ptr(), stream))
     else:
-        capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_me.data_ptr(), nreq, 32,
+        capi.check(L.xmi_me_search_batch_dev(cur.data_ptr(), W, planes.data_ptr(), stride, rows, PAD, d_me_built.data_ptr(), nreq, 32,
                                              d_me_res.data_ptr(), stream))
     capi.check(L.xmi_pred_inter_batch_dev(ref.data_ptr() + PAD * stride + PAD, stride, ref_u.data_ptr() + cpad * cstride + cpad,
                                           ref_v.data_ptr() + cpad * cstride + cpad, cstride, d_pr.data_ptr(), npu, pred_y.data_ptr(),
@@ -166,7 +179,7 @@ for surface in (False, True):
     b.record()
     torch.cuda.synchronize()
     t_eager = a.elapsed_time(b) / iters
-    print(json.dumps({"pipeline": "1080p P picture: planes" + (" + SAD surface (R=64)" if surface else "") + f" + {nreq} motion searches"
+    print(json.dumps({"pipeline": "1080p P picture: planes + MV candidates and search requests of " + str(nreq) + " PUs" + (" + SAD surface (R=64)" if surface else "") + f" + {nreq} motion searches"
                       + (" (integer SADs from the surface)" if surface else "") + f" + {npu} PUs predicted (Y, U, V) + {3 * npu} TU chains + boundary strengths + deblocking + SAO statistics and offsets + padding",
                       "ms_graph": round(t_graph, 3), "ms_eager": round(t_eager, 3), "pictures_per_s_graph": round(1e3 / t_graph, 1),
                       "coded_levels_nonzero_tus": int((sum_y != 0).sum().item())}))

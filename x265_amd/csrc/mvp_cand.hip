@@ -110,6 +110,43 @@ extern "C" int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_va
     return XMI_OK;
 }
 
+// Search requests from candidate lists, on the device: request i = PU i's origin and size (square PUs), its AMVP pair, the
+// clip box of its CTU (xCuMvClip, src/encode.cpp:3794-3812) and the caller's lambda term; what xEncDecideCU_Inter puts
+// together before it calls xMotionSearch (src/encode.cpp:3379). With it the chain maps -> candidates -> requests ->
+// searches needs no host table in between.
+struct BuildParams {
+    const xmi_mvp_request *pu;
+    const xmi_mvp_result *cand;
+    const uint8_t *zero_tested;
+    xmi_me_request *req;
+    int n, ctus_w, ctus_h;
+    uint32_t sqrt_lambda;
+};
+
+__global__ void __launch_bounds__(256) me_request_kernel(const BuildParams p)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const xmi_mvp_request pu = p.pu[i];
+    const xmi_mvp_result c = p.cand[i];
+    xmi_me_request rq = {};
+    rq.x0 = pu.x0;
+    rq.y0 = pu.y0;
+    // a PU the candidate kernel refused, or one that is not square, becomes a request the search kernel refuses (size 0)
+    rq.size = (c.merge_count >= 0 && pu.size_x == pu.size_y) ? pu.size_x : 0;
+    rq.mvp[0][0] = c.amvp[0][0]; rq.mvp[0][1] = c.amvp[0][1];
+    rq.mvp[1][0] = c.amvp[1][0]; rq.mvp[1][1] = c.amvp[1][1];
+    rq.zero_mv_tested = p.zero_tested ? p.zero_tested[i] != 0 : 0;
+    const int cx = pu.x0 >> 6, cy = pu.y0 >> 6;
+    auto clip = [](int v) { return v < -64 ? -64 : v > 64 ? 64 : v; };
+    rq.mv_min_ipel[0] = (int16_t)clip(-64 * cx - 64);
+    rq.mv_max_ipel[0] = (int16_t)clip(64 * (p.ctus_w - cx));
+    rq.mv_min_ipel[1] = (int16_t)clip(-64 * cy - 64);
+    rq.mv_max_ipel[1] = (int16_t)clip(64 * (p.ctus_h - cy));
+    rq.sqrt_lambda = p.sqrt_lambda;
+    p.req[i] = rq;
+}
+
 // Per-call form with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of the
 // CTU-local caches (pitch 18 flags per 4x4 row, MODE_INVALID = 255; pitch 10 vectors per 8x8 row). The five flag and
 // five vector entries the function addresses are copied into a small picture of their own - the PU at (8, 8), one 4x4
@@ -155,6 +192,22 @@ extern "C" int xmi_fill_mvp_cand(int16_t (*mvp)[2], const uint8_t *mode_y, const
     memcpy(mvp, res.amvp, sizeof res.amvp);
     memcpy(mvp + 2, res.merge, (size_t)res.merge_count * 4);
     return res.merge_count;
+}
+
+extern "C" int xmi_me_requests_from_candidates_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_mvp_result *d_cand,
+                                                   const uint8_t *d_zero_mv_tested, int n, uint32_t sqrt_lambda, xmi_me_request *d_req, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_me_requests_from_candidates_dev: negative request count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(width >= 64 && height >= 64 && width % 64 == 0 && height % 64 == 0, "xmi_me_requests_from_candidates_dev: picture %dx%d is not a multiple of the 64x64 CTU",
+            width, height);
+    XMI_ARG(d_pu && d_cand && d_req, "xmi_me_requests_from_candidates_dev: null argument");
+    BuildParams p = { d_pu, d_cand, d_zero_mv_tested, d_req, n, width / 64, height / 64, sqrt_lambda };
+    hipLaunchKernelGGL(me_request_kernel, dim3((n + 255) / 256), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
 }
 
 // xCuMvClip (src/encode.cpp:3794-3812): the integer clip box of every search in CTU (ctu_x, ctu_y) of a picture of
