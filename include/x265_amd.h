@@ -158,6 +158,12 @@ int xmi_mvp_candidates_dev(int width, int height, const uint8_t *d_valid, const 
 int xmi_me_requests_from_candidates_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_mvp_result *d_cand,
                                         const uint8_t *d_zero_mv_tested, int n, uint32_t sqrt_lambda, xmi_me_request *d_req, void *stream);
 
+/* The way back: the vectors of searches (d_res[i].mv of PU d_pu[i]; PUs on the 8x8 grid, results with mvp_idx < 0 skipped)
+ * stored into the picture-level maps - every 8x8 vector entry and 4x4 coded flag the PU covers -, as the reference's CU
+ * write-back does for its caches. PUs of one call must not overlap. */
+int xmi_mv_field_store_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_me_result *d_res, int n, uint8_t *d_valid,
+                           int16_t *d_mv, void *stream);
+
 /* xFillMvpCand with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of
  * the CTU-local caches (MAX_PU_XY + 2 = 18 flags per row with MODE_INVALID = 255, MAX_MV_XY + 2 = 10 vectors per row).
  * Writes mvp[0], mvp[1] and mvp[2 .. 2 + count) and returns count (< 0 on error); runs the batch kernel on one request. */

@@ -146,3 +146,38 @@ def test_search_requests_built_on_the_device(L):
                 mn[0], mn[1], mx[0], mx[1], 9)
         assert got == want, f"PU {k}"
     assert L.xmi_me_requests_from_candidates_dev(100, h, d_pu.data_ptr(), d_cand.data_ptr(), None, n, 9, d_req.data_ptr(), None) == -1
+
+
+def test_vectors_stored_back_into_the_maps(L):
+    """xmi_mv_field_store_dev: the PU's 8x8 vector entries and 4x4 coded flags, nothing else; refused results and PUs off
+    the picture are skipped."""
+    rng = np.random.default_rng(6)
+    w, h = 256, 128
+    pus, taken = [], np.zeros((h // 8, w // 8), bool)
+    while len(pus) < 60:                                   # non-overlapping PUs
+        s = int(rng.choice([8, 16, 32, 64]))
+        x0, y0 = int(rng.integers(0, (w - s) // 8 + 1)) * 8, int(rng.integers(0, (h - s) // 8 + 1)) * 8
+        if taken[y0 // 8:(y0 + s) // 8, x0 // 8:(x0 + s) // 8].any():
+            continue
+        taken[y0 // 8:(y0 + s) // 8, x0 // 8:(x0 + s) // 8] = True
+        pus.append((x0, y0, s))
+    n = len(pus) + 1
+    req = (capi.MvpRequest * n)()
+    res = (capi.MeResult * n)()
+    want_mv, want_valid = np.full((h // 8, w // 8, 2), 77, np.int16), np.zeros((h // 4, w // 4), np.uint8)
+    for k, (x0, y0, s) in enumerate(pus):
+        req[k].x0, req[k].y0, req[k].size_x, req[k].size_y = x0, y0, s, s
+        res[k].mv[0], res[k].mv[1] = int(rng.integers(-200, 201)), int(rng.integers(-200, 201))
+        res[k].mvp_idx = -1 if k % 13 == 5 else int(rng.integers(0, 2))
+        if res[k].mvp_idx >= 0:
+            want_mv[y0 // 8:(y0 + s) // 8, x0 // 8:(x0 + s) // 8] = (res[k].mv[0], res[k].mv[1])
+            want_valid[y0 // 4:(y0 + s) // 4, x0 // 4:(x0 + s) // 4] = 1
+    req[n - 1].x0, req[n - 1].y0, req[n - 1].size_x, req[n - 1].size_y = w - 8, 0, 16, 16      # sticks out: skipped
+    d_mv = torch.full((h // 8, w // 8, 2), 77, dtype=torch.int16, device="cuda")
+    d_valid = torch.zeros((h // 4, w // 4), dtype=torch.uint8, device="cuda")
+    d_req = torch.frombuffer(bytearray(bytes(req)), dtype=torch.uint8).cuda()
+    d_res = torch.frombuffer(bytearray(bytes(res)), dtype=torch.uint8).cuda()
+    capi.check(L.xmi_mv_field_store_dev(w, h, d_req.data_ptr(), d_res.data_ptr(), n, d_valid.data_ptr(), d_mv.data_ptr(), None))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d_mv.cpu().numpy(), want_mv)
+    np.testing.assert_array_equal(d_valid.cpu().numpy(), want_valid)

@@ -156,6 +156,8 @@ def load():
         L.xmi_mvp_candidates_dev.argtypes = [i, i, vp, vp, vp, i, vp, vp]
         L.xmi_me_requests_from_candidates_dev.restype = i
         L.xmi_me_requests_from_candidates_dev.argtypes = [i, i, vp, vp, vp, i, C.c_uint32, vp, vp]
+        L.xmi_mv_field_store_dev.restype = i
+        L.xmi_mv_field_store_dev.argtypes = [i, i, vp, vp, i, vp, vp, vp]
         L.xmi_fill_mvp_cand.restype = i
         L.xmi_fill_mvp_cand.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.xmi_cu_mv_clip.restype = i

@@ -147,6 +147,36 @@ __global__ void __launch_bounds__(256) me_request_kernel(const BuildParams p)
     p.req[i] = rq;
 }
 
+// The way back: the vectors the searches returned (or any final decision in the same form) stored into the picture-level
+// maps - the PU's area of 8x8 vector entries and of 4x4 coded flags -, which is what the reference's CU write-back does
+// for its caches (xEncCacheStoreCU / the MV cache updates of xEncDecideCU_Inter). One thread per (PU, 8x8 cell).
+struct StoreParams {
+    const xmi_mvp_request *pu;
+    const xmi_me_result *res;
+    uint8_t *valid;
+    short2 *mv;
+    int n, width, height;
+};
+
+__global__ void __launch_bounds__(256) mv_store_kernel(const StoreParams p)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), cell = threadIdx.x & 63;
+    if (i >= p.n) return;
+    const xmi_mvp_request pu = p.pu[i];
+    if (pu.x0 < 0 || pu.y0 < 0 || (pu.x0 & 7) || (pu.y0 & 7) || pu.size_x < 8 || pu.size_y < 8 || pu.size_x > 64 || pu.size_y > 64 ||
+        pu.x0 + pu.size_x > p.width || pu.y0 + pu.size_y > p.height)
+        return;
+    const xmi_me_result r = p.res[i];
+    if (r.mvp_idx < 0) return;                               // a refused search has no vector
+    const int cw = pu.size_x >> 3, ch = pu.size_y >> 3;
+    if (cell >= cw * ch) return;
+    const int cx = (pu.x0 >> 3) + cell % cw, cy = (pu.y0 >> 3) + cell / cw;
+    p.mv[cy * (p.width >> 3) + cx] = make_short2(r.mv[0], r.mv[1]);
+    uint8_t *v = p.valid + (2 * cy) * (p.width >> 2) + 2 * cx;
+    v[0] = v[1] = 1;
+    v[p.width >> 2] = v[(p.width >> 2) + 1] = 1;
+}
+
 // Per-call form with the reference's own arguments (src/encode.cpp:2703-2711): mode_y and mv point at the PU's entries of the
 // CTU-local caches (pitch 18 flags per 4x4 row, MODE_INVALID = 255; pitch 10 vectors per 8x8 row). The five flag and
 // five vector entries the function addresses are copied into a small picture of their own - the PU at (8, 8), one 4x4
@@ -192,6 +222,21 @@ extern "C" int xmi_fill_mvp_cand(int16_t (*mvp)[2], const uint8_t *mode_y, const
     memcpy(mvp, res.amvp, sizeof res.amvp);
     memcpy(mvp + 2, res.merge, (size_t)res.merge_count * 4);
     return res.merge_count;
+}
+
+extern "C" int xmi_mv_field_store_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_me_result *d_res, int n, uint8_t *d_valid,
+                                      int16_t *d_mv, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_mv_field_store_dev: negative count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(width >= 8 && height >= 8 && width % 8 == 0 && height % 8 == 0, "xmi_mv_field_store_dev: picture %dx%d must be a multiple of 8", width, height);
+    XMI_ARG(d_pu && d_res && d_valid && d_mv && ((uintptr_t)d_mv & 3) == 0, "xmi_mv_field_store_dev: null or unaligned argument");
+    StoreParams p = { d_pu, d_res, d_valid, reinterpret_cast<short2 *>(d_mv), n, width, height };
+    hipLaunchKernelGGL(mv_store_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
 }
 
 extern "C" int xmi_me_requests_from_candidates_dev(int width, int height, const xmi_mvp_request *d_pu, const xmi_mvp_result *d_cand,
