@@ -174,6 +174,23 @@ for n in (4, 8, 16, 32):
     print(json.dumps({"kernel": f"intra_search {n}x{n}", "requests": nreq, "ms": round(t * 1e3, 3),
                       "Msearch_per_s": round(nreq / t / 1e6, 2), "Gpixel_modes_per_s": round(nreq * n * n * 35 / t / 1e9, 1)}))
 
+# ---- motion-data glue of a 1080p P picture: candidates (xFillMvpCand), request table, vector write-back for 32 640 8x8 PUs ----
+npu8 = (W // 8) * (H // 8)
+pu8 = (capi.MvpRequest * npu8)()
+for i in range(npu8):
+    pu8[i].x0, pu8[i].y0, pu8[i].size_x, pu8[i].size_y = (i % (W // 8)) * 8, (i // (W // 8)) * 8, 8, 8
+d_pu8 = torch.frombuffer(bytearray(bytes(pu8)), dtype=torch.uint8).cuda()
+d_cd8 = torch.zeros(npu8 * C.sizeof(capi.MvpResult), dtype=torch.uint8, device="cuda")
+d_rq8 = torch.zeros(npu8 * C.sizeof(capi.MeRequest), dtype=torch.uint8, device="cuda")
+d_rs8 = torch.zeros(npu8 * C.sizeof(capi.MeResult), dtype=torch.uint8, device="cuda")
+vmap = torch.ones((H // 4, W // 4), dtype=torch.uint8, device="cuda")
+mmap = torch.randint(-40, 41, (H // 8, W // 8, 2), device="cuda", generator=g).to(torch.int16)
+for name, fn in (("mvp_candidates", lambda: L.xmi_mvp_candidates_dev(W, H, vmap.data_ptr(), mmap.data_ptr(), d_pu8.data_ptr(), npu8, d_cd8.data_ptr(), s)),
+                 ("me_requests_from_candidates", lambda: L.xmi_me_requests_from_candidates_dev(W, H, d_pu8.data_ptr(), d_cd8.data_ptr(), None, npu8, 9, d_rq8.data_ptr(), s)),
+                 ("mv_field_store", lambda: L.xmi_mv_field_store_dev(W, H, d_pu8.data_ptr(), d_rs8.data_ptr(), npu8, vmap.data_ptr(), mmap.data_ptr(), s))):
+    t = timeit(lambda: capi.check(fn()))
+    print(json.dumps({"kernel": f"{name} 8x8 PUs", "requests": npu8, "ms": round(t * 1e3, 4), "MPU_per_s": round(npu8 / t / 1e6, 1)}))
+
 # ---- intra chroma mode search: every 8x8 chroma CU (16x16 luma) of a 1080p I picture ----
 cw, chh = W // 2, H // 2
 pu_ = torch.randint(0, 256, (chh, cw), dtype=torch.uint8, device="cuda", generator=g)
