@@ -186,6 +186,17 @@ def main():
     global PAD
     PAD = max(PAD, args.range + 16)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand without a launcher: start the ranks (before anything here touches the GPU) and leave with
+        # their exit status. The driver's torch.distributed.run command line sets WORLD_SIZE and never comes here.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
     from x265_amd import capi
@@ -193,6 +204,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     # XMI_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks share devices)
     backend = os.environ.get("XMI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -271,6 +285,16 @@ def main():
                                 np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
     allrec = segments.gather_records(rec, device=comm_dev)
     assert allrec.shape[0] == args.steps * world
+    # per-rank view of the same records: average kernel time and the device each rank ran on
+    per_rank = []
+    for r in range(world):
+        mine = allrec[(allrec[:, 0] >= r * args.steps) & (allrec[:, 0] < (r + 1) * args.steps)]
+        per_rank.append(round(float(mine[:, 5].mean()) * 1e-3, 4))
+    devs = [None] * world
+    if world > 1:
+        dist.all_gather_object(devs, f"cuda:{local}" + ("" if backend == "nccl" else " (shared, gloo rehearsal)"))
+    else:
+        devs = [f"cuda:{local}"]
     if world > 1:              # all collectives are done: leave the group together, before rank 0's CPU-side legs
         dist.barrier()
         dist.destroy_process_group()
@@ -287,7 +311,7 @@ def main():
             "config": {"workload": f"{args.width}x{args.height} 8-bit luma (coded {w}x{h}, {nctu} CTUs), IPPP P-frame SAD pyramid, "
                                    f"search range {R} ({nmv1}x{nmv1} integer MVs), {args.frames} resident frames per GPU",
                        "cands_per_step": cands, "frames_per_s": round(args.steps * world / elapsed, 2),
-                       "parallelism": f"gop-segments x{world}"},
+                       "parallelism": f"gop-segments x{world}", "rank_devices": devs, "rank_kernel_ms_avg": per_rank},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(w, h, R),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),

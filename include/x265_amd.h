@@ -39,7 +39,11 @@ extern "C" {
 #define XMI_MODE_INVALID 255   /* inc/x265.h:163: "not an intra luma mode" -> DCT, not DST, for 4x4 */
 
 /* ---- library ------------------------------------------------------------------------------ */
-int         xmi_init(int device);      /* bind the calling process to `device`; idempotent */
+/* Bind the calling process to `device` and make it the calling thread's current device; idempotent. With more than one
+ * device visible this call is required before any other entry point (with one device the first call binds device 0).
+ * The library never changes a thread's current device afterwards: a call from a thread whose current device is not the
+ * bound one fails with XMI_ERR_ARG. */
+int         xmi_init(int device);
 void        xmi_shutdown(void);        /* free library-owned device memory */
 const char *xmi_last_error(void);
 int         xmi_device_count(void);
@@ -266,8 +270,8 @@ int xmi_frame_padding(uint8_t *plane, int stride, int width, int height, int pad
  * 8-sample grid, then every horizontal edge, each 4-sample segment filtered when the boundary strength the CTU loop
  * stored for it (ff_hevc_deblocking_boundary_strengths, src/Deblock.cpp:369) is 1 or 2; chroma on the 16-sample luma
  * grid for strength 2. Tables as the reference keeps them: vertical_bs[(x>>3) + (y>>2)*(width>>3)],
- * horizontal_bs[(x + y*(width>>3)) >> 2] (both (width/4)*(height/4) bytes), qp_tab one QP per 4x4 block, width/4 per
- * row. tc_offset / beta_offset are the picture's DBParams (inc/x265.h:329), cb/cr_qp_offset the PPS offsets. */
+ * horizontal_bs[(x + y*(width>>3)) >> 2] (both (width/8)*(height/4) bytes are read, the size xmi_deblock_strengths
+ * writes; the reference allocates more), qp_tab one QP per 4x4 block, width/4 per row, (width/4)*(height/4) bytes. tc_offset / beta_offset are the picture's DBParams (inc/x265.h:329), cb/cr_qp_offset the PPS offsets. */
 typedef struct xmi_deblock_params {
     int32_t width, height;            /* luma picture size, multiples of 8 */
     int32_t stride_y, stride_c;

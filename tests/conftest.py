@@ -17,6 +17,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "missing_prerequisite(reason): set by tests/prereq.py under XMI_REQUIRE_REF=1")
+
+
+def pytest_runtest_setup(item):
+    m = item.get_closest_marker("missing_prerequisite")
+    if m:
+        pytest.fail(f"XMI_REQUIRE_REF=1 and {m.args[0]}", pytrace=False)
 
 
 @pytest.fixture(scope="session")

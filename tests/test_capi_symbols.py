@@ -5,6 +5,8 @@ import subprocess
 
 import pytest
 
+from tests.prereq import needs_ref
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "x265_amd", "lib", "libx265_amd.so")
 DROPIN = os.path.join(ROOT, "x265_amd", "lib", "libx265_amd_dropin.so")
@@ -21,7 +23,6 @@ def declared():
     return set(re.findall(r"\b(xmi_[a-z0-9_]+)\s*\(", text))
 
 
-@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built (run __graft_entry__.build())")
 def test_every_declared_symbol_is_exported():
     decl = declared()
     assert len(decl) >= 20
@@ -29,7 +30,6 @@ def test_every_declared_symbol_is_exported():
     assert not missing, f"declared in include/x265_amd.h but not exported: {sorted(missing)}"
 
 
-@pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")
 def test_library_loads_and_reports_without_gpu():
     import ctypes as C
     lib = C.CDLL(LIB)
@@ -41,7 +41,6 @@ def test_library_loads_and_reports_without_gpu():
     assert lib.xmi_device_count() >= 0
 
 
-@pytest.mark.skipif(not os.path.exists(DROPIN), reason="drop-in library not built")
 def test_dropin_exports_the_reference_primitive_interface():
     # mangled names are the ones an object compiled from the reference's encode.cpp imports
     want = {"xSadN", "xSad_AMP", "xSatdN", "xSsdN", "xSatd_AMP", "_Z7xSubDctPsPhjS0_jS_S_ij", "_Z6xQuantPsS_jjii10xSliceType",
@@ -72,7 +71,7 @@ def test_no_cpu_fallback_when_no_gpu():
 GPU_ALL = os.path.join(ROOT, "oracle", "_ref", "x265_gpu_all")
 
 
-@pytest.mark.skipif(not (os.path.exists(GPU_ALL) and os.path.exists(DROPIN)), reason="all-GPU encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_all", how="make -C oracle trace")
 def test_reference_library_binds_to_the_dropin():
     """In the all-GPU encoder the reference's own shared library must take every pixel primitive and prediction
     function from libx265_amd_dropin.so (symbol interposition by link order): read the dynamic linker's binding log."""

@@ -11,6 +11,8 @@ import sys
 
 import pytest
 
+from tests.prereq import needs_ref
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))
@@ -28,7 +30,7 @@ def parse(key):
     return w, h, int(f[1:]), int(q[1:]), cut
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_oracle")), reason="integration harness not built (make -C oracle enc)")
+@needs_ref("x265_oracle", how="make -C oracle enc")
 @pytest.mark.parametrize("key,variants", CASES, ids=[c[0] for c in CASES])
 def test_recorded_bitstreams_on_cpu(tmp_path, key, variants):
     w, h, frames, qp, cut = parse(key)

@@ -13,6 +13,8 @@ import sys
 
 import pytest
 
+from tests.prereq import needs_ref
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 pytestmark = pytest.mark.gpu
@@ -27,7 +29,7 @@ def encode(variant, yuv, out, w, h, frames, qp, scene_change=0, threads=1):
     return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out)
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu")), reason="integration harness not built (make -C oracle enc)")
+@needs_ref("x265_gpu", how="make -C oracle enc")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_primitives(tmp_path, qp, frames):
     w, h = 416, 240
@@ -41,7 +43,7 @@ def test_bitstream_identical_with_gpu_primitives(tmp_path, qp, frames):
     assert got_g == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-ME encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_me", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (27, 8), (37, 8)])
 def test_bitstream_identical_with_gpu_motion_search(tmp_path, qp, frames):
     """The reference's encoder with every xMotionSearch call served by the GPU library through the frame session
@@ -55,7 +57,7 @@ def test_bitstream_identical_with_gpu_motion_search(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_planes")), reason="GPU-planes encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_planes", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_interpolation_planes(tmp_path, qp, frames):
     """The reference's encoder with xPredInterLumaBlk replaced by copies out of the GPU-built quarter-pel planes
@@ -68,7 +70,7 @@ def test_bitstream_identical_with_gpu_interpolation_planes(tmp_path, qp, frames)
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_deblock")), reason="GPU-deblock encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_deblock", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_deblocking(tmp_path, qp, frames):
     """The reference's encoder with xDeblockFrame replaced by xmi_deblock_frame (oracle/deblock_gpu_hook.cpp; the original
@@ -82,7 +84,7 @@ def test_bitstream_identical_with_gpu_deblocking(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_bs")), reason="GPU boundary-strength encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_bs", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_boundary_strengths(tmp_path, qp, frames):
     """The reference's encoder with ff_hevc_deblocking_boundary_strengths replaced by a recorder of picture-level maps and
@@ -97,7 +99,7 @@ def test_bitstream_identical_with_gpu_boundary_strengths(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_sao")), reason="GPU-SAO encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_sao", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (37, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_sao_statistics(tmp_path, qp, frames):
     """The reference's encoder with calcSaoStatsCu served from one GPU launch per picture (oracle/sao_gpu_hook.cpp; the
@@ -111,7 +113,7 @@ def test_bitstream_identical_with_gpu_sao_statistics(tmp_path, qp, frames):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_intra")), reason="GPU-intra encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_intra", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_intra_search(tmp_path, qp, frames):
     """The reference's encoder with every intra luma mode search answered by the GPU (oracle/intra_gpu_hook.cpp: the 35
@@ -132,7 +134,7 @@ def test_bitstream_identical_with_gpu_intra_search(tmp_path, qp, frames):
     assert m and int(m.group(1)) > 2000, res.stderr[-500:]
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_all")), reason="all-GPU encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_all", how="make -C oracle trace")
 def test_bitstream_identical_with_every_gpu_service(tmp_path):
     """Motion search from the frame session AND every pixel primitive (SAD / SATD / SSD tables, xSubDct, xQuant,
     xDeQuant, xIDctAdd, xPredInterLumaBlk, xPredInterChromaBlk, xEncIntraPred) from libx265_amd_dropin.so, which sits ahead of the reference's library in the link order and
@@ -145,7 +147,7 @@ def test_bitstream_identical_with_every_gpu_service(tmp_path):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-ME encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_me", how="make -C oracle trace")
 def test_gop_segments_on_two_ranks_with_gpu_motion_search():
     """tools/encode_segments.py, two ranks (gloo rendezvous, both on this box's GPU), each encoding its GOP with the GPU
     motion search: every gathered segment is the stream recorded for it (tests/golden/segment_md5.json)."""
@@ -154,7 +156,7 @@ def test_gop_segments_on_two_ranks_with_gpu_motion_search():
     assert res["parity"] == "identical" and res["ranks"] == 2
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_all")), reason="all-GPU encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_all", how="make -C oracle trace")
 @pytest.mark.parametrize("variant", ["gpu", "gpu_all"])
 def test_scene_change_detection_on_gpu_sad(tmp_path, variant):
     """The reference's scene-change detection (sceneChangeDetection, src/preProcess.cpp:104: 32x32 SADs of the source
@@ -169,7 +171,7 @@ def test_scene_change_detection_on_gpu_sad(tmp_path, variant):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_mt")), reason="threaded GPU encoder not built (make -C oracle enc)")
+@needs_ref("x265_gpu_mt", how="make -C oracle enc")
 def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
     """The reference's own OpenMP row threads (src/encode.cpp:5865; the build of x265_refsse_mt) calling the GPU per-call
     primitives concurrently, four rows at a time: the per-call entry points serialise on their staging buffers, and the
@@ -182,7 +184,7 @@ def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
     assert got == (want["md5"], want["bytes"])
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_me")), reason="GPU-service encoders not built (make -C oracle trace)")
+@needs_ref("x265_gpu_me", how="make -C oracle trace")
 @pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao", "gpu_bs")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock"))])
 def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants):
     """The geometry the headline metric is quoted on (1920x1080, coded 1920x1088, 510 CTUs; generator seed 7): the
@@ -198,7 +200,7 @@ def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants)
         assert encode(v, yuv, str(tmp_path / f"{v}.265"), w, h, frames, qp) == (want["md5"], want["bytes"]), f"x265_{v}"
 
 
-@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "x265_gpu_chroma")), reason="GPU chroma-search encoder not built (make -C oracle trace)")
+@needs_ref("x265_gpu_chroma", how="make -C oracle trace")
 @pytest.mark.parametrize("qp,frames", [(32, 8), (22, 3)])
 def test_bitstream_identical_with_gpu_chroma_search(tmp_path, qp, frames):
     """The reference's encoder with every intra chroma mode search answered by the GPU (oracle/chroma_gpu_hook.cpp: the ten

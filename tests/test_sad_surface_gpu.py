@@ -169,20 +169,56 @@ def test_surface_full_size_1080p_properties(L):
     _spot_checks(L, lambda lvl, idx: int(upl[lvl][idx].item()), g, cur, ref, pad, rng, (0, 29, 255, 480, 509))
 
 
-def test_surface_2160p_range128_ctu_band(L):
-    """The 2160p configuration (3840x2176, R = 128, 66 049 MVs per CTU): a band of CTUs of the 24 GB surface."""
+def test_surface_2160p_range128_full_frame(L):
+    """The 2160p configuration at full size (3840x2176, R = 128: 2 040 CTUs x 66 049 MVs x 85 PUs, 24.3 GB of output in one
+    launch), device resident: the pyramid must be consistent over every CTU, and direct SADs at the window corners and a few
+    other MVs must match in the four corner CTUs, on all four picture edges and inside."""
     torch = pytest.importorskip("torch")
     rng, pad, w, h = 128, 144, 3840, 2176
     cur, ref = make_frames(w, h, pad, seed=9, kind="smooth")
-    nctu = (w // 64) * (h // 64)
+    wc, hc = w // 64, h // 64
+    nctu = wc * hc
     g = capi.SadGeom(w, h, w, w + 2 * pad, rng)
     d_cur, d_ref = torch.from_numpy(cur).cuda(), torch.from_numpy(ref).cuda()
     dts = (torch.int16, torch.int16, torch.int32, torch.int32)
-    planes = [torch.empty((layout.plane_elems(nctu, rng, lvl),), dtype=dts[lvl], device="cuda") for lvl in range(4)]
-    lo, hi = 1000, 1048
+    planes = [torch.full((layout.plane_elems(nctu, rng, lvl),), -21846, dtype=dts[lvl], device="cuda") for lvl in range(4)]
     capi.check(L.xmi_sad_surface_dev(C.byref(g), d_cur.data_ptr(), d_ref.data_ptr() + pad * (w + 2 * pad) + pad,
-                                     *[p.data_ptr() for p in planes], lo, hi, None))
+                                     *[p.data_ptr() for p in planes], 0, nctu, None))
     torch.cuda.synchronize()
     upl = [planes[0].view(torch.uint16), planes[1].view(torch.uint16), planes[2], planes[3]]
-    _pyramid_checks(torch, upl, nctu, rng, lo, hi)
-    _spot_checks(L, lambda lvl, idx: int(upl[lvl][idx].item()), g, cur, ref, pad, rng, (lo, lo + 17, hi - 1))
+    _pyramid_checks(torch, upl, nctu, rng, 0, nctu)
+    ctus = (0, wc - 1, nctu - wc, nctu - 1,                      # corners
+            wc // 2, (hc // 2) * wc, (hc // 2) * wc + wc - 1, nctu - wc // 2,   # top, left, right, bottom edge
+            (hc // 2) * wc + wc // 2, 1000)                      # inside
+    _spot_checks(L, lambda lvl, idx: int(upl[lvl][idx].item()), g, cur, ref, pad, rng, ctus)
+
+
+def test_host_form_from_two_threads(L, orc):
+    """xmi_sad_surface stages frames and planes in library-owned buffers: two host threads calling it at once, with
+    different picture sizes (so that one call's buffers would have to grow under the other), both get the oracle's surface."""
+    import threading
+    jobs = [(128, 64, 32, 11), (64, 64, 16, 12), (64, 128, 32, 13), (128, 128, 16, 14)]
+    out, err = {}, []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for j in jobs[k::2]:
+                    w, h, rng, seed = j
+                    pad = ((rng + 4 + 15) // 16) * 16
+                    cur, ref = make_frames(w, h, pad, seed=seed)
+                    out[(j, rep)] = (gpu_surface(L, cur, ref, pad, rng), cur, ref, pad, rng)
+        except Exception as e:      # noqa: BLE001 - reported by the parent
+            err.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not err, err
+    assert len(out) == 12
+    for (j, rep), (got, cur, ref, pad, rng) in out.items():
+        want = O.sad_surface(orc, cur, ref, pad, rng)
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b, err_msg=f"{j} rep {rep}")

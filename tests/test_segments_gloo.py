@@ -8,6 +8,8 @@ import textwrap
 import numpy as np
 import pytest
 
+from tests.prereq import needs_ref
+
 from x265_amd import segments
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -87,7 +89,7 @@ def run_segment_encode(variant, nproc, extra_env=None):
     return json.loads(line)
 
 
-@pytest.mark.skipif(not os.path.exists(REFSSE), reason="integration harness not built (make -C oracle enc)")
+@needs_ref("x265_refsse", how="make -C oracle enc")
 def test_gop_segments_on_two_ranks_join_into_the_per_segment_reference_streams():
     """Two ranks encode one GOP each with a fresh encoder (the reference's control flow, CPU primitives); the gathered
     byte segments are the streams recorded per segment, and the joined stream is the same as one rank produces."""

@@ -296,7 +296,9 @@ int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_para
                 prm->stride_c >= prm->width / 2,
             "xmi_deblock_frame: bad geometry %dx%d, strides %d / %d", prm->width, prm->height, prm->stride_y, prm->stride_c);
     std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
-    const size_t w = (size_t)prm->width, h = (size_t)prm->height, tab = (w / 4) * (h / 4);
+    // strength tables: one entry per 4-sample segment of the 8-sample edge grid (what xmi_deblock_strengths writes and the
+    // kernels index); QP table: one entry per 4x4 block
+    const size_t w = (size_t)prm->width, h = (size_t)prm->height, tab = (w / 4) * (h / 4), nbs = (w / 8) * (h / 4);
     const size_t sy = (w + 3) & ~(size_t)3, sc = w / 2;
     const size_t off_u = sy * h, off_v = off_u + sc * (h / 2), off_vbs = (off_v + sc * (h / 2) + 15) & ~(size_t)15;
     const size_t off_hbs = off_vbs + tab, off_qp = off_hbs + tab, total = off_qp + tab;
@@ -305,8 +307,8 @@ int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_para
     XMI_HIP(hipMemcpy2D(d, sy, y, (size_t)prm->stride_y, w, h, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy2D(d + off_u, sc, u, (size_t)prm->stride_c, w / 2, h / 2, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy2D(d + off_v, sc, v, (size_t)prm->stride_c, w / 2, h / 2, hipMemcpyHostToDevice));
-    XMI_HIP(hipMemcpy(d + off_vbs, vertical_bs, tab, hipMemcpyHostToDevice));
-    XMI_HIP(hipMemcpy(d + off_hbs, horizontal_bs, tab, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_vbs, vertical_bs, nbs, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_hbs, horizontal_bs, nbs, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy(d + off_qp, qp_tab, tab, hipMemcpyHostToDevice));
     xmi_deblock_params dp = *prm;
     dp.stride_y = (int)sy;

@@ -68,6 +68,12 @@ int xmi_frame_create(int width, int height, int pad, xmi_frame **out)
         xmi_frame_destroy(f);
         return XMI_ERR_HIP;
     }
+    // the interpolation kernel leaves the 4 outermost samples of every plane unwritten; xmi_frame_planes_host copies whole planes
+    if (hipMemsetAsync(f->d_planes, 0, 16 * plane, f->stream) != hipSuccess) {
+        xmi::set_error("xmi_frame_create: clearing the phase planes failed");
+        xmi_frame_destroy(f);
+        return XMI_ERR_HIP;
+    }
     *out = f;
     return XMI_OK;
 }

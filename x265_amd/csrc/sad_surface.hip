@@ -321,18 +321,23 @@ size_t lds_bytes(int R, int seg_len)
 template <int R>
 int launch_surface(const SadParams &p, int n, int nseg, size_t lds, hipStream_t st)
 {
-    static bool attr_done = false;  // one flag per R instantiation
-    if (!attr_done) {
-        XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<R>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
     hipLaunchKernelGGL((sad_surface_kernel<R>), dim3(n, nseg), dim3(8 * R), lds, st, p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
 
 }  // namespace
+
+// The 160 KiB LDS opt-in of the four instantiations, for the device that is current: called once per device
+// binding (under the library mutex), never from a launch path, so no launch touches function attributes.
+int xmi::sad_surface_prepare_device()
+{
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return XMI_OK;
+}
 
 extern "C" {
 
@@ -426,6 +431,8 @@ int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *re
     const size_t ref_bytes = (size_t)g->ref_stride * ref_rows;
     const size_t e8 = xmi_sad_surface_elems(g, 0), e16 = xmi_sad_surface_elems(g, 1);
     const size_t e32 = xmi_sad_surface_elems(g, 2), e64 = xmi_sad_surface_elems(g, 3);
+    // scratch slots 0-5 are shared by every caller of this entry point: hold the lock until the last copy has returned
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());
     uint8_t *d_cur = (uint8_t *)xmi::scratch(0, cur_bytes);
     uint8_t *d_ref = (uint8_t *)xmi::scratch(1, ref_bytes);
     uint16_t *d8 = (uint16_t *)xmi::scratch(2, e8 * 2);

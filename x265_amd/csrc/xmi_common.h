@@ -15,9 +15,12 @@ void set_error(const char *fmt, ...);
 int  require_device();          // XMI_OK or XMI_ERR_NO_DEVICE (initialises on first use)
 hipStream_t as_stream(void *s);
 
+// per-device set-up of sad_surface.hip (LDS opt-in of its kernels); called when the library binds a device
+int sad_surface_prepare_device();
+
 // scratch device buffer owned by the library, grown on demand (used by the host-pointer entry points)
 void *scratch(int slot, size_t bytes);
-// serialises the picture-level host-pointer entry points (deblocking, SAO, padding), which share scratch slots
+// serialises the picture-level host-pointer entry points (SAD surface, deblocking, SAO, padding), which share scratch slots
 std::mutex &picture_call_mutex();
 
 #define XMI_HIP(call)                                                                    \

@@ -41,6 +41,8 @@ static int init_locked(int device)
         return XMI_ERR_NO_DEVICE;
     }
     XMI_HIP(hipSetDevice(device));
+    int rc = sad_surface_prepare_device();
+    if (rc != XMI_OK) return rc;
     g_device = device;
     return XMI_OK;
 }
@@ -49,12 +51,27 @@ int require_device()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_device >= 0) {
-        // the binding is per process; make it current for whichever host thread is calling
-        if (hipSetDevice(g_device) != hipSuccess) {
-            set_error("hipSetDevice(%d) failed", g_device);
+        // The binding is per process and the library never switches a caller's device behind its back: a thread whose
+        // current device is another one (a torch caller on a different GPU, a fresh thread in a process bound to a
+        // device other than 0) is told so instead of being moved.
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) {
+            set_error("hipGetDevice failed");
             return XMI_ERR_HIP;
         }
+        if (cur != g_device) {
+            set_error("the calling thread's current device is %d but the library is bound to device %d: make it current "
+                      "(hipSetDevice / torch.cuda.set_device) before calling",
+                      cur, g_device);
+            return XMI_ERR_ARG;
+        }
         return XMI_OK;
+    }
+    // implicit binding only where it cannot pick the wrong GPU
+    int n = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess && n > 1) {
+        set_error("%d devices visible: call xmi_init(device) before any other entry point", n);
+        return XMI_ERR_ARG;
     }
     return init_locked(0);
 }
