@@ -296,6 +296,17 @@ int xmi_deblock_strengths_dev(int width, int height, int intra_slice, const uint
 int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
                           uint8_t *vertical_bs, uint8_t *horizontal_bs);
 
+/* xmi_deblock_strengths for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code around a graph capture): same arguments, same tables, but the maps and tables are staged in an array
+ * that is part of the library's device image (2.25 MiB per GPU the library runs on, held until the process ends) instead
+ * of a buffer the library allocates, so the call performs no hipMalloc / hipFree. It has no counterpart in the reference.
+ * Limit: width * height <= 4096 * 2304 luma samples, larger pictures are refused with XMI_ERR_ARG. Needs xmi_init() (or the
+ * implicit binding of a one-device process) on the device it runs on. All calls on one GPU share that GPU's array: calls
+ * of one process take turns on an internal mutex; the array keeps the last call's contents, and every byte a call reads
+ * is written by that call first. */
+int xmi_deblock_strengths_static(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                                 uint8_t *vertical_bs, uint8_t *horizontal_bs);
+
 /* ---- SAO statistics -----------------------------------------------------------------------------------
  * calcSaoStatsCu (src/encode.cpp:364-622) for every 64x64 CTU and component of a deblocked 4:2:0 picture in one launch:
  * stats[ctu * 3 + component] holds, per SAO type (0..3 = edge classes EO_0..EO_3, 4 = band offset) and category, the

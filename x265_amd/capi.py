@@ -172,6 +172,9 @@ def load():
         L.xmi_deblock_strengths_dev.argtypes = [i, i, i, vp, vp, vp, vp, vp, vp]
         L.xmi_deblock_strengths.restype = i
         L.xmi_deblock_strengths.argtypes = [i, i, i, vp, vp, vp, vp, vp]
+    if hasattr(L, "xmi_deblock_strengths_static"):
+        L.xmi_deblock_strengths_static.restype = i
+        L.xmi_deblock_strengths_static.argtypes = [i, i, i, vp, vp, vp, vp, vp]
     if hasattr(L, "xmi_pred_inter_batch_dev"):
         L.xmi_pred_inter_batch_dev.restype = i
         L.xmi_pred_inter_batch_dev.argtypes = [vp, i, vp, vp, i, vp, i, vp, vp, vp, vp]

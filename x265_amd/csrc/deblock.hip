@@ -222,7 +222,31 @@ __global__ void __launch_bounds__(256) deblock_strengths_kernel(const BsParams p
     (vertical ? p.vbs : p.hbs)[t] = (uint8_t)bs;
 }
 
+// ---- staging without allocation ----
+// xmi_deblock_strengths_static stages its maps and tables in this array instead of a buffer from hipMalloc. Every device
+// the library's code object is loaded on holds its own copy at its own address; g_bs_static[device] is that address,
+// resolved once per device binding. Host code never passes the array's name to a kernel or a copy.
+constexpr size_t kBsStaticMaxSamples = (size_t)4096 * 2304;           // luma samples of the largest picture served
+constexpr size_t kBsStaticBytes = kBsStaticMaxSamples / 4 + 256;      // 2 maps (1/16 each) + vectors (1/16) + 2 tables (1/32 each)
+constexpr int kMaxDevices = 64;
+static uint8_t *g_bs_static[kMaxDevices] = {};
+
 }  // namespace
+
+// No kernel names the array (they get its address as an argument); the host-side use below is what makes the compiler
+// give the device-side symbol external linkage, which the runtime's lookup by name needs - so no 'used' attribute here,
+// which would pin it as a local symbol.
+[[maybe_unused]] static __device__ __align__(256) uint8_t scratch[kBsStaticBytes];
+
+// called when the library binds `device`, with that device current
+int xmi::deblock_prepare_device(int device)
+{
+    XMI_ARG(device >= 0 && device < kMaxDevices, "device index %d beyond %d", device, kMaxDevices - 1);
+    void *ptr = nullptr;
+    XMI_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(::scratch)));   // the array at file scope, not the function xmi::scratch
+    g_bs_static[device] = static_cast<uint8_t *>(ptr);
+    return XMI_OK;
+}
 
 extern "C" {
 
@@ -255,6 +279,39 @@ int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t 
     const size_t off_cbf = n4, off_mv = (2 * n4 + 15) & ~(size_t)15, off_v = off_mv + 4 * n8, off_h = off_v + nbs;
     uint8_t *d = static_cast<uint8_t *>(xmi::scratch(10, off_h + nbs));
     if (!d) return XMI_ERR_HIP;
+    XMI_HIP(hipMemcpy(d, unit_log2, n4, hipMemcpyHostToDevice));
+    XMI_HIP(hipMemcpy(d + off_cbf, cbf, n4, hipMemcpyHostToDevice));
+    if (!intra_slice) XMI_HIP(hipMemcpy(d + off_mv, mv, 4 * n8, hipMemcpyHostToDevice));
+    rc = xmi_deblock_strengths_dev(width, height, intra_slice, d, d + off_cbf, reinterpret_cast<const int16_t *>(d + off_mv), d + off_v, d + off_h, nullptr);
+    if (rc != XMI_OK) return rc;
+    XMI_HIP(hipMemcpy(vertical_bs, d + off_v, nbs, hipMemcpyDeviceToHost));
+    XMI_HIP(hipMemcpy(horizontal_bs, d + off_h, nbs, hipMemcpyDeviceToHost));
+    return XMI_OK;
+}
+
+int xmi_deblock_strengths_static(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                                 uint8_t *vertical_bs, uint8_t *horizontal_bs)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(width >= 16 && height >= 16 && width % 8 == 0 && height % 8 == 0, "xmi_deblock_strengths_static: picture %dx%d must be a multiple of 8, at least 16x16",
+            width, height);
+    XMI_ARG((size_t)width * (size_t)height <= kBsStaticMaxSamples,
+            "xmi_deblock_strengths_static: picture %dx%d exceeds the %zu luma samples (4096x2304) this entry point stages; use xmi_deblock_strengths", width,
+            height, kBsStaticMaxSamples);
+    XMI_ARG(unit_log2 && cbf && vertical_bs && horizontal_bs && (intra_slice || mv), "xmi_deblock_strengths_static: null argument");
+    int dev = -1;
+    XMI_HIP(hipGetDevice(&dev));
+    XMI_ARG(dev >= 0 && dev < kMaxDevices && g_bs_static[dev], "xmi_deblock_strengths_static: device %d was not bound by xmi_init", dev);
+    std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());   // one staging array per device: calls of a process take turns
+    uint8_t *d = g_bs_static[dev];
+    const size_t n4 = (size_t)(width / 4) * (height / 4), n8 = (size_t)(width / 8) * (height / 8), nbs = (size_t)(width / 8) * (height / 4);
+    const size_t off_cbf = n4, off_mv = (2 * n4 + 15) & ~(size_t)15, off_v = off_mv + 4 * n8, off_h = off_v + nbs;
+    if (off_h + nbs > kBsStaticBytes) {
+        xmi::set_error("xmi_deblock_strengths_static: %zu staging bytes exceed the array", off_h + nbs);
+        return XMI_ERR_ARG;
+    }
+    // every byte the kernel reads is copied in first and both tables are written in full: nothing of an earlier call survives
     XMI_HIP(hipMemcpy(d, unit_log2, n4, hipMemcpyHostToDevice));
     XMI_HIP(hipMemcpy(d + off_cbf, cbf, n4, hipMemcpyHostToDevice));
     if (!intra_slice) XMI_HIP(hipMemcpy(d + off_mv, mv, 4 * n8, hipMemcpyHostToDevice));

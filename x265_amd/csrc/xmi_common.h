@@ -17,6 +17,8 @@ hipStream_t as_stream(void *s);
 
 // per-device set-up of sad_surface.hip (LDS opt-in of its kernels); called when the library binds a device
 int sad_surface_prepare_device();
+// per-device set-up of deblock.hip (address of its statically allocated staging array on `device`, which is current)
+int deblock_prepare_device(int device);
 
 // scratch device buffer owned by the library, grown on demand (used by the host-pointer entry points)
 void *scratch(int slot, size_t bytes);

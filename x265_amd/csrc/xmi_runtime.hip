@@ -43,6 +43,8 @@ static int init_locked(int device)
     XMI_HIP(hipSetDevice(device));
     int rc = sad_surface_prepare_device();
     if (rc != XMI_OK) return rc;
+    rc = deblock_prepare_device(device);
+    if (rc != XMI_OK) return rc;
     g_device = device;
     return XMI_OK;
 }
