@@ -21,7 +21,9 @@
 //     reference Y ((width + 2 pad) x (height + 2 pad)), U, V (pad/2)      - garbage for the first picture
 //     unfiltered reconstruction Y, U, V
 //     double sum_cost[rows][cols][5], int32 count[rows][cols][5], double avg_cost[rows][cols][5]   (FAST_MD state, :3556-3568)
-//     uint64 frac_bits[rows]
+//     uint64 frac_bits[rows]            (after the CTU loop)
+//     uint64 frac_bits_start[rows]      (P slices: when the picture's first CTU is about to be decided. The last row's counter
+//                                        also serves the SAO decision of the previous picture, src/encode.cpp:1354, 1477)
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +37,7 @@ bool g_opened = false;
 double g_cost = 0;
 int g_has_cost = 0;
 unsigned char g_ctx_in[256];
+unsigned long long g_frac_start[MAX_HEIGHT_CU];
 
 FILE *out()
 {
@@ -68,6 +71,8 @@ UInt32 xEncDecideCU_Inter(X265_t *h, UInt32 *pCTUCmd, UInt8 *pucPixY, CUInt8 *pu
         abort();
     }
     if (uiDepth == 0) memcpy(g_ctx_in, ppcCabac[0]->contextModels, 256);
+    if (uiDepth == 0 && yCtu == 0 && xCtu == 0)
+        for (int y = 0; y < (int)h->PicHeightInCUs; y++) g_frac_start[y] = h->rdoParam[y].fracBits;
     // the reference declares the return type UInt32 but returns a double (src/encode.cpp:3638): the caller at depth 0
     // ignores it, the recursive calls read the truncated value. Only the truncated value exists.
     const UInt32 r = real(h, pCTUCmd, pucPixY, pucRefY, pucPredY, pucRecY, psCoefY, pasMV, pasMVD, paucMVPIdx, pucModeY, pusModeYInfo0, pucModeYInfo1,
@@ -143,6 +148,7 @@ void xDeblockFrame(X265_t *h, CUInt32 nCUWidth, CUInt32 nCUHeight, Int32 offX, I
             const unsigned long long fb = h->rdoParam[y].fracBits;
             fwrite(&fb, 8, 1, g_f);
         }
+        fwrite(g_frac_start, 8, rows, g_f);
         fflush(g_f);
     }
     real(h, nCUWidth, nCUHeight, offX, offY, bsOff, idxTiles);

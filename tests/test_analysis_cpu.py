@@ -1,0 +1,129 @@
+"""CPU: the host logic of the P-picture analysis loop (x265_amd/csrc/host/analysis_core.cpp - the decision recursion, the CABAC
+rate estimate, the wavefront of CTU rows) with the oracle's primitives as its evaluator (oracle/libx265_analysis_check.so),
+against what the reference's own CTU loop decided in bit-identical encodes: the committed pictures of tests/golden/ctu_trace.npz,
+and, where the reference's trace encoder is built, every P picture of a freshly recorded clip with the cost statistics carried
+from picture to picture by the loop itself."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import ctu_trace as T
+from tests.prereq import needs_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK = os.path.join(ROOT, "oracle", "libx265_analysis_check.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden", "ctu_trace.npz")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return C.CDLL(CHECK)
+
+
+def test_context_initialisation_matches_the_recorded_slices(lib):
+    g = np.load(GOLDEN)
+    lib.orc_analysis_init_contexts.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    for t in g["tags"]:
+        qp = int(g[f"{t}_meta"][3])
+        ctx = np.zeros(256, np.uint8)
+        lib.orc_analysis_init_contexts(1, qp, T.p(ctx))
+        np.testing.assert_array_equal(ctx, g[f"{t}_ctx_in"][0, 0], err_msg=f"{t}: contexts of the first CTU")
+
+
+def test_scan_and_transition_tables(lib):
+    """Diagonal scans against their definition (4x4 groups along anti-diagonals, bottom-left to top-right, and the same
+    order inside a group) and the leading entries of the standard's tables; the transition table against the two
+    properties the estimate relies on."""
+    lib.orc_analysis_scan.restype = C.POINTER(C.c_uint16)
+    s4 = [lib.orc_analysis_scan(2)[i] for i in range(16)]
+    assert s4 == [0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15]
+    s8 = [lib.orc_analysis_scan(3)[i] for i in range(64)]
+    assert s8[:16] == [0, 8, 1, 16, 9, 2, 24, 17, 10, 3, 25, 18, 11, 26, 19, 27] and s8[16:20] == [32, 40, 33, 48] and s8[32:34] == [4, 12]
+    s32 = [lib.orc_analysis_scan(5)[i] for i in range(1024)]
+    assert sorted(s32) == list(range(1024))
+    groups = [(s32[16 * k] // 32 // 4) * 8 + (s32[16 * k] % 32) // 4 for k in range(64)]
+    assert groups[:10] == [0, 8, 1, 16, 9, 2, 24, 17, 10, 3] and groups[-1] == 63
+    lib.orc_analysis_next_state.restype = C.POINTER(C.c_uint8)
+    nx = np.array([lib.orc_analysis_next_state()[i] for i in range(256)]).reshape(128, 2)
+    for s in range(124):
+        assert nx[s, s & 1] == s + 2                       # most probable symbol: one step up
+    assert list(nx[:8, 1]) == [1, 3, 0, 5, 2, 7, 4, 9] and list(nx[:8, 0]) == [2, 0, 4, 1, 6, 3, 8, 5]
+    assert nx[124, 0] == 124 and nx[125, 1] == 125 and nx[124, 1] == 76 and nx[125, 0] == 77
+
+
+def fixture_picture(g, t):
+    w, h, frames, qp, seed, k, cw, ch, pad, rows, cols = (int(v) for v in g[f"{t}_meta"])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        yuv = os.path.join(d, "in.yuv")
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(frames), str(seed), yuv])
+        raw = open(yuv, "rb").read()
+    assert hashlib.md5(raw).hexdigest() == bytes(g[f"{t}_clip_md5"]).decode()
+    frame = np.frombuffer(raw, np.uint8)[k * w * h * 3 // 2:(k + 1) * w * h * 3 // 2]
+    planes = [frame[:w * h].reshape(h, w), frame[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), frame[w * h * 5 // 4:].reshape(h // 2, w // 2)]
+    src = []
+    for i, c in enumerate("yuv"):
+        full = np.zeros((ch, cw) if i == 0 else (ch // 2, cw // 2), np.uint8)
+        hh, ww = planes[i].shape
+        full[:hh, :ww] = planes[i]
+        full[:, ww:] = g[f"{t}_src_right_{c}"]
+        full[hh:, :ww] = g[f"{t}_src_below_{c}"]
+        src.append(full)
+    pic = {"w": cw, "h": ch, "qp": qp, "pad": pad, "rows": rows, "cols": cols, "src": tuple(src), "ref": tuple(g[f"{t}_ref_{c}"] for c in "yuv"),
+           "frac_start": g[f"{t}_in_frac"], "frac": g[f"{t}_out_frac"]}
+    for key in ("sum", "count", "avg"):
+        pic[key] = g[f"{t}_out_{key}"]
+    for key in ("info0", "info1", "mv", "mvd", "mvp_idx", "coef_y", "coef_u", "coef_v", "ctx_in", "ctx_out", "rd_cost"):
+        pic[key] = g[f"{t}_{key}"]
+    before = {key: g[f"{t}_in_{key}"] for key in ("sum", "count", "avg")}
+    rec_md5 = [bytes(g[f"{t}_rec_md5_{c}"]).decode() for c in "yuv"]
+    return pic, before, rec_md5
+
+
+def check_fixture_picture(runner_factory, t):
+    g = np.load(GOLDEN)
+    pic, before, rec_md5 = fixture_picture(g, t)
+    r = runner_factory(pic["w"], pic["h"])
+    try:
+        r.set_state(before, pic)
+        out = r.run(pic)
+        state = r.get_state(pic["rows"], pic["cols"])
+    finally:
+        r.close()
+    pic["rec"] = (out["rec_y"], out["rec_u"], out["rec_v"])          # planes are pinned by their md5 below
+    assert T.compare(pic, out, state) == []
+    for i, c in enumerate("yuv"):
+        assert hashlib.md5(out[f"rec_{c}"].tobytes()).hexdigest() == rec_md5[i], f"{t}: reconstruction {c}"
+    assert out["counters"][1] >= pic["rows"] * pic["cols"]
+    return out
+
+
+@pytest.mark.parametrize("tag", ["416x240_q32_p1", "416x240_q32_p2", "416x240_q32_p7", "416x240_q22_p1"])
+def test_recorded_pictures_are_reproduced(lib, tag):
+    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h), tag)
+
+
+@needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")
+@pytest.mark.parametrize("w,h,frames,qp,seed", [(416, 240, 6, 37, 1234), (416, 240, 4, 27, 1234)])
+def test_fresh_trace_with_carried_statistics(lib, tmp_path, w, h, frames, qp, seed):
+    """All P pictures of a clip in order: the cost statistics stay in the analyser from picture to picture (never reloaded);
+    the rate counters are reloaded, because the last row's also serves the SAO decision in between (src/encode.cpp:1354)."""
+    pics, _ = T.record_trace(str(tmp_path), w, h, frames, qp, seed)
+    r = T.Runner(lib, "orc_analysis_", pics[0]["w"], pics[0]["h"])
+    try:
+        r.set_state(pics[0], pics[1])
+        for k in range(1, len(pics)):
+            pic = pics[k]
+            assert pic["slice"] == 1
+            st = r.get_state(pic["rows"], pic["cols"])
+            st["frac_start"] = pic["frac_start"]
+            r.set_state(st, st)
+            out = r.run(pic)
+            assert T.compare(pic, out, r.get_state(pic["rows"], pic["cols"])) == [], f"picture {k}"
+    finally:
+        r.close()

@@ -1,0 +1,887 @@
+// analysis_core.cpp - see analysis_core.h. Host logic only: no pixel arithmetic, no device code.
+//
+// Structure: one host thread per CTU row runs the decision recursion in plain sequential form and blocks whenever it
+// needs pixels (a CuEval or the ChromaEval list of a finished CTU) or a neighbour (the CTU above and to the right).
+// When every row thread is blocked, the calling thread hands all pending requests to the evaluator in one call, then
+// wakes the rows. The number of evaluator calls per picture is therefore the length of the critical path through the
+// wavefront, not the number of CUs.
+#include "analysis_core.h"
+
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace xmi {
+namespace analysis {
+namespace {
+
+// ---- context layout (inc/x265.h:286-311) ----
+enum {
+    kCtxSplit = 0, kCtxSkip = 3, kCtxMergeFlag = 6, kCtxMergeIdx = 7, kCtxPartSize = 8, kCtxPredMode = 13, kCtxMvd = 22,
+    kCtxQtCbf = 29, kCtxQtRootCbf = 39, kCtxSigCg = 40, kCtxSig = 44, kCtxLastX = 86, kCtxLastY = 116, kCtxOne = 146,
+    kCtxAbs = 170, kCtxMvpIdx = 176,
+    kNumSigCg = 2, kNumSigLuma = 27, kNumLast = 15, kNumOneLuma = 16, kNumAbsLuma = 4
+};
+constexpr int kInvalid = 255, kValid = 0;                 // MODE_INVALID / MODE_VALID (inc/x265.h:163)
+constexpr int kFlagInter = 0x80, kOffCbfC = 8;            // ausModeYInfo0 bits (inc/x265.h:216-217)
+constexpr int kOffSize = 6, kOffCbfY = 5, kOff64 = 4, kMaskSkip = 1, kValidT = 3, kValidL = 1;   // aucModeYInfo1 bits
+constexpr double kDoubleMax = 1.7976931348623158e+308;
+
+// Context initialisation values of P and I slices in context order (src/bitstream.cpp:371-564, rows [1] and [2] of each
+// table; 154 = "not used"). xCabacInit turns them into states for the slice QP.
+const uint8_t kInitP[184] = {
+    107, 139, 126, 197, 185, 201, 110, 122, 154, 139, 154, 154, 154, 149, 154, 152, 139, 95, 79, 63, 31, 31, 140, 198, 153, 153, 154, 154, 154,
+    153, 111, 154, 154, 154, 149, 107, 167, 154, 154, 79, 121, 140, 61, 154,
+    155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 170, 153, 123, 123,
+    107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140,
+    125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+    125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+    154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
+    107, 167, 91, 122, 107, 167, 168, 154, 124, 138, 94, 139, 153, 185
+};
+const uint8_t kInitI[184] = {
+    139, 141, 157, 154, 154, 154, 154, 154, 184, 154, 154, 154, 154, 154, 184, 63, 139, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+    111, 141, 154, 154, 154, 94, 138, 182, 154, 154, 154, 91, 171, 134, 141,
+    111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 140, 139, 182, 182,
+    152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111,
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+    110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154,
+    140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
+    138, 153, 136, 167, 152, 152, 154, 154, 153, 138, 138, 139, 153, 200
+};
+
+// Fractional bit cost (15 fractional bits) of coding a bin in a given state: index = state ^ bin (src/encode.cpp:131-142,
+// the table of the HEVC test model).
+const int32_t kEntropyBits[128] = {
+    0x07b23, 0x085f9, 0x074a0, 0x08cbc, 0x06ee4, 0x09354, 0x067f4, 0x09c1b, 0x060b0, 0x0a62a, 0x05a9c, 0x0af5b, 0x0548d, 0x0b955, 0x04f56, 0x0c2a9,
+    0x04a87, 0x0cbf7, 0x045d6, 0x0d5c3, 0x04144, 0x0e01b, 0x03d88, 0x0e937, 0x039e0, 0x0f2cd, 0x03663, 0x0fc9e, 0x03347, 0x10600, 0x03050, 0x10f95,
+    0x02d4d, 0x11a02, 0x02ad3, 0x12333, 0x0286e, 0x12cad, 0x02604, 0x136df, 0x02425, 0x13f48, 0x021f4, 0x149c4, 0x0203e, 0x1527b, 0x01e4d, 0x15d00,
+    0x01c99, 0x166de, 0x01b18, 0x17017, 0x019a5, 0x17988, 0x01841, 0x18327, 0x016df, 0x18d50, 0x015d9, 0x19547, 0x0147c, 0x1a083, 0x0138e, 0x1a8a3,
+    0x01251, 0x1b418, 0x01166, 0x1bd27, 0x01068, 0x1c77b, 0x00f7f, 0x1d18e, 0x00eda, 0x1d91a, 0x00e19, 0x1e254, 0x00d4f, 0x1ec9a, 0x00c90, 0x1f6e0,
+    0x00c01, 0x1fef8, 0x00b5f, 0x208b1, 0x00ab6, 0x21362, 0x00a15, 0x21e46, 0x00988, 0x2285d, 0x00934, 0x22ea8, 0x008a8, 0x239b2, 0x0081d, 0x24577,
+    0x007c9, 0x24ce6, 0x00763, 0x25663, 0x00710, 0x25e8f, 0x006a0, 0x26a26, 0x00672, 0x26f23, 0x005e8, 0x27ef8, 0x005ba, 0x284b5, 0x0055e, 0x29057,
+    0x0050c, 0x29bab, 0x004c1, 0x2a674, 0x004a7, 0x2aa5e, 0x0046f, 0x2b32f, 0x0041f, 0x2c0ad, 0x003e7, 0x2ca8d, 0x003ba, 0x2d323, 0x0010c, 0x3bfbb
+};
+
+// CABAC state transitions (state = 2 * probability index + MPS): the standard's transIdxLps table; the MPS step is +1
+// up to probability index 62.
+const uint8_t kLpsNext[64] = { 0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,  11, 11, 12, 13, 13, 15, 15, 16, 16,
+                               18, 18, 19, 19, 21, 21, 22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30,
+                               31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+
+struct Tables {
+    uint8_t next[128][2];
+    uint16_t scan[4][1024];     // log2 size 2..5
+    Tables()
+    {
+        for (int s = 0; s < 128; s++) {
+            const int p = s >> 1, mps = s & 1;
+            const int up = p < 62 ? p + 1 : p;
+            next[s][mps] = (uint8_t)(2 * up + mps);
+            next[s][mps ^ 1] = p == 0 ? (uint8_t)(mps ^ 1) : (uint8_t)(2 * kLpsNext[p] + mps);
+        }
+        next[126][0] = next[126][1] = 126, next[127][0] = next[127][1] = 127;   // the terminating state does not move
+        // up-right diagonal order of a 4x4 block (and of the 4x4 groups of a larger block): along every anti-diagonal from
+        // bottom-left to top-right
+        uint8_t d4[16], d8[64], d2[4];
+        auto diag = [](int n, uint8_t *o) {
+            int k = 0;
+            for (int d = 0; d < 2 * n - 1; d++)
+                for (int y = d < n ? d : n - 1; y >= 0 && d - y < n; y--) o[k++] = (uint8_t)(y * n + (d - y));
+        };
+        diag(2, d2), diag(4, d4), diag(8, d8);
+        for (int l = 2; l <= 5; l++) {
+            const int n = 1 << l, g = n / 4;
+            const uint8_t *go = g == 1 ? nullptr : g == 2 ? d2 : g == 4 ? d4 : d8;
+            int k = 0;
+            for (int gi = 0; gi < g * g; gi++) {
+                const int gp = go ? go[gi] : 0, gy = gp / g, gx = gp % g;
+                for (int i = 0; i < 16; i++) scan[l - 2][k++] = (uint16_t)((gy * 4 + d4[i] / 4) * n + gx * 4 + d4[i] % 4);
+            }
+        }
+    }
+};
+const Tables &tables()
+{
+    static const Tables t;
+    return t;
+}
+
+struct Ctx {
+    uint8_t m[256];
+};
+
+// Rate counter of one CTU row (xRdoParam, inc/x265.h:354): the fraction of a bit left over from the previous estimate is
+// kept (frac &= 32767 at the start of every estimate, src/encode.cpp:189), and the working contexts are cabacRdo[y][0] -
+// the same memory as the depth-0 contexts (rdoParam[y].pCabacRdo = cabacRdo[y], src/encode.cpp:5263).
+struct Rate {
+    uint64_t frac = 0;
+    bool transitions = false;   // only row 0 has a next-state table (xBuildNextStateTable(h->rdoParam), src/encode.cpp:5052); the
+                                // other rows' tables are zero-filled, so every context they touch falls to state 0
+    Ctx *w = nullptr;
+    void bin(unsigned b, int c)
+    {
+        const uint8_t s = w->m[c];
+        frac += (uint64_t)kEntropyBits[s ^ b];
+        w->m[c] = transitions ? tables().next[s][b] : 0;
+    }
+    void ep(unsigned n) { frac += 32768ull * n; }
+    void begin() { frac &= 32767; }
+    uint32_t bits() const { return (uint32_t)(frac >> 15); }
+};
+
+inline int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) l++;
+    return l;
+}
+
+// ---- residual syntax of one transform block, rate only (xEncodeCoeffNxN, src/encode.cpp:2385-2553, diagonal scan) ----
+const uint8_t kGroupIdx[32] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9 };
+
+void rate_last_xy(Rate &r, int x, int y, int log2, bool luma)
+{
+    const int size = 1 << log2;
+    const int cx = kCtxLastX + (luma ? 0 : kNumLast), cy = kCtxLastY + (luma ? 0 : kNumLast);
+    const int gx = kGroupIdx[x], gy = kGroupIdx[y], gmax = kGroupIdx[size - 1];
+    const int off = luma ? (log2 - 2) * 3 + ((log2 - 1) >> 2) : 0, sh = luma ? (log2 + 1) >> 2 : log2 - 2;
+    for (int c = 0; c < gx; c++) r.bin(1, cx + off + (c >> sh));
+    if (gx < gmax) r.bin(0, cx + off + (gx >> sh));
+    for (int c = 0; c < gy; c++) r.bin(1, cy + off + (c >> sh));
+    if (gy < gmax) r.bin(0, cy + off + (gy >> sh));
+    if (gx > 3) r.ep((gx - 2) >> 1);
+    if (gy > 3) r.ep((gy - 2) >> 1);
+}
+
+int sig_ctx(int pattern, int x, int y, int log2, bool luma)
+{
+    static const uint8_t map4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+    if (x + y == 0) return 0;
+    if (log2 == 2) return map4[4 * y + x];
+    const int off = log2 == 3 ? 9 : (luma ? 21 : 12);       // diagonal scan
+    const int xs = x & 3, ys = y & 3;
+    int cnt;
+    if (pattern == 0) cnt = xs + ys <= 2 ? (xs + ys == 0 ? 2 : 1) : 0;
+    else if (pattern == 1) cnt = ys <= 1 ? (ys == 0 ? 2 : 1) : 0;
+    else if (pattern == 2) cnt = xs <= 1 ? (xs == 0 ? 2 : 1) : 0;
+    else cnt = 2;
+    return ((luma && ((x >> 2) + (y >> 2)) > 0) ? 3 : 0) + off + cnt;
+}
+
+void rate_remaining(Rate &r, unsigned v, unsigned rice)
+{
+    if (v < (3u << rice)) {
+        r.ep((v >> rice) + 1);
+        if (rice) r.ep(rice);
+    } else {
+        unsigned len = rice, code = v - (3u << rice);
+        while (code >= (1u << len)) {
+            code -= 1u << len;
+            len++;
+        }
+        r.ep(3 + len + 1 - rice);
+        if (len) r.ep(len);
+    }
+}
+
+void rate_coefficients(Rate &r, const int16_t *coef, int stride, int size, bool luma)
+{
+    const int log2 = ilog2(size), side = size >> 2;
+    const uint16_t *scan = tables().scan[log2 - 2];
+    uint8_t cg_flag[64] = {};
+    unsigned remaining = 0;
+    for (int y = 0; y < size; y++)
+        for (int x = 0; x < size; x++) remaining += coef[y * stride + x] != 0;
+    int last = -1, lx = 0, ly = 0;
+    do {
+        const int p = scan[++last];
+        ly = p >> log2, lx = p - (ly << log2);
+        if (coef[ly * stride + lx]) {
+            cg_flag[side * (ly >> 2) + (lx >> 2)] = 1;
+            remaining--;
+        }
+    } while (remaining > 0);
+    rate_last_xy(r, lx, ly, log2, luma);
+
+    const int base_cg = kCtxSigCg + (luma ? 0 : kNumSigCg), base_sig = kCtxSig + (luma ? 0 : kNumSigLuma);
+    const int last_set = last >> 4;
+    unsigned c1 = 1;
+    int pos = last;
+    for (int set = last_set; set >= 0; set--) {
+        const int first = set << 4;
+        int16_t mag[16];
+        int n = 0;
+        unsigned rice = 0;
+        if (pos == last) {
+            mag[0] = (int16_t)std::abs((int)coef[ly * stride + lx]);
+            n = 1;
+            pos--;
+        }
+        // the group this subset covers: the position of its first coefficient names it
+        const int p0 = scan[first], gy = (p0 >> log2) >> 2, gx = (p0 & (size - 1)) >> 2, g = gy * side + gx;
+        const bool right = gx < side - 1 && cg_flag[g + 1], below = gy < side - 1 && cg_flag[g + side];
+        if (set == last_set || set == 0) cg_flag[g] = 1;
+        else r.bin(cg_flag[g] != 0, base_cg + (right || below));
+        if (cg_flag[g]) {
+            const int pattern = size == 4 ? -1 : (int)right + 2 * (int)below;
+            for (; pos >= first; pos--) {
+                const int p = scan[pos], y = p >> log2, x = p - (y << log2);
+                const int v = coef[y * stride + x];
+                if (pos != first || set == 0 || n) r.bin(v != 0, base_sig + sig_ctx(pattern, x, y, log2, luma));
+                if (v) mag[n++] = (int16_t)std::abs(v);
+            }
+        } else {
+            pos = first - 1;
+        }
+        if (n > 0) {
+            unsigned ctx_set = (set > 0 && luma) ? 2 : 0;
+            if (c1 == 0) ctx_set++;
+            c1 = 1;
+            int base = kCtxOne + 4 * ctx_set + (luma ? 0 : kNumOneLuma);
+            const int n1 = n < 8 ? n : 8;
+            int first_g1 = 16;
+            for (int i = 0; i < n1; i++) {
+                const unsigned g1 = mag[i] > 1;
+                r.bin(g1, base + c1);
+                if (g1) {
+                    c1 = 0;
+                    if (first_g1 > i) first_g1 = i;
+                } else if (c1 != 0) {
+                    c1 = c1 + 1 < 3 ? c1 + 1 : 3;
+                }
+            }
+            if (c1 == 0) {
+                base = kCtxAbs + ctx_set + (luma ? 0 : kNumAbsLuma);
+                if (first_g1 != 16) r.bin(mag[first_g1] > 2, base);
+            }
+            r.ep(n);   // signs
+            int first2 = 1;
+            if (c1 == 0 || n > 8) {
+                for (int i = 0; i < n; i++) {
+                    const int base_level = i < 8 ? 2 + first2 : 1;
+                    if (mag[i] >= base_level) {
+                        rate_remaining(r, mag[i] - base_level, rice);
+                        if (mag[i] > 3 * (1 << rice)) rice = rice + 1 < 4 ? rice + 1 : 4;
+                    }
+                    if (mag[i] >= 2) first2 = 0;
+                }
+            }
+        }
+    }
+}
+
+// Bits of the luma part of one CU as xPreEncRec counts them (src/encode.cpp:3038-3077): prediction mode, part size, the
+// coded-block flag of each transform unit and its coefficients, and the root flag of a 64x64 CU.
+uint32_t rate_cu_luma(Rate &r, const int16_t *level, int size, const uint32_t sum[4], int *cbf)
+{
+    r.begin();
+    r.bin(0, kCtxPredMode);
+    r.bin(1, kCtxPartSize);
+    if (size == 64) {
+        *cbf = 0;
+        uint32_t total = 0;
+        for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 2; i++) {
+                const uint32_t s = sum[j * 2 + i];
+                *cbf |= (s ? 1 : 0) << (j * 2 + i);
+                total += s;
+                r.bin(s != 0, kCtxQtCbf);
+                if (s) rate_coefficients(r, level + j * 32 * 64 + i * 32, 64, 32, true);
+            }
+        r.bin(total != 0, kCtxQtRootCbf);
+    } else {
+        *cbf = sum[0] ? 1 : 0;
+        r.bin(sum[0] != 0, kCtxQtCbf);
+        if (sum[0]) rate_coefficients(r, level, size, size, true);
+    }
+    return r.bits();
+}
+
+// motion vector difference and predictor index (xWriteMVD, xWriteUnaryMaxSymbol with one candidate beyond the first;
+// src/encode.cpp:4482-4523, 2357-2382)
+void rate_mvd(Rate &r, int dx, int dy, int mvp_idx)
+{
+    const unsigned ax = (unsigned)std::abs(dx), ay = (unsigned)std::abs(dy);
+    r.bin(ax != 0, kCtxMvd);
+    r.bin(ay != 0, kCtxMvd);
+    if (ax) r.bin(ax > 1, kCtxMvd + 1);
+    if (ay) r.bin(ay > 1, kCtxMvd + 1);
+    auto golomb1 = [&](unsigned v) {   // first-order Exp-Golomb, one bypass command
+        unsigned k = 1, bins = 0;
+        while (v >= (1u << k)) v -= 1u << k, k++, bins++;
+        r.ep(bins + 1 + k);
+    };
+    if (ax) {
+        if (ax > 1) golomb1(ax - 2);
+        r.ep(1);
+    }
+    if (ay) {
+        if (ay > 1) golomb1(ay - 2);
+        r.ep(1);
+    }
+    r.bin(mvp_idx ? 1 : 0, kCtxMvpIdx);
+}
+
+struct Shared;
+
+// ---- one CTU row ----
+struct Row {
+    Shared *sh = nullptr;
+    int y = 0;
+    // CTU-local caches with the reference's borders: validity (MAX_PU_XY + 2)^2 with a border on every side, info1
+    // (MAX_PU_XY + 1)^2 with a top / left border, vectors (MAX_MV_XY + 2)^2 (inc/x265.h:209-261)
+    uint8_t mode[18 * 18];
+    uint16_t info0[16 * 16];
+    uint8_t info1[17 * 17];
+    Mv mv[10 * 10], mvd[8 * 8];
+    uint8_t mvp_idx[8 * 8];
+    uint8_t rec_y[64 * 64], rec_u[32 * 32], rec_v[32 * 32];
+    int16_t coef_y[64 * 64], coef_u[32 * 32], coef_v[32 * 32];
+    // best candidate of the CU being decided, per CU size 8/16/32/64 (paucRecYTmp, pasCoefYTmp, paiCbfYTmp)
+    uint8_t best_rec[4][64 * 64];
+    int16_t best_coef[4][64 * 64];
+    int best_cbf[4];
+    Ctx cab[5];                 // cabacRdo[y][0..4]; [0] doubles as the working set
+    Rate rate;
+    Mv min_ipel, max_ipel;
+    double lambda = 0;
+    int qp = 0, ctu_x = 0;
+    CuEval cu_req;
+    std::vector<ChromaEval> chroma_req;
+    bool pending = false;
+    int need = -1;
+
+    uint8_t &M(int r, int c) { return mode[(r + 1) * 18 + c + 1]; }
+    uint8_t &I1(int r, int c) { return info1[(r + 1) * 17 + c + 1]; }
+    uint16_t &I0(int r, int c) { return info0[r * 16 + c]; }
+    Mv &V(int r, int c) { return mv[(r + 1) * 10 + c + 1]; }
+
+    int fill_candidates(Mv out[7], int r4, int c4, int r8, int c8, int size);
+    uint32_t decide(int px, int py, int size, int depth);
+    void chroma_pass();
+    void collect_cus(int px, int py, int size, std::vector<int> &list);
+    void run();
+    void evaluate_cu();
+    void evaluate_chroma();
+};
+
+struct Shared {
+    std::mutex m;
+    std::condition_variable cv_rows, cv_main;
+    int running = 0, finished = 0, error = 0;
+    std::vector<CuEval *> cu;
+    std::vector<ChromaEval *> chroma;
+    std::vector<int> done;          // CTUs finished per row
+    std::vector<Row> rows;
+    std::vector<Ctx> saved;         // contexts after CTU 1 of a row: where the row below starts (cabacRdoSaved, src/encode.cpp:5481)
+    Ctx start;                      // contexts of the slice start
+    Analyser *an = nullptr;
+    PictureResult *out = nullptr;
+    int w = 0, h = 0, cols = 0, nrows = 0, qp = 0;
+};
+
+struct Abort {};
+
+// xFillMvpCand (src/encode.cpp:2703-2809) for a square 2Nx2N PU: out[0..1] the two AMVP predictors, out[2..] the merge
+// candidates; returns their number.
+int Row::fill_candidates(Mv out[7], int r4, int c4, int r8, int c8, int size)
+{
+    const int b4 = size / 4, b8 = size / 8;
+    const bool bl = M(r4 + b4, c4 - 1) != kInvalid, l = M(r4 + b4 - 1, c4 - 1) != kInvalid;
+    const bool tr = M(r4 - 1, c4 + b4) != kInvalid, t = M(r4 - 1, c4 + b4 - 1) != kInvalid, tl = M(r4 - 1, c4 - 1) != kInvalid;
+    const Mv vbl = V(r8 + b8, c8 - 1), vl = V(r8 + b8 - 1, c8 - 1), vtr = V(r8 - 1, c8 + b8), vt = V(r8 - 1, c8 + b8 - 1), vtl = V(r8 - 1, c8 - 1);
+    auto same = [](Mv a, Mv b) { return a.x == b.x && a.y == b.y; };
+    const Mv zero = { 0, 0 };
+    int n = 0;
+    out[0] = zero;
+    if (bl || l) out[n++] = bl ? vbl : vl;
+    if (tr || t || tl) out[n++] = tr ? vtr : t ? vt : vtl;
+    if ((bl || l) && (tr || t || tl) && same(out[0], out[1])) out[1] = zero;
+    if (n < 2) out[1] = zero;
+    n = 0;
+    Mv *mg = out + 2;
+    if (l) mg[n++] = vl;
+    if (t && (!l || !same(vl, vt))) mg[n++] = vt;
+    if (tr && (!t || !same(vt, vtr))) mg[n++] = vtr;
+    if (bl && (!l || !same(vl, vbl))) mg[n++] = vbl;
+    if (n < 4) {
+        if (tl && (!l || !same(vl, vtl)) && (!t || !same(vt, vtl))) {
+            mg[n++] = vtl;
+        } else {
+            bool has_zero = false;
+            for (int i = 0; i < n; i++) has_zero |= same(mg[i], zero);
+            if (!has_zero) mg[n++] = zero;
+        }
+    }
+    return n;
+}
+
+void block_in(void *dst, int dst_pitch, const void *src, int src_pitch, int rows, int bytes)
+{
+    for (int i = 0; i < rows; i++) std::memcpy((char *)dst + (size_t)i * dst_pitch, (const char *)src + (size_t)i * src_pitch, bytes);
+}
+
+// xEncDecideCU_Inter (src/encode.cpp:3080-3639), FAST_MD build: returns the RD cost as the reference's callers see it,
+// truncated to 32 bits by the function's declared return type.
+uint32_t Row::decide(int px, int py, int size, int depth)
+{
+    const int log2 = ilog2(size), b4 = size / 4, b8 = size / 8, r4 = py / 4, c4 = px / 4, r8 = py / 8, c8 = px / 8, li = log2 - 3;
+    const Ctx entry = cab[depth];
+    Ctx &work = cab[0];
+    Mv cand[7];
+    const int nmerge = fill_candidates(cand, r4, c4, r8, c8, size);
+    const Mv *mg = cand + 2;
+    const int qmin_x = 4 * (min_ipel.x - 4), qmin_y = 4 * (min_ipel.y - 4), qmax_x = 4 * (max_ipel.x - 4), qmax_y = 4 * (max_ipel.y - 4);
+    const bool skip_left = (I1(r4, c4 - 1) & kMaskSkip) && M(r4 + b4 - 1, c4 - 1) != kInvalid;
+    const bool skip_above = (I1(r4 - 1, c4) & kMaskSkip) && M(r4 - 1, c4 + b4 - 1) != kInvalid;
+    const int ctx_skip = kCtxSkip + (skip_left ? 1 : 0) + (skip_above ? 1 : 0);
+
+    CuEval &q = cu_req;
+    q.x0 = ctu_x * 64 + px, q.y0 = y * 64 + py, q.size = size;
+    q.n_merge = nmerge;
+    for (int k = 0; k < nmerge; k++) {
+        q.merge_mv[k] = mg[k];
+        q.merge_ok[k] = mg[k].x >= qmin_x && mg[k].x <= qmax_x && mg[k].y >= qmin_y && mg[k].y <= qmax_y;
+    }
+    q.amvp[0] = cand[0], q.amvp[1] = cand[1];
+    q.mv_min_ipel = min_ipel, q.mv_max_ipel = max_ipel;
+    q.lambda = lambda, q.qp = qp;
+    evaluate_cu();
+
+    double best = kDoubleMax;
+    int merge_idx = 0, skip = 0;
+    Mv bmv = { 0, 0 };
+    bool go_me = true;
+    if (q.best_merge >= 0) {
+        const int k = q.best_merge;
+        work = entry;
+        int cbf = 0;
+        const uint32_t coeff_bits = rate_cu_luma(rate, q.level_merge, size, q.sum_merge, &cbf);
+        rate.begin();
+        rate.bin(1, kCtxMergeFlag);
+        rate.bin(k != 0, kCtxMergeIdx);
+        if (k) rate.ep(k);
+        const uint32_t merge_bits = rate.bits();
+        double cost = q.ssd_merge + lambda * (coeff_bits + merge_bits);
+        const double cost_skip = q.ssd_skip + lambda * merge_bits;
+        int is_skip = 0;
+        if (cost_skip < cost) {
+            is_skip = 1;
+            cost = cost_skip;
+            work = entry;
+        }
+        if (cost < best) {
+            best = cost;
+            merge_idx = k + 1;
+            skip = is_skip;
+            cab[depth] = work;
+            bmv = mg[k];
+            if (skip) {
+                std::memcpy(best_rec[li], q.pred_merge, (size_t)size * size);
+                std::memset(best_coef[li], 0, (size_t)size * size * 2);
+                best_cbf[li] = 0;
+            } else {
+                std::memcpy(best_rec[li], q.rec_merge, (size_t)size * size);
+                std::memcpy(best_coef[li], q.level_merge, (size_t)size * size * 2);
+                best_cbf[li] = cbf;
+            }
+        }
+        if (skip || cbf == 0) go_me = false;      // FAST_MD: a skipped or residual-free merge ends the CU's own search (:3370-3374)
+    }
+    if (go_me) {
+        const Mv m = q.mv_me;
+        work = entry;
+        int cbf = 0;
+        const uint32_t coeff_bits = rate_cu_luma(rate, q.level_me, size, q.sum_me, &cbf);
+        int idx = 0;
+        while (idx < nmerge && !(m.x == mg[idx].x && m.y == mg[idx].y)) idx++;
+        const int merge_found = idx != nmerge ? idx + 1 : 0;
+        uint32_t mvd_bits = 0, merge_bits = 0;
+        if (merge_found) {
+            merge_bits = idx == 4 ? idx : idx + 1;
+        } else {
+            int pi = 0;
+            if (std::abs(cand[0].x - cand[1].x) + std::abs(cand[0].y - cand[1].y) > 0) {
+                const unsigned d0 = std::abs(cand[0].x - m.x) + std::abs(cand[0].y - m.y);
+                const unsigned d1 = std::abs(cand[1].x - m.x) + std::abs(cand[1].y - m.y) + 1;
+                pi = d0 <= d1 ? 0 : 1;
+            }
+            rate.begin();
+            rate_mvd(rate, (int16_t)(cand[pi].x - m.x), (int16_t)(cand[pi].y - m.y), pi);
+            mvd_bits = rate.bits();
+        }
+        const double cost = q.ssd_me + lambda * (mvd_bits + merge_bits + coeff_bits);
+        if (cost < best) {
+            best = cost;
+            merge_idx = merge_found;
+            skip = 0;
+            bmv = m;
+            rate.bin(0, ctx_skip);                 // the skip flag joins the estimate here without a fresh start of the counter (:3452)
+            cab[depth] = work;
+            std::memcpy(best_rec[li], q.rec_me, (size_t)size * size);
+            std::memcpy(best_coef[li], q.level_me, (size_t)size * size * 2);
+            best_cbf[li] = cbf;
+        }
+    }
+
+    bool replace = size == 8 || skip;
+    if (size > 8 && !skip) {
+        Analyser &an = *sh->an;
+        const int cols = sh->cols;
+        auto at = [&](int ry, int rx, int d) { return ((size_t)ry * cols + rx) * 5 + d; };
+        bool descend = true;
+        if (depth != 0) {
+            // cost statistics of this CTU and of its left / upper neighbours at this depth: a CU already cheaper than their
+            // weighted average is not split (:3476-3508)
+            const double own_cost = an.avg_cost[at(y, ctu_x, depth)], own_n = an.count[at(y, ctu_x, depth)];
+            double nb_cost = 0;
+            int nb_n = 0;
+            auto add = [&](int ry, int rx) { nb_cost += an.avg_cost[at(ry, rx, depth)], nb_n += an.count[at(ry, rx, depth)]; };
+            if (y > 0) add(y - 1, ctu_x);
+            if (y > 0 && ctu_x > 0) add(y - 1, ctu_x - 1);
+            if (y > 0 && ctu_x < cols - 1) add(y - 1, ctu_x + 1);
+            if (ctu_x > 0) add(y, ctu_x - 1);
+            double avg = -1.0;
+            if (own_n + nb_n) avg = (0.6 * own_cost + 0.4 * nb_cost) / (0.6 * own_n + 0.4 * nb_n);
+            if (best < avg && avg > 0) {
+                replace = true;
+                descend = false;
+            }
+        }
+        if (descend) {
+            double sub = 0;
+            const int half = size / 2;
+            for (int part = 0; part < 4; part++) {
+                const uint32_t c = decide(px + (part & 1) * half, py + (part >> 1) * half, half, depth + 1);
+                sub += (double)c;
+                const size_t i = at(y, ctu_x, depth + 1);
+                an.sum_cost[i] += (double)c;
+                an.count[i] += 1;
+                an.avg_cost[i] = an.sum_cost[i] / an.count[i];
+            }
+            if (depth == 0) {
+                const size_t i = at(y, ctu_x, 0);
+                an.sum_cost[i] += best;
+                an.count[i] += 1;
+                an.avg_cost[i] = an.sum_cost[i] / an.count[i];
+            }
+            if (sub >= best) {
+                replace = true;
+                for (int d = depth + 1; d < 5; d++) cab[d] = cab[depth];
+            } else {
+                best = sub;
+                cab[depth] = cab[depth + 1];
+            }
+        }
+    }
+
+    if (replace) {
+        block_in(rec_y + py * 64 + px, 64, best_rec[li], size, size, size);
+        block_in(coef_y + py * 64 + px, 128, best_coef[li], size * 2, size, size * 2);
+        int pi = 0;
+        if (std::abs(cand[0].x - cand[1].x) + std::abs(cand[0].y - cand[1].y) > 0) {
+            const unsigned d0 = std::abs(cand[0].x - bmv.x) + std::abs(cand[0].y - bmv.y);
+            const unsigned d1 = std::abs(cand[1].x - bmv.x) + std::abs(cand[1].y - bmv.y) + 1;
+            pi = d0 <= d1 ? 0 : 1;
+        }
+        for (int i = 0; i < b8; i++)
+            for (int j = 0; j < b8; j++) {
+                V(r8 + i, c8 + j) = bmv;
+                mvp_idx[(r8 + i) * 8 + c8 + j] = (uint8_t)pi;
+                mvd[(r8 + i) * 8 + c8 + j] = { (int16_t)(bmv.x - cand[pi].x), (int16_t)(bmv.y - cand[pi].y) };
+            }
+        const int above = y * 64 + py > 0, left = ctu_x * 64 + px > 0;
+        for (int i = 0; i < b4; i++)
+            for (int j = 0; j < b4; j++) {
+                M(r4 + i, c4 + j) = kValid;
+                I0(r4 + i, c4 + j) = (uint16_t)(kFlagInter | merge_idx);
+                const int cbf = size == 64 ? (best_cbf[li] >> ((i >> 3) * 2 + (j >> 3))) & 1 : best_cbf[li] & 1;
+                I1(r4 + i, c4 + j) = (uint8_t)(((log2 - 2) << kOffSize) | ((size == 64) << kOff64) | (above << kValidT) | (left << kValidL) |
+                                               (cbf << kOffCbfY) | skip);
+            }
+    }
+    return (uint32_t)best;
+}
+
+// the decided CUs of the CTU in coding order: a CU is recognised by the size its first 4x4 entry records
+void Row::collect_cus(int px, int py, int size, std::vector<int> &list)
+{
+    const uint8_t f = I1(py / 4, px / 4);
+    const int is64 = (f >> kOff64) & 1 & (I0(0, 0) >> 7);
+    const int cu = is64 ? 64 : 4 << (f >> kOffSize);
+    if (cu >= size) {
+        list.push_back(px | (py << 8) | (size << 16));
+        return;
+    }
+    const int half = size / 2;
+    for (int part = 0; part < 4; part++) collect_cus(px + (part & 1) * half, py + (part >> 1) * half, half, list);
+}
+
+// xEncInterCTU (src/encode.cpp:3641-3791)
+void Row::chroma_pass()
+{
+    static const uint8_t chroma_qp[58] = { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                                           29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+    std::vector<int> list;
+    collect_cus(0, 0, 64, list);
+    chroma_req.resize(list.size());
+    for (size_t i = 0; i < list.size(); i++) {
+        const int px = list[i] & 255, py = (list[i] >> 8) & 255, size = list[i] >> 16;
+        ChromaEval &c = chroma_req[i];
+        c.x0 = ctu_x * 64 + px, c.y0 = y * 64 + py, c.size = size;
+        c.mv = V(py / 8, px / 8);
+        c.skip = I1(py / 4, px / 4) & 1 & (I0(0, 0) >> 7);
+        c.qpc = chroma_qp[qp];
+    }
+    evaluate_chroma();
+    for (size_t n = 0; n < list.size(); n++) {
+        const int px = list[n] & 255, py = (list[n] >> 8) & 255, size = list[n] >> 16, r4 = py / 4, c4 = px / 4, b4 = size / 4, sc = size / 2;
+        const ChromaEval &c = chroma_req[n];
+        block_in(rec_u + (py / 2) * 32 + px / 2, 32, c.rec_u, sc, sc, sc);
+        block_in(rec_v + (py / 2) * 32 + px / 2, 32, c.rec_v, sc, sc, sc);
+        if (c.skip) {
+            for (int i = 0; i < sc; i++) {
+                std::memset(coef_u + (py / 2 + i) * 32 + px / 2, 0, (size_t)sc * 2);
+                std::memset(coef_v + (py / 2 + i) * 32 + px / 2, 0, (size_t)sc * 2);
+            }
+            continue;
+        }
+        block_in(coef_u + (py / 2) * 32 + px / 2, 64, c.level_u, sc * 2, sc, sc * 2);
+        block_in(coef_v + (py / 2) * 32 + px / 2, 64, c.level_v, sc * 2, sc, sc * 2);
+        const int merge_idx = I0(r4, c4) & 0x3f;
+        if (size == 64) {
+            int any = 0;
+            for (int j = 0; j < 2; j++)
+                for (int i = 0; i < 2; i++) {
+                    const int cbf_c = (c.sum_v[j * 2 + i] ? 2 : 0) | (c.sum_u[j * 2 + i] ? 1 : 0);
+                    const int cbf_y = (I1(r4 + j * 8, c4 + i * 8) >> kOffCbfY) & 1;
+                    any |= cbf_y | cbf_c;
+                    const uint16_t first = I0(r4 + j * 8, c4 + i * 8);
+                    for (int ii = 0; ii < 8; ii++)
+                        for (int jj = 0; jj < 8; jj++) I0(r4 + j * 8 + ii, c4 + i * 8 + jj) = (uint16_t)(first | (cbf_c << kOffCbfC));
+                }
+            if (merge_idx && any == 0)
+                for (int ii = 0; ii < 16; ii++)
+                    for (int jj = 0; jj < 16; jj++) I1(r4 + ii, c4 + jj) |= kMaskSkip;
+        } else {
+            const int cbf_c = (c.sum_v[0] ? 2 : 0) | (c.sum_u[0] ? 1 : 0), cbf_y = (I1(r4, c4) >> kOffCbfY) & 1;
+            const bool skipped = merge_idx && (cbf_y | cbf_c) == 0;
+            const uint16_t first0 = I0(r4, c4);
+            const uint8_t first1 = I1(r4, c4);
+            for (int ii = 0; ii < b4; ii++)
+                for (int jj = 0; jj < b4; jj++) {
+                    I0(r4 + ii, c4 + jj) = (uint16_t)(first0 | kFlagInter | (cbf_c << kOffCbfC));
+                    I1(r4 + ii, c4 + jj) = (uint8_t)(first1 | (skipped ? kMaskSkip : 0));
+                }
+        }
+    }
+}
+
+void Row::evaluate_cu()
+{
+    std::unique_lock<std::mutex> lk(sh->m);
+    sh->cu.push_back(&cu_req);
+    pending = true;
+    if (--sh->running == 0) sh->cv_main.notify_one();
+    sh->cv_rows.wait(lk, [&] { return !pending; });
+    if (sh->error) throw Abort();
+}
+
+void Row::evaluate_chroma()
+{
+    std::unique_lock<std::mutex> lk(sh->m);
+    for (ChromaEval &c : chroma_req) sh->chroma.push_back(&c);
+    pending = true;
+    if (--sh->running == 0) sh->cv_main.notify_one();
+    sh->cv_rows.wait(lk, [&] { return !pending; });
+    if (sh->error) throw Abort();
+}
+
+// the row loop of xEncodeCUs (src/encode.cpp:5233-5590), P slices
+void Row::run()
+{
+    Shared &S = *sh;
+    PictureResult &out = *S.out;
+    const int cols = S.cols, w4 = S.w / 4, w8 = S.w / 8;
+    qp = S.qp;
+    lambda = 0.578 * std::pow(2.0, (qp - 12) / 3.0);
+    rate.frac = S.an->frac_bits[y];
+    rate.transitions = y == 0;
+    rate.w = &cab[0];
+    Ctx last = S.start;
+    auto clip64 = [](int v) { return v < -64 ? -64 : v > 64 ? 64 : v; };
+    try {
+        for (int x = 0; x < cols; x++) {
+            ctu_x = x;
+            if (y > 0) {   // top-right neighbour done (or the whole row above)
+                const int need = x + 2 < cols ? x + 2 : cols;
+                std::unique_lock<std::mutex> lk(S.m);
+                if (S.done[y - 1] < need) {
+                    this->need = need;
+                    if (--S.running == 0) S.cv_main.notify_one();
+                    S.cv_rows.wait(lk, [&] { return this->need < 0; });
+                    if (S.error) throw Abort();
+                }
+            }
+            // caches: neighbours from the picture-level arrays of the CTUs already done
+            std::memset(mode, kInvalid, sizeof mode);
+            std::memset(info1, 0, sizeof info1);
+            std::memset(info0, 0, sizeof info0);
+            std::memset(mv, 0, sizeof mv);
+            if (y > 0) {
+                for (int c = 0; c < 16; c++) M(-1, c) = kValid;
+                if (x > 0) M(-1, -1) = kValid;
+                if (x < cols - 1) M(-1, 16) = kValid;
+                for (int c = 0; c < 16; c++) I1(-1, c) = out.info1[(size_t)(y * 16 - 1) * w4 + x * 16 + c];
+                for (int c = -1; c <= 8; c++) {
+                    const int gx = x * 8 + c;
+                    if (gx >= 0 && gx < w8) V(-1, c) = out.mv[(size_t)(y * 8 - 1) * w8 + gx];
+                }
+            }
+            if (x > 0) {
+                for (int r = 0; r < 16; r++) {
+                    M(r, -1) = kValid;
+                    I1(r, -1) = out.info1[(size_t)(y * 16 + r) * w4 + x * 16 - 1];
+                }
+                for (int r = 0; r < 8; r++) V(r, -1) = out.mv[(size_t)(y * 8 + r) * w8 + x * 8 - 1];
+            }
+            const Ctx &init = (y == 0 || x > 0) ? last : S.saved[y - 1];
+            for (int d = 0; d < 5; d++) cab[d] = init;
+            std::memcpy(&out.ctx_in[((size_t)y * cols + x) * 256], cab[0].m, 256);
+            // xCuMvClip (:3794-3812)
+            min_ipel.x = (int16_t)clip64(-64 * x - 64), max_ipel.x = (int16_t)clip64(64 * (cols - x));
+            min_ipel.y = (int16_t)clip64(-64 * y - 64), max_ipel.y = (int16_t)clip64(64 * (S.nrows - y));
+
+            out.rd_cost[(size_t)y * cols + x] = decide(0, 0, 64, 0);
+            chroma_pass();
+
+            last = cab[0];
+            std::memcpy(&out.ctx_out[((size_t)y * cols + x) * 256], cab[0].m, 256);
+            for (int r = 0; r < 16; r++) {
+                std::memcpy(&out.info0[(size_t)(y * 16 + r) * w4 + x * 16], &I0(r, 0), 32);
+                std::memcpy(&out.info1[(size_t)(y * 16 + r) * w4 + x * 16], &I1(r, 0), 16);
+            }
+            for (int r = 0; r < 8; r++) {
+                std::memcpy(&out.mv[(size_t)(y * 8 + r) * w8 + x * 8], &V(r, 0), 8 * sizeof(Mv));
+                std::memcpy(&out.mvd[(size_t)(y * 8 + r) * w8 + x * 8], &mvd[r * 8], 8 * sizeof(Mv));
+                std::memcpy(&out.mvp_idx[(size_t)(y * 8 + r) * w8 + x * 8], &mvp_idx[r * 8], 8);
+            }
+            block_in(&out.rec_y[(size_t)(y * 64) * S.w + x * 64], S.w, rec_y, 64, 64, 64);
+            block_in(&out.coef_y[(size_t)(y * 64) * S.w + x * 64], S.w * 2, coef_y, 128, 64, 128);
+            block_in(&out.rec_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_u, 32, 32, 32);
+            block_in(&out.rec_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_v, 32, 32, 32);
+            block_in(&out.coef_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_u, 64, 32, 64);
+            block_in(&out.coef_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_v, 64, 32, 64);
+            {
+                std::lock_guard<std::mutex> lk(S.m);
+                if (x == 1 && y != S.nrows - 1) S.saved[y] = cab[0];
+                S.done[y] = x + 1;
+                if (y + 1 < S.nrows) {
+                    Row &below = S.rows[y + 1];
+                    if (below.need >= 0 && S.done[y] >= below.need) {
+                        below.need = -1;
+                        S.running++;
+                        S.cv_rows.notify_all();
+                    }
+                }
+            }
+        }
+    } catch (const Abort &) {
+    }
+    S.an->frac_bits[y] = rate.frac;
+    std::lock_guard<std::mutex> lk(S.m);
+    S.finished++;
+    if (--S.running == 0) S.cv_main.notify_one();
+}
+
+}  // namespace
+
+static_assert(sizeof kInitP == 184 && sizeof kInitI == 184, "one initialisation value per context");
+
+const uint8_t *next_state_table() { return &tables().next[0][0]; }
+
+const uint16_t *diag_scan(int log2_size) { return log2_size >= 2 && log2_size <= 5 ? tables().scan[log2_size - 2] : nullptr; }
+
+void init_contexts(int slice_type, int qp, uint8_t ctx[256])
+{
+    std::memset(ctx, 0, 256);
+    const uint8_t *v = slice_type == 2 ? kInitI : kInitP;
+    for (int i = 0; i < 184; i++) {
+        const int m = (v[i] >> 4) * 5 - 45, n = ((v[i] & 15) << 3) - 16;
+        int s = ((m * qp) >> 4) + n;
+        s = s < 1 ? 1 : s > 126 ? 126 : s;
+        const int mps = s >= 64;
+        ctx[i] = (uint8_t)(((mps ? s - 64 : 63 - s) << 1) + mps);
+    }
+}
+
+Analyser::Analyser(int width, int height) : w_(width), h_(height), rows_(height / 64), cols_(width / 64)
+{
+    const size_t n = (size_t)rows_ * cols_ * 5;
+    sum_cost.assign(n, 0.0);
+    avg_cost.assign(n, 0.0);
+    count.assign(n, 0);
+    frac_bits.assign(rows_, 0);
+}
+
+int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
+{
+    if (w_ <= 0 || h_ <= 0 || w_ % 64 || h_ % 64 || qp < 0 || qp > 51) return -1;
+    const size_t n4 = (size_t)(w_ / 4) * (h_ / 4), n8 = (size_t)(w_ / 8) * (h_ / 8), ny = (size_t)w_ * h_, nctu = (size_t)rows_ * cols_;
+    out.info0.assign(n4, 0), out.info1.assign(n4, 0);
+    out.mv.assign(n8, Mv{ 0, 0 }), out.mvd.assign(n8, Mv{ 0, 0 }), out.mvp_idx.assign(n8, 0);
+    out.coef_y.assign(ny, 0), out.coef_u.assign(ny / 4, 0), out.coef_v.assign(ny / 4, 0);
+    out.rec_y.assign(ny, 0), out.rec_u.assign(ny / 4, 0), out.rec_v.assign(ny / 4, 0);
+    out.rd_cost.assign(nctu, 0);
+    out.ctx_in.assign(nctu * 256, 0), out.ctx_out.assign(nctu * 256, 0);
+    out.evaluator_calls = out.cu_requests = out.chroma_requests = 0;
+
+    Shared S;
+    S.an = this, S.out = &out;
+    S.w = w_, S.h = h_, S.cols = cols_, S.nrows = rows_, S.qp = qp;
+    S.done.assign(rows_, 0);
+    S.saved.resize(rows_);
+    init_contexts(1, qp, S.start.m);
+    S.rows.resize(rows_);
+    S.running = rows_;
+    for (int y = 0; y < rows_; y++) S.rows[y].sh = &S, S.rows[y].y = y;
+    std::vector<std::thread> threads;
+    threads.reserve(rows_);
+    for (int y = 0; y < rows_; y++) threads.emplace_back([&S, y] { S.rows[y].run(); });
+
+    std::vector<CuEval *> cu;
+    std::vector<ChromaEval *> chroma;
+    {
+        std::unique_lock<std::mutex> lk(S.m);
+        for (;;) {
+            S.cv_main.wait(lk, [&] { return S.running == 0; });
+            if (S.finished == rows_) break;
+            cu.swap(S.cu), chroma.swap(S.chroma);
+            S.cu.clear(), S.chroma.clear();
+            int rc = 0;
+            if (cu.empty() && chroma.empty()) {
+                rc = -2;      // every row waits for a neighbour: cannot happen with a sound dependency order
+            } else if (!S.error) {
+                lk.unlock();
+                rc = ev.evaluate(cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
+                lk.lock();
+                out.evaluator_calls++, out.cu_requests += cu.size(), out.chroma_requests += chroma.size();
+            }
+            if (rc && !S.error) S.error = rc;
+            for (Row &r : S.rows) {
+                if (r.pending) r.pending = false, S.running++;
+                if (S.error && r.need >= 0) r.need = -1, S.running++;
+            }
+            cu.clear(), chroma.clear();
+            S.cv_rows.notify_all();
+        }
+    }
+    for (std::thread &t : threads) t.join();
+    return S.error;
+}
+
+}  // namespace analysis
+}  // namespace xmi

@@ -1,0 +1,114 @@
+// analysis_core.h - host side of the P-picture analysis loop: the reference's CU decision for inter pictures
+// (xEncodeCUs / xEncDecideCU_Inter / xPreEncRec / xEncInterCTU, src/encode.cpp:5203-5591, 3080-3639, 3023-3078, 3641-3791)
+// restated so that every pixel operation of a CU - candidate predictions, distortions, the motion search, the transform
+// chains - is ONE request to an evaluator, and the requests of all CTU rows that are ready (the reference's wavefront
+// order) are handed over together. This file knows nothing about where the evaluator runs: libx265_amd.so binds it to
+// the GPU kernels; the test harness under oracle/ binds it to the CPU checker.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace xmi {
+namespace analysis {
+
+struct Mv {
+    int16_t x, y;
+};
+
+// One square inter CU, everything xEncDecideCU_Inter asks of the pixel primitives for it (src/encode.cpp:3272-3404):
+//   - the prediction of every usable merge candidate and its SSD against the source; the first smallest wins (:3272-3289);
+//   - transform chain of the source against that prediction (xPreEncRec, :3297), SSD of its reconstruction (:3321);
+//   - xMotionSearch (:3379) with bZeroMV set when that candidate is the zero vector (:3341), prediction at the vector
+//     found (:3385), transform chain (:3389), SSD of its reconstruction (:3404).
+// A 64x64 CU is transformed as four 32x32 units (:3047-3064): sum_*[j*2+i] belongs to the unit at (32 i, 32 j); smaller
+// CUs use sum_*[0]. Blocks are size x size, rows `size` apart. The evaluator owns the output blocks; they stay valid until
+// its next call.
+struct CuEval {
+    int x0, y0, size;                 // luma position in the picture, 8..64
+    int n_merge;                      // entries of merge_mv
+    Mv merge_mv[5];
+    uint8_t merge_ok[5];              // 0: candidate left out (its clipped form differs, :3275)
+    Mv amvp[2];                       // sMVP[0], sMVP[1] of xFillMvpCand
+    Mv mv_min_ipel, mv_max_ipel;      // xCuMvClip box (:3794)
+    double lambda;                    // dLambda; the search uses (UInt32)sqrt(lambda) (:2836)
+    int qp;
+    // results
+    int best_merge;                   // index into merge_mv, -1 when no candidate was usable
+    uint32_t ssd_skip;                // SSD(source, prediction of best_merge)
+    uint32_t ssd_merge;               // SSD(source, reconstruction of best_merge)
+    uint32_t sum_merge[4];            // sum |level| per transform unit
+    const uint8_t *pred_merge, *rec_merge;
+    const int16_t *level_merge;
+    Mv mv_me;
+    uint32_t ssd_me, sum_me[4];
+    const uint8_t *rec_me;
+    const int16_t *level_me;
+};
+
+// Chroma of one decided CU (xEncInterCTU, src/encode.cpp:3719-3788): prediction of U and V at the CU's vector; unless
+// the CU is skipped, their transform chains at the chroma QP. Blocks are size/2 x size/2; a 64x64 CU again as four units.
+// For a skipped CU the reconstruction is the prediction and the levels are zero.
+struct ChromaEval {
+    int x0, y0, size;                 // luma position and size of the CU
+    Mv mv;
+    int skip;
+    int qpc;
+    const uint8_t *rec_u, *rec_v;
+    const int16_t *level_u, *level_v;
+    uint32_t sum_u[4], sum_v[4];
+};
+
+class Evaluator {
+public:
+    virtual ~Evaluator() {}
+    // fills the result fields of every request; returns 0, or an error code that ends the picture
+    virtual int evaluate(CuEval *const *cu, int ncu, ChromaEval *const *chroma, int nchroma) = 0;
+};
+
+// What a picture leaves behind, picture-level arrays (CTU caches of the reference laid side by side):
+//   info0 (ausModeYInfo0) and info1 (aucModeYInfo1) per 4x4 block, width/4 per row; mv, mvd, mvp_idx per 8x8 block,
+//   width/8 per row; levels and reconstruction per sample; per CTU the RD cost xEncDecideCU_Inter returned at depth 0
+//   and the estimation contexts before and after the CTU (256 bytes each, cabacRdo[y][0] / cabacRdoLast[y]).
+struct PictureResult {
+    std::vector<uint16_t> info0;
+    std::vector<uint8_t> info1;
+    std::vector<Mv> mv, mvd;
+    std::vector<uint8_t> mvp_idx;
+    std::vector<int16_t> coef_y, coef_u, coef_v;
+    std::vector<uint8_t> rec_y, rec_u, rec_v;
+    std::vector<uint32_t> rd_cost;
+    std::vector<uint8_t> ctx_in, ctx_out;
+    uint64_t evaluator_calls = 0, cu_requests = 0, chroma_requests = 0;
+};
+
+class Analyser {
+public:
+    Analyser(int width, int height);          // coded size, multiples of 64
+    int width() const { return w_; }
+    int height() const { return h_; }
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+
+    // State the reference carries from picture to picture and never resets: the FAST_MD cost statistics per CTU and depth
+    // (dSumOfRdCosts, nRdCounts, dAverageRdCosts, src/encode.cpp:3556-3568) and the fractional bits of every row's rate
+    // counter (rdoParam[y].fracBits, :189).
+    std::vector<double> sum_cost, avg_cost;   // [row][col][5]
+    std::vector<int32_t> count;
+    std::vector<uint64_t> frac_bits;          // [row]
+
+    // One P picture: decisions and reconstruction of every CTU, rows advancing as a wavefront (a CTU starts when its
+    // left neighbour and the CTU above and to the right are done). The evaluator is bound to the picture pair (source,
+    // padded previous reconstruction) by its owner before the call. Returns 0 or the evaluator's error.
+    int p_picture(int qp, Evaluator &ev, PictureResult &out);
+
+private:
+    int w_, h_, rows_, cols_;
+};
+
+// the tables the rate estimate walks; exposed for the tests that pin them against the reference's
+const uint16_t *diag_scan(int log2_size);               // coefficient scan of a 4..32 block, positions y * size + x
+const uint8_t *next_state_table();                       // [state][bin] -> state, 128 x 2
+void init_contexts(int slice_type, int qp, uint8_t ctx[256]);   // xCabacInit (src/bitstream.cpp:588), slice 1 = P, 2 = I
+
+}  // namespace analysis
+}  // namespace xmi
