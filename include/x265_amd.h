@@ -365,6 +365,35 @@ int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_i
 int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const uint8_t *pred, const uint8_t *qp,
                        const uint8_t *flags, int16_t *level, uint8_t *rec, uint32_t *sum);
 
+/* ---- P-picture analysis ----------------------------------------------------------------------------------
+ * The reference's CTU loop for inter pictures - xEncodeCUs (src/encode.cpp:5203-5591) with xEncDecideCU_Inter (:3080-3639),
+ * xPreEncRec (:3023-3078), the bit estimate of xEncodeCoeffNxN (:2385-2553) / xEstimateCmdsBit (:162) and the chroma pass
+ * xEncInterCTU (:3641-3791) - as one call per picture: mode decision and reconstruction of every CTU, with the decisions,
+ * costs and contexts the reference's loop arrives at. The serial part (decision recursion, CABAC rate estimate) runs on
+ * the host, one thread per CTU row in the reference's wavefront order; every pixel operation of a CU - merge candidates,
+ * motion search, prediction, transform chains, distortions - is batched over the rows that are ready and runs on the GPU.
+ *
+ * xmi_analysis_create: width, height = coded size (multiples of 64). NULL on failure (xmi_last_error()).
+ * xmi_analysis_state : the state the reference carries from picture to picture and never resets - per CTU and depth the
+ *   FAST_MD cost statistics (dSumOfRdCosts, nRdCounts, dAverageRdCosts, inc/x265.h:379-381: (height/64) x (width/64) x 5
+ *   entries each) and per CTU row the fractional bits of its rate counter (rdoParam[y].fracBits, inc/x265.h:359). set != 0
+ *   loads it, set == 0 reads it back. A new handle starts from zeros, as the reference does.
+ * xmi_analysis_p_picture: one P picture. src_*: source planes, packed (width x height, width/2 x height/2); ref_*: first
+ *   byte of the padded previous reconstruction ((width + 2 pad) x (height + 2 pad), chroma with pad/2), pad = PAD_YSIZE = 80
+ *   (inc/config.h:52); qp: slice QP. Outputs (any may be NULL), picture-level arrays of what the reference keeps per CTU:
+ *   info0 / info1 = ausModeYInfo0 / aucModeYInfo1 per 4x4 block (inc/x265.h:220, 228), mv / mvd = vectors and vector
+ *   differences per 8x8 block (x, y), mvp_idx per 8x8 block, coef_* = levels, rec_* = unfiltered reconstruction, rd_cost =
+ *   the depth-0 return value of xEncDecideCU_Inter per CTU, ctx_in / ctx_out = 256 estimation contexts per CTU before and
+ *   after it (cabacRdo[y][0], cabacRdoLast[y]), counters = { evaluator round trips, CU requests, chroma requests }. */
+typedef struct xmi_analysis xmi_analysis;
+xmi_analysis *xmi_analysis_create(int width, int height);
+void xmi_analysis_destroy(xmi_analysis *a);
+int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits);
+int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, const uint8_t *ref_y,
+                           const uint8_t *ref_u, const uint8_t *ref_v, int pad, int qp, uint16_t *info0, uint8_t *info1, int16_t *mv,
+                           int16_t *mvd, uint8_t *mvp_idx, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint8_t *rec_y, uint8_t *rec_u,
+                           uint8_t *rec_v, uint32_t *rd_cost, uint8_t *ctx_in, uint8_t *ctx_out, uint64_t *counters);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

@@ -623,8 +623,6 @@ void Row::collect_cus(int px, int py, int size, std::vector<int> &list)
 // xEncInterCTU (src/encode.cpp:3641-3791)
 void Row::chroma_pass()
 {
-    static const uint8_t chroma_qp[58] = { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
-                                           29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
     std::vector<int> list;
     collect_cus(0, 0, 64, list);
     chroma_req.resize(list.size());
@@ -634,7 +632,7 @@ void Row::chroma_pass()
         c.x0 = ctu_x * 64 + px, c.y0 = y * 64 + py, c.size = size;
         c.mv = V(py / 8, px / 8);
         c.skip = I1(py / 4, px / 4) & 1 & (I0(0, 0) >> 7);
-        c.qpc = chroma_qp[qp];
+        c.qpc = chroma_qp(qp);
     }
     evaluate_chroma();
     for (size_t n = 0; n < list.size(); n++) {
@@ -800,6 +798,13 @@ void Row::run()
 }  // namespace
 
 static_assert(sizeof kInitP == 184 && sizeof kInitI == 184, "one initialisation value per context");
+
+int chroma_qp(int qp)
+{
+    static const uint8_t t[58] = { 0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                                   29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+    return qp < 0 ? 0 : qp > 57 ? 51 : t[qp];
+}
 
 const uint8_t *next_state_table() { return &tables().next[0][0]; }
 

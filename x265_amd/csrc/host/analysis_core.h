@@ -109,6 +109,7 @@ private:
 const uint16_t *diag_scan(int log2_size);               // coefficient scan of a 4..32 block, positions y * size + x
 const uint8_t *next_state_table();                       // [state][bin] -> state, 128 x 2
 void init_contexts(int slice_type, int qp, uint8_t ctx[256]);   // xCabacInit (src/bitstream.cpp:588), slice 1 = P, 2 = I
+int chroma_qp(int qp);                                   // xg_aucChromaScale (src/table.cpp:160)
 
 }  // namespace analysis
 }  // namespace xmi
