@@ -172,6 +172,19 @@ def satd_rates(L, capi, torch, dev, stream, reps=10):
     return out
 
 
+def analysis_rate(L, qp=32, pictures=4):
+    """The encode-side half of the headline metric with this library's code only: P pictures per second of
+    xmi_analysis_p_picture (mode decision + reconstruction of every CTU of a 1080p picture: the reference's xEncodeCUs for
+    inter pictures, host decision logic + GPU pixel work). Outside the timed region, rank 0. The reference's own encoder on
+    the host cores is reported under cpu_baseline.encoder (fps = one thread, fps_row_threads = its OpenMP row threads)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import bench_analysis
+        return bench_analysis.run(1920, 1080, qp, pictures, lib=L)
+    except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +331,7 @@ def main():
                          "kernel_ms_min": round(kern_ms[0], 4)},
         }
         out["satd"] = satd_rates(L, capi, torch, dev, stream)
+        out["analysis"] = analysis_rate(L)
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

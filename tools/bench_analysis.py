@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""P pictures per second of xmi_analysis_p_picture (decision + reconstruction of every CTU, this library's code only) on
+synthetic video: picture t is analysed against the padded source of picture t-1 as its reference (no loop filters in
+between: the analysis work per picture is what is measured, not a conforming encode). Prints one JSON line."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def synth(w, h, t, seed):
+    rng = np.random.default_rng(seed * 1000 + t)
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = np.clip(128 + 60 * np.sin((xx + 3 * t) / 17.0) + 40 * np.cos((yy + 2 * t) / 11.0) + rng.integers(-6, 7, (h, w)), 0, 255).astype(np.uint8)
+    y2, x2 = np.mgrid[0:h // 2, 0:w // 2]
+    u = np.clip(128 + 30 * np.sin((2 * x2 + 3 * t) / 23.0), 0, 255).astype(np.uint8)
+    v = np.clip(128 + 30 * np.cos((2 * y2 + 2 * t) / 19.0), 0, 255).astype(np.uint8)
+    return y, u, v
+
+
+def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lib=None):
+    from x265_amd import capi
+    from tests import ctu_trace as T
+    L = lib or capi.load()
+    capi.check(L.xmi_init(0))
+    w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
+    frames = [synth(w, h, t, seed) for t in range(pictures + 1)]
+    r = T.Runner(L, "xmi_analysis_", w, h)
+    times, rounds, cus = [], [], []
+    try:
+        for t in range(1, pictures + 1):
+            pic = {"w": w, "h": h, "qp": qp, "pad": 80, "rows": h // 64, "cols": w // 64, "src": frames[t],
+                   "ref": tuple(np.pad(p, 80 if i == 0 else 40, mode="edge") for i, p in enumerate(frames[t - 1]))}
+            t0 = time.perf_counter()
+            out = r.run(pic)
+            times.append(time.perf_counter() - t0)
+            rounds.append(int(out["counters"][0]))
+            cus.append(int(out["counters"][1]))
+    finally:
+        r.close()
+    steady = times[1:] if len(times) > 1 else times
+    return {"analysis_fps": round(len(steady) / sum(steady), 3), "ms_per_picture": [round(x * 1e3, 2) for x in times], "round_trips": rounds,
+            "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp,
+            "what": f"{width}x{height} synthetic P pictures, decision + reconstruction of every CTU; includes the host copies of the call "
+                    "(planes up, result arrays down)"}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--qp", type=int, default=32)
+    ap.add_argument("--pictures", type=int, default=6)
+    a = ap.parse_args()
+    print(json.dumps(run(a.width, a.height, a.qp, a.pictures)))
