@@ -1,28 +1,29 @@
 // analysis_gpu.hip - the P-picture analysis loop on the GPU: host/analysis_core.cpp (decision recursion, rate estimate,
-// wavefront of CTU rows) bound to an evaluator that serves every batch of CU requests with the library's kernels, and the
-// C ABI around it (xmi_analysis_*).
+// wavefront of CTU rows) bound to an evaluator that serves every batch of CU requests with ONE kernel launch, and the C ABI
+// around it (xmi_analysis_*).
 //
-// One evaluator call = one round trip: the request tables go up in one copy, a fixed sequence of launches runs on one
-// stream, everything the host needs comes back in one copy.
-//   luma, per CU    : analysis_prepare_kernel  SSD of every usable merge candidate against the source, read from the
-//                                              quarter-pel planes (a prediction is a plain copy out of the plane of its
-//                                              phase); first smallest wins; its prediction and the source block are packed
-//                                              as transform units; the search request learns whether that candidate was
-//                                              the zero vector
-//                     xmi_me_search_batch_dev  xMotionSearch replay
-//                     analysis_me_pred_kernel  prediction at the vector found, packed as transform units
-//                     xmi_tu_chain_batch_dev   per transform size: both candidates of every CU in one batch
-//                     xmi_block_metric_batch_dev (SSD) per transform size: source against reconstruction
-//   chroma, per CTU : analysis_gather_kernel   source blocks of U and V packed as transform units
-//                     xmi_pred_inter_batch_dev prediction of U, then of V, at the CU's vector
-//                     xmi_tu_chain_batch_dev   per transform size, U and V units in one batch
+// A batch is a handful of CUs (one per CTU row that is ready), and what the host waits for is its latency, not its
+// throughput. So a round trip is: the host writes the job table into pinned memory the GPU reads directly, launches
+// analysis_round_kernel, and spins on a word of pinned memory; the kernel writes every result straight into pinned host
+// memory and its last workgroup sets that word. No copies are enqueued and nothing waits on an interrupt.
+//   luma job, two workgroups (they share no data, so the two candidates of a CU are evaluated side by side):
+//     both     SSD of every usable merge candidate against the source - a prediction is a plain copy out of the quarter-pel
+//              plane of its phase - and the first smallest (src/encode.cpp:3272-3289)
+//     merge    transform chain of the source against that prediction (xPreEncRec), SSD of the reconstruction
+//     search   xMotionSearch (me_search_device.h, one wavefront) with bZeroMV from the selection; prediction at the vector
+//              found; transform chain; SSD of the reconstruction
+//   chroma job (one plane of one transform unit), one workgroup: 4-tap prediction at the CU's vector, transform chain
+// The transform chain is the VALU form of tu_chain.hip (LDS operands, v_dot2) for one unit per workgroup; a 64x64 CU runs its
+// four 32x32 units one after the other.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "host/analysis_core.h"
-#include "xmi_common.h"
+#include "me_search_device.h"
+#include "tu_valu_device.h"
 
 using namespace xmi::analysis;
 
@@ -31,172 +32,309 @@ namespace {
 constexpr int kPad = 80, kPadC = 40;          // PAD_YSIZE / PAD_CSIZE of the reference (inc/config.h:52-53)
 constexpr int kMeRange = 32;                  // ME_RANGE (inc/config.h:50)
 
+// ---- job and result records (pinned host memory, read / written by the kernel) ----
 struct LumaJob {
     int32_t x0, y0, size;
     int32_t n_merge;
     int16_t merge_mv[5][2];
     uint8_t merge_ok[5];
-    uint8_t cls;                  // transform class: 0 = 8x8, 1 = 16x16, 2 = 32x32
-    uint8_t units;                // transform units per candidate: 1, or 4 for a 64x64 CU
-    uint8_t reserved;
-    int32_t unit_merge, unit_me;  // first unit of the two candidates inside the class arena
+    uint8_t reserved[3];
+    int16_t amvp[2][2];
+    int16_t mv_min_ipel[2], mv_max_ipel[2];
+    uint32_t sqrt_lambda;
+    uint32_t out_head;            // byte offsets into the result area: LumaHead, then the blocks
+    uint32_t out_pred_merge, out_rec_merge, out_level_merge, out_rec_me, out_level_me;
 };
-struct LumaOut {
+struct LumaHead {
     int32_t best_merge;
-    uint32_t ssd_skip;
+    uint32_t ssd_skip, ssd_merge, sum_merge[4];
+    int16_t mv[2];
+    uint32_t ssd_me, sum_me[4];
 };
-struct GatherJob {
-    int32_t plane;                // 0 = U, 1 = V source
-    int32_t x, y, n;              // block in plane samples
-    uint32_t dst;                 // byte offset in the packed source arena
+struct ChromaJob {
+    int32_t plane;                // 0 = U, 1 = V
+    int32_t x, y, n;              // unit in plane samples: 4, 8 or 16 square
+    int16_t mv[2];                // the CU's luma vector (eighth-pel in chroma)
+    int32_t skip;
+    uint32_t out_sum, out_rec, out_level;
+    int32_t rec_stride;           // samples per row of the CU's result blocks (the unit may be a quarter of them)
 };
 
-struct ClassPtrs {
-    uint8_t *pix[3], *pred[3];
-};
-
-struct PrepareParams {
+struct RoundParams {
     const LumaJob *jobs;
-    LumaOut *out;
-    xmi_me_request *me_req;
-    const xmi_me_result *me_res;
-    const uint8_t *src;           // source luma, stride = width
-    const uint8_t *planes;        // 16 quarter-pel planes of the padded reference
-    int width, stride, rows;      // plane geometry (stride x rows bytes per plane)
-    ClassPtrs c;
+    const ChromaJob *cjobs;
+    int ncu, nchroma;
+    const uint8_t *src[3];        // source planes, rows width / width/2 apart
+    const uint8_t *planes;        // 16 quarter-pel luma planes of the padded reference
+    const uint8_t *ref_c[2];      // sample (0,0) of the padded chroma reference planes
+    int width, stride, rows, stride_c;
+    int qp, qpc;
+    uint8_t *out;                 // result area
+    unsigned *counter;            // workgroups finished since the handle was made (device memory)
+    unsigned target;              // value of the counter when this round is complete
+    unsigned *flag;               // pinned host word the host spins on
+    unsigned seq;
 };
 
-__device__ __forceinline__ const uint8_t *plane_block(const PrepareParams &p, int x0, int y0, int mvx, int mvy)
+__constant__ int k_chroma_taps[8][4] = { { 0, 64, 0, 0 },   { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+                                         { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };   // src/table.cpp:532-541
+
+// LDS of one workgroup: transform operands (up to 32x32), the unit's source and prediction bytes, the search window
+struct __align__(16) RoundLds {
+    int16_t mat[2][32 * 34];      // core matrix and its transpose, rows N + 2 apart
+    int16_t a[32 * 34], b[32 * 34];
+    uint8_t pix[32 * 32], pred[32 * 32];
+    uint8_t win[(64 + 16) * (64 + 24)];
+    uint32_t red[4];
+    uint32_t acc[2];
+    xmi_me_result me;
+};
+
+__device__ __forceinline__ const uint8_t *plane_block(const RoundParams &p, int x0, int y0, int mvx, int mvy)
 {
     const size_t plane = (size_t)((mvy & 3) * 4 + (mvx & 3)) * (size_t)p.stride * p.rows;
     return p.planes + plane + (size_t)(kPad + y0 + (mvy >> 2)) * p.stride + kPad + x0 + (mvx >> 2);
 }
 
-// byte offset of sample (x, y) of a CU inside its packed transform units
-__device__ __forceinline__ uint32_t unit_offset(int first_unit, int size, int x, int y)
-{
-    if (size == 64) return (uint32_t)(first_unit + (y >> 5) * 2 + (x >> 5)) * 1024u + (uint32_t)((y & 31) * 32 + (x & 31));
-    return (uint32_t)first_unit * (uint32_t)(size * size) + (uint32_t)(y * size + x);
-}
-
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *lds)
+__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return lds[0] + lds[1] + lds[2] + lds[3];
+    return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void __launch_bounds__(256) analysis_prepare_kernel(const PrepareParams p)
+// xSubDctQuantRec (src/encode.cpp:3005-3021) of one N x N unit by the whole workgroup, P-slice rounding, DCT:
+// source and prediction come with their own strides (any address space); levels, reconstruction and, when asked for, the
+// prediction go out with the stride of the CU's result blocks. Returns sum |level| and the SSD of the reconstruction
+// against the source in every thread.
+template <int N>
+__device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
+                           uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd)
 {
-    __shared__ uint32_t red[4];
-    const LumaJob j = p.jobs[blockIdx.x];
-    const int n = j.size, npx = n * n, tid = threadIdx.x;
-    const uint8_t *src = p.src + (size_t)j.y0 * p.width + j.x0;
+    constexpr int LD = N + 2, LG = Cfg<N>::LOG2, TPT = Cfg<N>::TPT;
+    const int tid = threadIdx.x;
+    const bool live = tid < TPT;
+    int16_t *M = L.mat[0], *Mt = L.mat[1];
+    for (int e = tid; e < N * N; e += 256) {
+        const int k = e / N, j = e % N;
+        const int16_t c = (int16_t)dct_coef(N, k, j);
+        M[k * LD + j] = c;
+        Mt[j * LD + k] = c;
+        const int s = pix[(size_t)k * pix_stride + j], q = pred[(size_t)k * pred_stride + j];
+        L.pix[e] = (uint8_t)s;
+        L.pred[e] = (uint8_t)q;
+        L.a[k * LD + j] = (int16_t)(s - q);
+    }
+    if (tid < 2) L.acc[tid] = 0;
+    __syncthreads();
+    if (live) stage<N, false>(M, L.a, L.b, LG - 1, tid);
+    __syncthreads();
+    if (live) stage<N, false>(M, L.b, L.a, LG + 6, tid);
+    __syncthreads();
+    const int qbits = 14 + qp / 6 + (15 - 8 - LG), q = k_quant_scales[qp % 6], qrnd = 85 << (qbits - 9);
+    const int dshift = 20 - 14 - (15 - 8 - LG), dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
+    uint32_t local = 0;
+    for (int e = tid; e < N * N; e += 256) {
+        const int k = e / N, i = e % N;
+        const int c = L.a[k * LD + i];
+        const int mag = (abs(c) * q + qrnd) >> qbits;
+        local += (uint32_t)mag;
+        const int lv = clip16(c < 0 ? -mag : mag);
+        level[(size_t)k * out_stride + i] = (int16_t)lv;
+        L.b[i * LD + k] = (int16_t)clip16((lv * dscale + (1 << (dshift - 1))) >> dshift);
+    }
+    if (local) atomicAdd(&L.acc[0], local);
+    __syncthreads();
+    if (live) stage<N, true>(Mt, L.b, L.a, 7, tid);
+    __syncthreads();
+    if (live) stage<N, true>(Mt, L.a, L.b, 12, tid);
+    __syncthreads();
+    uint32_t d2 = 0;
+    for (int e = tid; e < N * N; e += 256) {
+        const int i = e / N, j = e % N;
+        const int pr = L.pred[e];
+        const int v = min(255, max(0, (int)L.b[j * LD + i] + pr));
+        rec[(size_t)i * out_stride + j] = (uint8_t)v;
+        if (pred_out) pred_out[(size_t)i * out_stride + j] = (uint8_t)pr;
+        const int d = (int)L.pix[e] - v;
+        d2 += (uint32_t)(d * d);
+    }
+    if (d2) atomicAdd(&L.acc[1], d2);
+    __syncthreads();
+    sum = L.acc[0];
+    ssd = L.acc[1];
+    __syncthreads();
+}
+
+template <int N>
+__device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, int path)
+{
+    constexpr int UN = N == 64 ? 32 : N, UNITS = N == 64 ? 4 : 1;
+    const int tid = threadIdx.x;
+    const uint8_t *src = p.src[0] + (size_t)j.y0 * p.width + j.x0;
+    // merge candidates: both workgroups of the job come to the same selection
     uint32_t best_ssd = 0xffffffffu;
     int best = -1;
     for (int k = 0; k < j.n_merge; k++) {
-        if (!j.merge_ok[k]) continue;                       // uniform
+        if (!j.merge_ok[k]) continue;
         const uint8_t *pr = plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]);
         uint32_t acc = 0;
-        for (int i = tid * 4; i < npx; i += 1024) {         // four samples of one row (sizes are multiples of 8)
-            const int y = i / n, x = i - y * n;
-            const uint8_t *a = src + (size_t)y * p.width + x, *b = pr + (size_t)y * p.stride + x;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int d = (int)a[t] - (int)b[t];
-                acc += (uint32_t)(d * d);
-            }
+        for (int i = tid * 4; i < N * N; i += 1024) {
+            const int y = i / N, x = i - y * N;
+            const uchar4 a = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.width + x);
+            const uint8_t *b = pr + (size_t)y * p.stride + x;
+            const int d0 = (int)a.x - b[0], d1 = (int)a.y - b[1], d2 = (int)a.z - b[2], d3 = (int)a.w - b[3];
+            acc += (uint32_t)(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
         }
-        const uint32_t ssd = block_sum(acc, red);
-        if (ssd < best_ssd) best_ssd = ssd, best = k;       // every thread holds the same totals
+        const uint32_t ssd = block_sum(acc, L.red);
+        if (ssd < best_ssd) best_ssd = ssd, best = k;
+    }
+    LumaHead *head = reinterpret_cast<LumaHead *>(p.out + j.out_head);
+    int mvx, mvy;
+    if (path == 0) {
+        if (tid == 0) head->best_merge = best, head->ssd_skip = best_ssd;
+        if (best < 0) return;
+        mvx = j.merge_mv[best][0], mvy = j.merge_mv[best][1];
+    } else {
+        if (tid < 64) {
+            xmi_me_request rq;
+            rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N;
+            rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
+            rq.zero_mv_tested = best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0;
+            rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
+            rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
+            rq.sqrt_lambda = j.sqrt_lambda;
+            MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+            search<N, false>(mp, rq, 0, tid, L.win);
+        }
+        __syncthreads();
+        mvx = L.me.mv[0], mvy = L.me.mv[1];
+        if (tid == 0) head->mv[0] = (int16_t)mvx, head->mv[1] = (int16_t)mvy;
+    }
+    const uint8_t *pr = plane_block(p, j.x0, j.y0, mvx, mvy);
+    int16_t *level = reinterpret_cast<int16_t *>(p.out + (path ? j.out_level_me : j.out_level_merge));
+    uint8_t *rec = p.out + (path ? j.out_rec_me : j.out_rec_merge), *pred_out = path ? nullptr : p.out + j.out_pred_merge;
+    uint32_t ssd_total = 0;
+#pragma unroll 1
+    for (int u = 0; u < UNITS; u++) {
+        const int ux = (u & 1) * 32, uy = (u >> 1) * 32;
+        const size_t o = (size_t)uy * N + ux;
+        uint32_t sum, ssd;
+        chain_unit<UN>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
+                       pred_out ? pred_out + o : nullptr, N, sum, ssd);
+        ssd_total += ssd;
+        if (tid == 0) (path ? head->sum_me : head->sum_merge)[u] = sum;
     }
     if (tid == 0) {
-        p.out[blockIdx.x].best_merge = best;
-        p.out[blockIdx.x].ssd_skip = best_ssd;
-        p.me_req[blockIdx.x].zero_mv_tested = best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0;
+        if (path) head->ssd_me = ssd_total;
+        else head->ssd_merge = ssd_total;
     }
-    const uint8_t *pr = best >= 0 ? plane_block(p, j.x0, j.y0, j.merge_mv[best][0], j.merge_mv[best][1]) : nullptr;
-    uint8_t *pix = p.c.pix[j.cls], *pred = p.c.pred[j.cls];
-    for (int i = tid * 4; i < npx; i += 1024) {
-        const int y = i / n, x = i - y * n;
-        const uchar4 s = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.width + x);
-        uchar4 q = make_uchar4(0, 0, 0, 0);
-        if (pr) {
-            const uint8_t *b = pr + (size_t)y * p.stride + x;
-            q = make_uchar4(b[0], b[1], b[2], b[3]);
+}
+
+// one sample of xPredInterChromaBlk (src/pixel.cpp:9657-9703): 4-tap filters at eighth-pel; with both fractions the second
+// stage works on the unrounded first-stage sums, (sum + 2048) >> 12 (the reference's -8192 / +8192*64 offsets cancel)
+__device__ __forceinline__ int chroma_sample(const uint8_t *ref, int stride, int xf, int yf)
+{
+    if (!xf && !yf) return ref[0];
+    if (!yf) {
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) s += (int)ref[t - 1] * k_chroma_taps[xf][t];
+        return min(255, max(0, (s + 32) >> 6));
+    }
+    if (!xf) {
+        int s = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) s += (int)ref[(ptrdiff_t)(t - 1) * stride] * k_chroma_taps[yf][t];
+        return min(255, max(0, (s + 32) >> 6));
+    }
+    int s = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int hsum = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) hsum += (int)ref[(ptrdiff_t)(r - 1) * stride + t - 1] * k_chroma_taps[xf][t];
+        s += hsum * k_chroma_taps[yf][r];
+    }
+    return min(255, max(0, (s + 2048) >> 12));
+}
+
+template <int N>
+__device__ void chroma_job(const RoundParams &p, RoundLds &L, const ChromaJob &j, uint8_t *pred_lds)
+{
+    const int tid = threadIdx.x;
+    const uint8_t *ref = p.ref_c[j.plane] + (ptrdiff_t)(j.y + (j.mv[1] >> 3)) * p.stride_c + j.x + (j.mv[0] >> 3);
+    const int xf = j.mv[0] & 7, yf = j.mv[1] & 7;
+    for (int e = tid; e < N * N; e += 256) {
+        const int y = e / N, x = e - y * N;
+        pred_lds[e] = (uint8_t)chroma_sample(ref + (ptrdiff_t)y * p.stride_c + x, p.stride_c, xf, yf);
+    }
+    __syncthreads();
+    uint8_t *rec = p.out + j.out_rec;
+    if (j.skip) {
+        for (int e = tid; e < N * N; e += 256) rec[(size_t)(e / N) * j.rec_stride + e % N] = pred_lds[e];
+        return;
+    }
+    uint32_t sum, ssd;
+    chain_unit<N>(L, p.src[1 + j.plane] + (size_t)j.y * (p.width / 2) + j.x, p.width / 2, pred_lds, N, p.qpc,
+                  reinterpret_cast<int16_t *>(p.out + j.out_level), rec, nullptr, j.rec_stride, sum, ssd);
+    if (tid == 0) *reinterpret_cast<uint32_t *>(p.out + j.out_sum) = sum;
+}
+
+__global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p)
+{
+    __shared__ RoundLds L;
+    __shared__ uint8_t s_cpred[16 * 16];
+    const int b = blockIdx.x;
+    if (b < 2 * p.ncu) {
+        const LumaJob j = p.jobs[b >> 1];
+        switch (j.size) {
+        case 8: luma_job<8>(p, L, j, b & 1); break;
+        case 16: luma_job<16>(p, L, j, b & 1); break;
+        case 32: luma_job<32>(p, L, j, b & 1); break;
+        case 64: luma_job<64>(p, L, j, b & 1); break;
+        default: break;
         }
-        *reinterpret_cast<uchar4 *>(pix + unit_offset(j.unit_merge, n, x, y)) = s;
-        *reinterpret_cast<uchar4 *>(pix + unit_offset(j.unit_me, n, x, y)) = s;
-        *reinterpret_cast<uchar4 *>(pred + unit_offset(j.unit_merge, n, x, y)) = q;
+    } else if (b - 2 * p.ncu < p.nchroma) {
+        const ChromaJob j = p.cjobs[b - 2 * p.ncu];
+        switch (j.n) {
+        case 4: chroma_job<4>(p, L, j, s_cpred); break;
+        case 8: chroma_job<8>(p, L, j, s_cpred); break;
+        case 16: chroma_job<16>(p, L, j, s_cpred); break;
+        default: break;
+        }
     }
-}
-
-__global__ void __launch_bounds__(256) analysis_me_pred_kernel(const PrepareParams p)
-{
-    const LumaJob j = p.jobs[blockIdx.x];
-    const xmi_me_result r = p.me_res[blockIdx.x];
-    const int n = j.size, npx = n * n;
-    const int mvx = r.mvp_idx < 0 ? 0 : r.mv[0], mvy = r.mvp_idx < 0 ? 0 : r.mv[1];   // a refused request predicts from the zero vector
-    const uint8_t *pr = plane_block(p, j.x0, j.y0, mvx, mvy);
-    uint8_t *pred = p.c.pred[j.cls];
-    for (int i = threadIdx.x * 4; i < npx; i += 1024) {
-        const int y = i / n, x = i - y * n;
-        const uint8_t *b = pr + (size_t)y * p.stride + x;
-        *reinterpret_cast<uchar4 *>(pred + unit_offset(j.unit_me, n, x, y)) = make_uchar4(b[0], b[1], b[2], b[3]);
-    }
-}
-
-struct GatherParams {
-    const GatherJob *jobs;
-    const uint8_t *plane[2];
-    int stride;
-    uint8_t *dst;
-};
-
-__global__ void __launch_bounds__(64) analysis_gather_kernel(const GatherParams p)
-{
-    const GatherJob j = p.jobs[blockIdx.x];
-    const uint8_t *src = p.plane[j.plane] + (size_t)j.y * p.stride + j.x;
-    uint8_t *dst = p.dst + j.dst;
-    for (int i = threadIdx.x * 4; i < j.n * j.n; i += 256) {
-        const int y = i / j.n, x = i - y * j.n;
-        *reinterpret_cast<uchar4 *>(dst + i) = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.stride + x);
+    // completion: every wavefront waits until its own results have left for host memory, then the workgroup counts itself;
+    // the last one of the round tells the host
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(p.counter, 1u) + 1u;
+        if (done == p.target) {
+            __threadfence_system();
+            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
-// Offsets of one class of transform units inside the download area: sums, SSDs, levels, reconstruction, prediction.
-struct ClassLayout {
-    int n = 0, units = 0;
-    size_t sum = 0, ssd = 0, level = 0, rec = 0, pred = 0;
-    size_t place(size_t at, int n_, int units_, bool with_ssd)
-    {
-        n = n_, units = units_;
-        const size_t px = (size_t)units * n * n;
-        sum = at, at = align_up(at + 4 * (size_t)units);
-        ssd = at, at = with_ssd ? align_up(at + 4 * (size_t)units) : at;
-        level = at, at = align_up(at + 2 * px);
-        rec = at, at = align_up(at + px);
-        pred = at, at = align_up(at + px);
-        return at;
-    }
-};
-
 class GpuEvaluator : public Evaluator {
 public:
     int w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0;
     uint8_t *d_src[3] = {}, *d_ref[3] = {}, *d_planes = nullptr;
-    uint8_t *d_up = nullptr, *d_down = nullptr, *d_pix = nullptr, *d_qp = nullptr;   // d_qp: [luma qp x cap][chroma qp x cap][flags = 0 x cap]
-    uint8_t *h_up = nullptr, *h_down = nullptr;
-    size_t up_bytes = 0, down_bytes = 0, pix_bytes = 0, qp_cap = 0;
+    unsigned *d_counter = nullptr;
+    uint8_t *h_jobs = nullptr, *h_out = nullptr;       // pinned, mapped; the kernel reads / writes them in place
+    unsigned *h_flag = nullptr;
+    uint8_t *g_jobs = nullptr, *g_out = nullptr;       // the same buffers as the GPU addresses them
+    unsigned *g_flag = nullptr;
+    size_t jobs_bytes = 0, out_bytes = 0;
+    unsigned issued = 0, seq = 0;
     hipStream_t st = nullptr;
-    std::vector<uint8_t> untile_b;
-    std::vector<int16_t> untile_w;
-    int cur_qp = -1, cur_qpc = -1;
+    int cur_qp = 0, cur_qpc = 0;
     char err[256] = "";
 
     ~GpuEvaluator() override { release(); }
@@ -208,10 +346,11 @@ public:
             if (d_ref[i]) (void)hipFree(d_ref[i]);
             d_src[i] = d_ref[i] = nullptr;
         }
-        for (uint8_t **q : { &d_planes, &d_up, &d_down, &d_pix, &d_qp })
-            if (*q) (void)hipFree(*q), *q = nullptr;
-        if (h_up) (void)hipHostFree(h_up), h_up = nullptr;
-        if (h_down) (void)hipHostFree(h_down), h_down = nullptr;
+        if (d_planes) (void)hipFree(d_planes), d_planes = nullptr;
+        if (d_counter) (void)hipFree(d_counter), d_counter = nullptr;
+        if (h_jobs) (void)hipHostFree(h_jobs), h_jobs = nullptr;
+        if (h_out) (void)hipHostFree(h_out), h_out = nullptr;
+        if (h_flag) (void)hipHostFree(h_flag), h_flag = nullptr;
         if (st) (void)hipStreamDestroy(st), st = nullptr;
     }
 
@@ -220,16 +359,12 @@ public:
         w = width, h = height;
         stride = w + 2 * kPad, rows = h + 2 * kPad, stride_c = w / 2 + 2 * kPadC, rows_c = h / 2 + 2 * kPadC;
         max_cu = h / 64;                      // one CU request per CTU row and round
-        max_chroma = (h / 64) * 64;           // the CUs of one CTU per row: at most 64 of 8x8
+        max_chroma = (h / 64) * 64 * 2;       // per CTU at most 64 CUs of 8x8, two planes
         const size_t plane = (size_t)stride * rows, plane_c = (size_t)stride_c * rows_c;
-        // worst cases per round: every CU a 64x64 (8 units of 32x32 each with both candidates), every chroma CU a 4x4 pair
-        const size_t luma_px = (size_t)max_cu * 2 * 4096, chroma_px = (size_t)max_chroma * 2 * 64 * 4;
-        up_bytes = align_up(sizeof(LumaJob) * max_cu) + align_up(sizeof(xmi_me_request) * max_cu) + align_up(sizeof(GatherJob) * max_chroma * 2 * 4) +
-                   2 * align_up(sizeof(xmi_inter_pred_request) * max_chroma * 4) + 4096;
-        down_bytes = align_up(sizeof(LumaOut) * max_cu) + align_up(sizeof(xmi_me_result) * max_cu) + 3 * 5 * 256 + 4 * luma_px + 8 * (size_t)max_cu * 8 +
-                     3 * 5 * 256 + 4 * chroma_px + 8 * (size_t)max_chroma * 8 + 65536;
-        pix_bytes = align_up(3 * luma_px) + align_up(3 * chroma_px) + 4096;
-        qp_cap = align_up(std::max<size_t>((size_t)max_cu * 8, (size_t)max_chroma * 2 * 4) + 64);
+        jobs_bytes = align_up(sizeof(LumaJob) * max_cu) + align_up(sizeof(ChromaJob) * max_chroma);
+        // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
+        // sums and four blocks, each rounded up to the 256-byte grid of the area
+        out_bytes = (size_t)max_cu * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)(h / 64) * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[0]), (size_t)w * h));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[1]), (size_t)w * h / 4));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[2]), (size_t)w * h / 4));
@@ -237,18 +372,20 @@ public:
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_ref[1]), plane_c));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_ref[2]), plane_c));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_planes), 16 * plane));
-        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_up), up_bytes));
-        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_down), down_bytes));
-        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_pix), pix_bytes));
-        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_qp), 3 * qp_cap));
-        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_up), up_bytes, hipHostMallocDefault));
-        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_down), down_bytes, hipHostMallocDefault));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_counter), 256));
+        const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_jobs), jobs_bytes, flags));
+        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_out), out_bytes, flags));
+        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flag), 256, flags));
+        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_jobs), h_jobs, 0));
+        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_out), h_out, 0));
+        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_flag), h_flag, 0));
+        std::memset(h_out, 0, out_bytes);
+        *h_flag = 0;
         XMI_HIP(hipStreamCreate(&st));
         XMI_HIP(hipMemsetAsync(d_planes, 0, 16 * plane, st));
-        XMI_HIP(hipMemsetAsync(d_pix, 0, pix_bytes, st));
-        XMI_HIP(hipMemsetAsync(d_down, 0, down_bytes, st));
-        untile_b.resize((size_t)max_cu * 3 * 4096);
-        untile_w.resize((size_t)max_cu * 2 * 4096);
+        XMI_HIP(hipMemsetAsync(d_counter, 0, 256, st));
+        XMI_HIP(hipStreamSynchronize(st));
         return XMI_OK;
     }
 
@@ -263,12 +400,7 @@ public:
         XMI_HIP(hipMemcpyAsync(d_ref[2], ref[2], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
         int rc = xmi_interp_planes_dev(d_ref[0], stride, rows, stride, d_planes, st);
         if (rc != XMI_OK) return rc;
-        if (qp != cur_qp || qpc != cur_qpc) {
-            XMI_HIP(hipMemsetAsync(d_qp, qp, qp_cap, st));
-            XMI_HIP(hipMemsetAsync(d_qp + qp_cap, qpc, qp_cap, st));
-            XMI_HIP(hipMemsetAsync(d_qp + 2 * qp_cap, 0, qp_cap, st));
-            cur_qp = qp, cur_qpc = qpc;
-        }
+        cur_qp = qp, cur_qpc = qpc;
         XMI_HIP(hipStreamSynchronize(st));
         return XMI_OK;
     }
@@ -281,235 +413,134 @@ public:
     }
 
 private:
+    struct ChromaPlace {
+        size_t sum, rec[2], level[2];
+    };
+    std::vector<ChromaPlace> place;
+
     int run(CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
     {
-        XMI_ARG(ncu <= max_cu && nch <= max_chroma, "analysis: %d CU / %d chroma requests exceed the round capacity %d / %d", ncu, nch, max_cu, max_chroma);
-        // ---- upload area ----
-        size_t up = 0;
-        LumaJob *jobs = reinterpret_cast<LumaJob *>(h_up + up);
-        const size_t off_jobs = up;
-        up = align_up(up + sizeof(LumaJob) * ncu);
-        xmi_me_request *me_req = reinterpret_cast<xmi_me_request *>(h_up + up);
-        const size_t off_me_req = up;
-        up = align_up(up + sizeof(xmi_me_request) * ncu);
-
-        // luma: transform classes; both candidates of a CU get the same relative unit index in the two halves of a class
-        int units_in[3] = { 0, 0, 0 };
+        XMI_ARG(ncu <= max_cu, "analysis: %d CU requests exceed the round capacity %d", ncu, max_cu);
+        LumaJob *jobs = reinterpret_cast<LumaJob *>(h_jobs);
+        ChromaJob *cjobs = reinterpret_cast<ChromaJob *>(h_jobs + align_up(sizeof(LumaJob) * max_cu));
+        size_t out = 0;
         for (int i = 0; i < ncu; i++) {
             const CuEval &q = *cu[i];
             LumaJob &j = jobs[i];
             XMI_ARG(q.size == 8 || q.size == 16 || q.size == 32 || q.size == 64, "analysis: CU size %d", q.size);
-            XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 + q.size <= w && q.y0 + q.size <= h && q.n_merge >= 0 && q.n_merge <= 5, "analysis: CU outside the picture");
+            XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 8 == 0 && q.y0 % 8 == 0 && q.x0 + q.size <= w && q.y0 + q.size <= h && q.n_merge >= 0 && q.n_merge <= 5,
+                    "analysis: CU (%d,%d) size %d outside the picture", q.x0, q.y0, q.size);
             j.x0 = q.x0, j.y0 = q.y0, j.size = q.size, j.n_merge = q.n_merge;
             for (int k = 0; k < 5; k++) {
                 j.merge_mv[k][0] = k < q.n_merge ? q.merge_mv[k].x : 0, j.merge_mv[k][1] = k < q.n_merge ? q.merge_mv[k].y : 0;
-                // a candidate the clip of the reference would change is left out by the caller; one that would leave the
-                // padded planes can only come from a caller's mistake and is left out here
+                // a candidate the reference's clip would change is left out by the caller; one that would leave the padded
+                // planes can only be a caller's mistake and is left out here
                 const bool inside = std::abs(j.merge_mv[k][0] >> 2) <= kPad - 8 && std::abs(j.merge_mv[k][1] >> 2) <= kPad - 8;
                 j.merge_ok[k] = k < q.n_merge && q.merge_ok[k] && inside;
             }
-            j.cls = q.size == 8 ? 0 : q.size == 16 ? 1 : 2;
-            j.units = q.size == 64 ? 4 : 1;
-            j.reserved = 0;
-            j.unit_merge = units_in[j.cls];
-            units_in[j.cls] += j.units;
-            xmi_me_request &r = me_req[i];
-            r.x0 = q.x0, r.y0 = q.y0, r.size = q.size;
-            r.mvp[0][0] = q.amvp[0].x, r.mvp[0][1] = q.amvp[0].y, r.mvp[1][0] = q.amvp[1].x, r.mvp[1][1] = q.amvp[1].y;
-            r.zero_mv_tested = 0;
-            r.mv_min_ipel[0] = q.mv_min_ipel.x, r.mv_min_ipel[1] = q.mv_min_ipel.y;
-            r.mv_max_ipel[0] = q.mv_max_ipel.x, r.mv_max_ipel[1] = q.mv_max_ipel.y;
-            r.sqrt_lambda = (uint32_t)std::sqrt(q.lambda);
+            j.amvp[0][0] = q.amvp[0].x, j.amvp[0][1] = q.amvp[0].y, j.amvp[1][0] = q.amvp[1].x, j.amvp[1][1] = q.amvp[1].y;
+            j.mv_min_ipel[0] = q.mv_min_ipel.x, j.mv_min_ipel[1] = q.mv_min_ipel.y;
+            j.mv_max_ipel[0] = q.mv_max_ipel.x, j.mv_max_ipel[1] = q.mv_max_ipel.y;
+            j.sqrt_lambda = (uint32_t)std::sqrt(q.lambda);
+            // what the batch kernel checks per request (request_in_bounds, me_search.hip): every block the search can read lies in the planes
+            xmi_me_request rq = {};
+            rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
+            rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1], rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
+            XMI_ARG(xmi::me_request_reach(rq) + 8 <= kPad, "analysis: the search of the CU at (%d,%d) could leave the padded reference", q.x0, q.y0);
+            const size_t px = (size_t)q.size * q.size;
+            j.out_head = (uint32_t)out, out = align_up(out + sizeof(LumaHead));
+            j.out_pred_merge = (uint32_t)out, out = align_up(out + px);
+            j.out_rec_merge = (uint32_t)out, out = align_up(out + px);
+            j.out_rec_me = (uint32_t)out, out = align_up(out + px);
+            j.out_level_merge = (uint32_t)out, out = align_up(out + 2 * px);
+            j.out_level_me = (uint32_t)out, out = align_up(out + 2 * px);
         }
-        for (int i = 0; i < ncu; i++) jobs[i].unit_me = units_in[jobs[i].cls] + jobs[i].unit_merge;
-
-        // chroma: one unit list per transform class (4, 8, 16), U units first, then V units at the same relative index
-        int cunits_in[3] = { 0, 0, 0 };
-        struct ChromaPlace {
-            int cls, first, units;
-        };
-        std::vector<ChromaPlace> cplace(nch);
+        int nc = 0;
+        place.resize(nch);
         for (int i = 0; i < nch; i++) {
             const ChromaEval &c = *ch[i];
             XMI_ARG(c.size == 8 || c.size == 16 || c.size == 32 || c.size == 64, "analysis: chroma CU size %d", c.size);
             XMI_ARG(c.x0 >= 0 && c.y0 >= 0 && c.x0 + c.size <= w && c.y0 + c.size <= h, "analysis: chroma CU outside the picture");
             XMI_ARG(std::abs(c.mv.x >> 2) <= kPad - 8 && std::abs(c.mv.y >> 2) <= kPad - 8, "analysis: chroma vector (%d,%d) leaves the padded reference", c.mv.x, c.mv.y);
-            const int cls = c.size == 8 ? 0 : c.size == 16 ? 1 : 2, units = c.size == 64 ? 4 : 1;
-            cplace[i] = { cls, cunits_in[cls], units };
-            cunits_in[cls] += units;
+            const int n = c.size / 2, units = c.size == 64 ? 4 : 1, un = units == 4 ? 16 : n;
+            XMI_ARG(nc + 2 * units <= max_chroma, "analysis: chroma units exceed the round capacity %d", max_chroma);
+            ChromaPlace &pl = place[i];
+            pl.sum = out, out = align_up(out + 4 * 8);
+            for (int k = 0; k < 2; k++) pl.rec[k] = out, out = align_up(out + (size_t)n * n);
+            for (int k = 0; k < 2; k++) pl.level[k] = out, out = align_up(out + 2 * (size_t)n * n);
+            for (int k = 0; k < 2; k++)
+                for (int u = 0; u < units; u++) {
+                    const int ox = units == 4 ? (u & 1) * 16 : 0, oy = units == 4 ? (u >> 1) * 16 : 0;
+                    ChromaJob &j = cjobs[nc++];
+                    j.plane = k, j.x = c.x0 / 2 + ox, j.y = c.y0 / 2 + oy, j.n = un;
+                    j.mv[0] = c.mv.x, j.mv[1] = c.mv.y;
+                    j.skip = c.skip;
+                    j.out_sum = (uint32_t)(pl.sum + 4 * (size_t)(k * 4 + u));
+                    j.out_rec = (uint32_t)(pl.rec[k] + (size_t)oy * n + ox);
+                    j.out_level = (uint32_t)(pl.level[k] + 2 * ((size_t)oy * n + ox));
+                    j.rec_stride = n;
+                }
         }
-        const int cn[3] = { 4, 8, 16 }, ln[3] = { 8, 16, 32 };
-        int ctotal = 0;
-        for (int c = 0; c < 3; c++) ctotal += cunits_in[c];
-        GatherJob *gjobs = reinterpret_cast<GatherJob *>(h_up + up);
-        const size_t off_gjobs = up;
-        up = align_up(up + sizeof(GatherJob) * 2 * ctotal);
-        xmi_inter_pred_request *preq[2];
-        size_t off_preq[2];
-        for (int pl = 0; pl < 2; pl++) {
-            preq[pl] = reinterpret_cast<xmi_inter_pred_request *>(h_up + up);
-            off_preq[pl] = up;
-            up = align_up(up + sizeof(xmi_inter_pred_request) * ctotal);
-        }
-        XMI_ARG(up <= up_bytes, "analysis: upload area too small");
+        XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
 
-        // ---- device-only packed sources and the download area ----
-        size_t pix_luma[3], pix_chroma[3], px = 0;
-        for (int c = 0; c < 3; c++) pix_luma[c] = px, px = align_up(px + (size_t)2 * units_in[c] * ln[c] * ln[c]);
-        for (int c = 0; c < 3; c++) pix_chroma[c] = px, px = align_up(px + (size_t)2 * cunits_in[c] * cn[c] * cn[c]);
-        XMI_ARG(px <= pix_bytes, "analysis: packed-source area too small");
-        size_t down = 0;
-        const size_t off_out = down;
-        down = align_up(down + sizeof(LumaOut) * ncu);
-        const size_t off_me_res = down;
-        down = align_up(down + sizeof(xmi_me_result) * ncu);
-        ClassLayout L[3], Cc[3];
-        for (int c = 0; c < 3; c++) down = L[c].place(down, ln[c], 2 * units_in[c], true);
-        for (int c = 0; c < 3; c++) down = Cc[c].place(down, cn[c], 2 * cunits_in[c], false);
-        XMI_ARG(down <= down_bytes, "analysis: download area too small");
-
-        // chroma job tables
-        {
-            int g = 0, r = 0;
-            for (int i = 0; i < nch; i++) {
-                const ChromaEval &c = *ch[i];
-                const ChromaPlace &pc = cplace[i];
-                const int n = cn[pc.cls];
-                for (int u = 0; u < pc.units; u++) {
-                    const int ox = pc.units == 4 ? (u & 1) * 32 : 0, oy = pc.units == 4 ? (u >> 1) * 32 : 0;   // luma offsets of the unit
-                    for (int pl = 0; pl < 2; pl++) {
-                        const uint32_t unit = (uint32_t)(pl * cunits_in[pc.cls] + pc.first + u);
-                        gjobs[g++] = { pl, (c.x0 + ox) / 2, (c.y0 + oy) / 2, n, (uint32_t)(pix_chroma[pc.cls] + (size_t)unit * n * n) };
-                        xmi_inter_pred_request &q = preq[pl][r];
-                        q.x0 = c.x0 + ox, q.y0 = c.y0 + oy, q.size = pc.units == 4 ? 32 : c.size;
-                        q.mv[0] = c.mv.x, q.mv[1] = c.mv.y;
-                        q.out_y = 0;
-                        q.out_c = (uint32_t)(Cc[pc.cls].pred + (size_t)unit * n * n);
-                    }
-                    r++;
+        RoundParams p;
+        p.jobs = reinterpret_cast<const LumaJob *>(g_jobs);
+        p.cjobs = reinterpret_cast<const ChromaJob *>(g_jobs + align_up(sizeof(LumaJob) * max_cu));
+        p.ncu = ncu, p.nchroma = nc;
+        for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
+        p.planes = d_planes;
+        p.ref_c[0] = d_ref[1] + (size_t)kPadC * stride_c + kPadC, p.ref_c[1] = d_ref[2] + (size_t)kPadC * stride_c + kPadC;
+        p.width = w, p.stride = stride, p.rows = rows, p.stride_c = stride_c;
+        p.qp = cur_qp, p.qpc = cur_qpc;
+        p.out = g_out;
+        const unsigned groups = (unsigned)(2 * ncu + nc);
+        issued += groups;
+        seq++;
+        p.counter = d_counter, p.target = issued, p.flag = g_flag, p.seq = seq;
+        std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
+        hipLaunchKernelGGL(analysis_round_kernel, dim3(groups), dim3(256), 0, st, p);
+        XMI_HIP(hipGetLastError());
+        // spin on the completion word; look at the stream now and then so that a failed launch cannot hang the host
+        volatile unsigned *flag = h_flag;
+        for (unsigned spins = 0; *flag != seq; spins++) {
+            if ((spins & 0xfffff) == 0xfffff) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {
+                    if (*flag == seq) break;
+                    xmi::set_error("analysis: the round kernel finished without reporting completion");
+                    return XMI_ERR_HIP;
+                }
+                if (q != hipErrorNotReady) {
+                    xmi::set_error("analysis: round kernel failed: %s", hipGetErrorString(q));
+                    return XMI_ERR_HIP;
                 }
             }
         }
+        std::atomic_thread_fence(std::memory_order_acquire);
 
-        XMI_HIP(hipMemcpyAsync(d_up, h_up, up, hipMemcpyHostToDevice, st));
-        int rc;
-        if (ncu) {
-            PrepareParams pp;
-            pp.jobs = reinterpret_cast<const LumaJob *>(d_up + off_jobs);
-            pp.out = reinterpret_cast<LumaOut *>(d_down + off_out);
-            pp.me_req = reinterpret_cast<xmi_me_request *>(d_up + off_me_req);
-            pp.me_res = reinterpret_cast<const xmi_me_result *>(d_down + off_me_res);
-            pp.src = d_src[0], pp.planes = d_planes, pp.width = w, pp.stride = stride, pp.rows = rows;
-            for (int c = 0; c < 3; c++) pp.c.pix[c] = d_pix + pix_luma[c], pp.c.pred[c] = d_down + L[c].pred;
-            hipLaunchKernelGGL(analysis_prepare_kernel, dim3(ncu), dim3(256), 0, st, pp);
-            XMI_HIP(hipGetLastError());
-            rc = xmi_me_search_batch_dev(d_src[0], w, d_planes, stride, rows, kPad, pp.me_req, ncu, kMeRange,
-                                         reinterpret_cast<xmi_me_result *>(d_down + off_me_res), st);
-            if (rc != XMI_OK) return rc;
-            hipLaunchKernelGGL(analysis_me_pred_kernel, dim3(ncu), dim3(256), 0, st, pp);
-            XMI_HIP(hipGetLastError());
-            for (int c = 0; c < 3; c++) {
-                if (!L[c].units) continue;
-                rc = xmi_tu_chain_batch_dev(ln[c], L[c].units, d_pix + pix_luma[c], d_down + L[c].pred, d_qp, d_qp + 2 * qp_cap,
-                                            reinterpret_cast<int16_t *>(d_down + L[c].level), d_down + L[c].rec,
-                                            reinterpret_cast<uint32_t *>(d_down + L[c].sum), st);
-                if (rc != XMI_OK) return rc;
-                rc = xmi_block_metric_batch_dev(XMI_METRIC_SSD, ln[c], L[c].units, d_pix + pix_luma[c], d_down + L[c].rec,
-                                                reinterpret_cast<uint32_t *>(d_down + L[c].ssd), st);
-                if (rc != XMI_OK) return rc;
-            }
-        }
-        if (nch) {
-            GatherParams gp = { reinterpret_cast<const GatherJob *>(d_up + off_gjobs), { d_src[1], d_src[2] }, w / 2, d_pix };
-            hipLaunchKernelGGL(analysis_gather_kernel, dim3(2 * ctotal), dim3(64), 0, st, gp);
-            XMI_HIP(hipGetLastError());
-            for (int pl = 0; pl < 2; pl++) {    // the chroma plane goes through the request's "U" slot both times
-                rc = xmi_pred_inter_batch_dev(nullptr, stride, d_ref[1 + pl] + (size_t)kPadC * stride_c + kPadC, nullptr, stride_c,
-                                              reinterpret_cast<const xmi_inter_pred_request *>(d_up + off_preq[pl]), ctotal, nullptr, d_down, nullptr, st);
-                if (rc != XMI_OK) return rc;
-            }
-            for (int c = 0; c < 3; c++) {
-                if (!Cc[c].units) continue;
-                rc = xmi_tu_chain_batch_dev(cn[c], Cc[c].units, d_pix + pix_chroma[c], d_down + Cc[c].pred, d_qp + qp_cap, d_qp + 2 * qp_cap,
-                                            reinterpret_cast<int16_t *>(d_down + Cc[c].level), d_down + Cc[c].rec,
-                                            reinterpret_cast<uint32_t *>(d_down + Cc[c].sum), st);
-                if (rc != XMI_OK) return rc;
-            }
-        }
-        XMI_HIP(hipMemcpyAsync(h_down, d_down, down, hipMemcpyDeviceToHost, st));
-        XMI_HIP(hipStreamSynchronize(st));
-
-        // ---- hand the results out ----
-        const LumaOut *lo = reinterpret_cast<const LumaOut *>(h_down + off_out);
-        const xmi_me_result *mr = reinterpret_cast<const xmi_me_result *>(h_down + off_me_res);
-        uint8_t *ub = untile_b.data();
-        int16_t *uw = untile_w.data();
         for (int i = 0; i < ncu; i++) {
             CuEval &q = *cu[i];
             const LumaJob &j = jobs[i];
-            const ClassLayout &l = L[j.cls];
-            const int n = ln[j.cls];
-            const uint32_t *sum = reinterpret_cast<const uint32_t *>(h_down + l.sum), *ssd = reinterpret_cast<const uint32_t *>(h_down + l.ssd);
-            const int16_t *lev = reinterpret_cast<const int16_t *>(h_down + l.level);
-            const uint8_t *rec = h_down + l.rec, *pred = h_down + l.pred;
-            XMI_ARG(mr[i].mvp_idx >= 0, "analysis: the motion search refused the request of the CU at (%d,%d) size %d", q.x0, q.y0, q.size);
-            q.best_merge = lo[i].best_merge, q.ssd_skip = lo[i].ssd_skip;
-            q.mv_me = { mr[i].mv[0], mr[i].mv[1] };
-            q.ssd_merge = q.ssd_me = 0;
-            for (int u = 0; u < 4; u++) q.sum_merge[u] = q.sum_me[u] = 0;
-            for (int u = 0; u < j.units; u++) {
-                q.sum_merge[u] = sum[j.unit_merge + u], q.sum_me[u] = sum[j.unit_me + u];
-                q.ssd_merge += ssd[j.unit_merge + u], q.ssd_me += ssd[j.unit_me + u];
-            }
-            const size_t um = (size_t)j.unit_merge * n * n, ue = (size_t)j.unit_me * n * n;
-            if (j.units == 1) {
-                q.pred_merge = pred + um, q.rec_merge = rec + um, q.level_merge = lev + um;
-                q.rec_me = rec + ue, q.level_me = lev + ue;
-            } else {      // four 32x32 units back to rows of 64
-                auto rows64 = [](auto *dst, const auto *src) {
-                    for (int u = 0; u < 4; u++)
-                        for (int y = 0; y < 32; y++) std::memcpy(dst + ((u >> 1) * 32 + y) * 64 + (u & 1) * 32, src + u * 1024 + y * 32, 32 * sizeof(*dst));
-                };
-                rows64(ub, pred + um), rows64(ub + 4096, rec + um), rows64(ub + 8192, rec + ue);
-                rows64(uw, lev + um), rows64(uw + 4096, lev + ue);
-                q.pred_merge = ub, q.rec_merge = ub + 4096, q.rec_me = ub + 8192, q.level_merge = uw, q.level_me = uw + 4096;
-                ub += 3 * 4096, uw += 2 * 4096;
-            }
+            const LumaHead &hd = *reinterpret_cast<const LumaHead *>(h_out + j.out_head);
+            q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip, q.ssd_merge = hd.ssd_merge;
+            q.mv_me = { hd.mv[0], hd.mv[1] };
+            q.ssd_me = hd.ssd_me;
+            for (int u = 0; u < 4; u++) q.sum_merge[u] = hd.sum_merge[u], q.sum_me[u] = hd.sum_me[u];
+            q.pred_merge = h_out + j.out_pred_merge, q.rec_merge = h_out + j.out_rec_merge, q.rec_me = h_out + j.out_rec_me;
+            q.level_merge = reinterpret_cast<const int16_t *>(h_out + j.out_level_merge);
+            q.level_me = reinterpret_cast<const int16_t *>(h_out + j.out_level_me);
         }
-        size_t need_b = 0, need_w = 0;
-        for (int i = 0; i < nch; i++)
-            if (cplace[i].units == 4) need_b += 2 * 1024, need_w += 2 * 1024;
-        chroma_b.resize(need_b), chroma_w.resize(need_w);
-        uint8_t *cb = chroma_b.data();
-        int16_t *cw = chroma_w.data();
         for (int i = 0; i < nch; i++) {
             ChromaEval &c = *ch[i];
-            const ChromaPlace &pc = cplace[i];
-            const ClassLayout &l = Cc[pc.cls];
-            const int n = cn[pc.cls], half = cunits_in[pc.cls];
-            const uint32_t *sum = reinterpret_cast<const uint32_t *>(h_down + l.sum);
-            const int16_t *lev = reinterpret_cast<const int16_t *>(h_down + l.level);
-            const uint8_t *rec = h_down + (c.skip ? l.pred : l.rec);      // a skipped CU keeps its prediction
-            for (int u = 0; u < 4; u++) c.sum_u[u] = c.sum_v[u] = 0;
-            for (int u = 0; u < pc.units; u++) c.sum_u[u] = c.skip ? 0 : sum[pc.first + u], c.sum_v[u] = c.skip ? 0 : sum[half + pc.first + u];
-            const size_t uu = (size_t)pc.first * n * n, uv = (size_t)(half + pc.first) * n * n;
-            if (pc.units == 1) {
-                c.rec_u = rec + uu, c.rec_v = rec + uv, c.level_u = lev + uu, c.level_v = lev + uv;
-            } else {      // four 16x16 units back to rows of 32
-                auto rows32 = [](auto *dst, const auto *src) {
-                    for (int u = 0; u < 4; u++)
-                        for (int y = 0; y < 16; y++) std::memcpy(dst + ((u >> 1) * 16 + y) * 32 + (u & 1) * 16, src + u * 256 + y * 16, 16 * sizeof(*dst));
-                };
-                rows32(cb, rec + uu), rows32(cb + 1024, rec + uv), rows32(cw, lev + uu), rows32(cw + 1024, lev + uv);
-                c.rec_u = cb, c.rec_v = cb + 1024, c.level_u = cw, c.level_v = cw + 1024;
-                cb += 2048, cw += 2048;
-            }
+            const ChromaPlace &pl = place[i];
+            const uint32_t *sum = reinterpret_cast<const uint32_t *>(h_out + pl.sum);
+            const int units = c.size == 64 ? 4 : 1;
+            for (int u = 0; u < 4; u++) c.sum_u[u] = (!c.skip && u < units) ? sum[u] : 0, c.sum_v[u] = (!c.skip && u < units) ? sum[4 + u] : 0;
+            c.rec_u = h_out + pl.rec[0], c.rec_v = h_out + pl.rec[1];
+            c.level_u = reinterpret_cast<const int16_t *>(h_out + pl.level[0]), c.level_v = reinterpret_cast<const int16_t *>(h_out + pl.level[1]);
         }
         return XMI_OK;
     }
-
-    std::vector<uint8_t> chroma_b;
-    std::vector<int16_t> chroma_w;
 };
 
 }  // namespace
