@@ -374,6 +374,10 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
  * motion search, prediction, transform chains, distortions - is batched over the rows that are ready and runs on the GPU.
  *
  * xmi_analysis_create: width, height = coded size (multiples of 64). NULL on failure (xmi_last_error()).
+ * xmi_analysis_configure: lanes (1..8) = groups the CTU rows are dealt to (row y -> lane y % lanes). Each lane batches the
+ *   requests of its rows and makes its own round trips to the GPU, on a stream of its own, so the host work of one lane
+ *   overlaps the GPU time of another. Results do not depend on the number of lanes. Not while a picture is in flight.
+ *   (The reference has no counterpart: its -t option sets the number of row threads, src/encode.cpp:5800-5860.)
  * xmi_analysis_state : the state the reference carries from picture to picture and never resets - per CTU and depth the
  *   FAST_MD cost statistics (dSumOfRdCosts, nRdCounts, dAverageRdCosts, inc/x265.h:379-381: (height/64) x (width/64) x 5
  *   entries each) and per CTU row the fractional bits of its rate counter (rdoParam[y].fracBits, inc/x265.h:359). set != 0
@@ -388,6 +392,7 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
 typedef struct xmi_analysis xmi_analysis;
 xmi_analysis *xmi_analysis_create(int width, int height);
 void xmi_analysis_destroy(xmi_analysis *a);
+int xmi_analysis_configure(xmi_analysis *a, int lanes);
 int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits);
 int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, const uint8_t *ref_y,
                            const uint8_t *ref_u, const uint8_t *ref_v, int pad, int qp, uint16_t *info0, uint8_t *info1, int16_t *mv,

@@ -3,6 +3,7 @@
 // decision logic can be held against traces of the reference's encoder without a GPU (tests/test_analysis_cpu.py). Built
 // into oracle/libx265_analysis_check.so by `make -C oracle analysis_check`. Nothing in the product links or loads this.
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../x265_amd/csrc/host/analysis_core.h"
@@ -21,11 +22,15 @@ struct Pictures {
 class CpuEvaluator : public Evaluator {
 public:
     Pictures p;
-    std::vector<uint8_t> bytes;
-    std::vector<int16_t> words;
+    std::mutex mu;
+    std::vector<uint8_t> lane_bytes[8];
+    std::vector<int16_t> lane_words[8];
 
-    int evaluate(CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
+    int evaluate(int lane, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
     {
+        std::lock_guard<std::mutex> lk(mu);     // the oracle's transform chain keeps a static work buffer
+        std::vector<uint8_t> &bytes = lane_bytes[lane & 7];
+        std::vector<int16_t> &words = lane_words[lane & 7];
         size_t nb = 0, nw = 0;
         for (int i = 0; i < ncu; i++) nb += 3 * (size_t)cu[i]->size * cu[i]->size, nw += 2 * (size_t)cu[i]->size * cu[i]->size;
         for (int i = 0; i < nch; i++) nb += (size_t)ch[i]->size * ch[i]->size / 2, nw += (size_t)ch[i]->size * ch[i]->size / 2;
@@ -137,6 +142,12 @@ struct Handle {
 extern "C" {
 
 void *orc_analysis_create(int width, int height) { return new Handle(width, height); }
+int orc_analysis_configure(void *h, int lanes)
+{
+    if (lanes < 1 || lanes > 8) return -1;
+    static_cast<Handle *>(h)->an.lanes = lanes;
+    return 0;
+}
 void orc_analysis_destroy(void *h) { delete static_cast<Handle *>(h); }
 
 // set != 0: load the carried state; else read it back. Arrays: rows * cols * 5 (sum, count, avg), rows (frac).

@@ -108,6 +108,12 @@ def test_recorded_pictures_are_reproduced(lib, tag):
     check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h), tag)
 
 
+@pytest.mark.parametrize("lanes,tag", [(2, "416x240_q32_p2"), (3, "416x240_q22_p1"), (4, "416x240_q32_p7")])
+def test_row_lanes_do_not_change_the_result(lib, lanes, tag):
+    """rows dealt to several lanes, each with its own round trips to the evaluator: same picture, more calls"""
+    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes), tag)
+
+
 @needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")
 @pytest.mark.parametrize("w,h,frames,qp,seed", [(416, 240, 6, 37, 1234), (416, 240, 4, 27, 1234)])
 def test_fresh_trace_with_carried_statistics(lib, tmp_path, w, h, frames, qp, seed):

@@ -26,12 +26,17 @@ def test_recorded_pictures_are_reproduced(L, tag):
     assert out["counters"][0] > 0
 
 
+@pytest.mark.parametrize("lanes,tag", [(1, "416x240_q32_p2"), (2, "416x240_q32_p2"), (3, "416x240_q22_p1"), (4, "416x240_q32_p7")])
+def test_row_lanes_do_not_change_the_result(L, lanes, tag):
+    check_fixture_picture(lambda w, h: T.Runner(L, "xmi_analysis_", w, h, lanes), tag)
+
+
 @needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")
-@pytest.mark.parametrize("w,h,frames,qp,seed", [(416, 240, 8, 32, 1234), (416, 240, 4, 22, 1234), (1920, 1080, 3, 32, 7), (1920, 1080, 3, 27, 7),
-                                                (1920, 1080, 2, 22, 7), (1920, 1080, 2, 37, 7)])
-def test_fresh_trace_with_carried_statistics(L, tmp_path, w, h, frames, qp, seed):
+@pytest.mark.parametrize("w,h,frames,qp,seed,lanes", [(416, 240, 8, 32, 1234, None), (416, 240, 4, 22, 1234, 2), (1920, 1080, 3, 32, 7, None),
+                                                      (1920, 1080, 3, 27, 7, 3), (1920, 1080, 2, 22, 7, 1), (1920, 1080, 2, 37, 7, 4)])
+def test_fresh_trace_with_carried_statistics(L, tmp_path, w, h, frames, qp, seed, lanes):
     pics, _ = T.record_trace(str(tmp_path), w, h, frames, qp, seed)
-    r = T.Runner(L, "xmi_analysis_", pics[0]["w"], pics[0]["h"])
+    r = T.Runner(L, "xmi_analysis_", pics[0]["w"], pics[0]["h"], lanes)
     try:
         r.set_state(pics[0], pics[1])
         for k in range(1, len(pics)):
@@ -52,3 +57,10 @@ def test_bad_arguments_are_refused(L):
     L.xmi_analysis_create.argtypes = [C.c_int, C.c_int]
     assert not L.xmi_analysis_create(416, 240)
     assert b"multiple of 64" in L.xmi_last_error()
+    a = L.xmi_analysis_create(128, 128)
+    assert a
+    L.xmi_analysis_configure.argtypes = [C.c_void_p, C.c_int]
+    assert L.xmi_analysis_configure(a, 0) != 0 and L.xmi_analysis_configure(a, 9) != 0
+    assert L.xmi_analysis_configure(a, 2) == 0
+    L.xmi_analysis_destroy.argtypes = [C.c_void_p]
+    L.xmi_analysis_destroy(a)

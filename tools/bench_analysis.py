@@ -25,14 +25,55 @@ def synth(w, h, t, seed):
     return y, u, v
 
 
-def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lib=None):
+def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=None, lib=None):
+    """`segments` independent GOP segments analysed at the same time on one GPU (one handle, one host thread each; the C
+    call releases the interpreter lock): aggregate P pictures per second."""
+    import threading
+    from x265_amd import capi
+    from tests import ctu_trace as T
+    L = lib or capi.load()
+    capi.check(L.xmi_init(0))
+    w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
+    clips = [[synth(w, h, t, 7 + s) for t in range(pictures + 1)] for s in range(segments)]
+    refs = [[tuple(np.pad(p, 80 if i == 0 else 40, mode="edge") for i, p in enumerate(f)) for f in clip] for clip in clips]
+    runners = [T.Runner(L, "xmi_analysis_", w, h, lanes) for _ in range(segments)]
+    errs = []
+
+    def work(s, lo, hi):
+        try:
+            for t in range(lo, hi):
+                pic = {"w": w, "h": h, "qp": qp, "pad": 80, "rows": h // 64, "cols": w // 64, "src": clips[s][t], "ref": refs[s][t - 1]}
+                runners[s].run(pic)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    def phase(lo, hi):
+        th = [threading.Thread(target=work, args=(s, lo, hi)) for s in range(segments)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    phase(1, 2)                                   # warm-up picture per segment
+    sec = phase(2, pictures + 1)
+    for r in runners:
+        r.close()
+    if errs:
+        return {"error": errs[0]}
+    return {"segments": segments, "lanes": lanes, "analysis_fps": round(segments * (pictures - 1) / sec, 3), "qp": qp,
+            "what": f"{segments} GOP segments of {width}x{height} analysed concurrently on one GPU, aggregate P pictures per second"}
+
+
+def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, lib=None):
     from x265_amd import capi
     from tests import ctu_trace as T
     L = lib or capi.load()
     capi.check(L.xmi_init(0))
     w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     frames = [synth(w, h, t, seed) for t in range(pictures + 1)]
-    r = T.Runner(L, "xmi_analysis_", w, h)
+    r = T.Runner(L, "xmi_analysis_", w, h, lanes)
     times, rounds, cus = [], [], []
     try:
         for t in range(1, pictures + 1):
@@ -47,7 +88,7 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lib=None):
         r.close()
     steady = times[1:] if len(times) > 1 else times
     return {"analysis_fps": round(len(steady) / sum(steady), 3), "ms_per_picture": [round(x * 1e3, 2) for x in times], "round_trips": rounds,
-            "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp,
+            "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp, "lanes": lanes,
             "what": f"{width}x{height} synthetic P pictures, decision + reconstruction of every CTU; includes the host copies of the call "
                     "(planes up, result arrays down)"}
 
@@ -58,5 +99,10 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--qp", type=int, default=32)
     ap.add_argument("--pictures", type=int, default=6)
+    ap.add_argument("--segments", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=None)
     a = ap.parse_args()
-    print(json.dumps(run(a.width, a.height, a.qp, a.pictures)))
+    if a.segments > 1:
+        print(json.dumps(run_segments(a.width, a.height, a.qp, a.pictures, a.segments, a.lanes)))
+    else:
+        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes)))

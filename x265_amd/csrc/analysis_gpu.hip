@@ -45,11 +45,16 @@ struct LumaJob {
     uint32_t out_head;            // byte offsets into the result area: LumaHead, then the blocks
     uint32_t out_pred_merge, out_rec_merge, out_level_merge, out_rec_me, out_level_me;
 };
-struct LumaHead {
+struct LumaHead {                 // per transform unit: a 64x64 CU has four, each written by a workgroup of its own
     int32_t best_merge;
-    uint32_t ssd_skip, ssd_merge, sum_merge[4];
+    uint32_t ssd_skip, ssd_merge[4], sum_merge[4];
     int16_t mv[2];
-    uint32_t ssd_me, sum_me[4];
+    uint32_t ssd_me[4], sum_me[4];
+};
+struct LumaGroup {                // what one workgroup of the luma part does
+    uint16_t job;
+    uint8_t path;                 // 0 = merge candidate, 1 = motion search
+    uint8_t unit;
 };
 struct ChromaJob {
     int32_t plane;                // 0 = U, 1 = V
@@ -62,8 +67,9 @@ struct ChromaJob {
 
 struct RoundParams {
     const LumaJob *jobs;
+    const LumaGroup *groups;
     const ChromaJob *cjobs;
-    int ncu, nchroma;
+    int nluma, nchroma;           // workgroups of the luma part, chroma jobs
     const uint8_t *src[3];        // source planes, rows width / width/2 apart
     const uint8_t *planes;        // 16 quarter-pel luma planes of the padded reference
     const uint8_t *ref_c[2];      // sample (0,0) of the padded chroma reference planes
@@ -170,9 +176,9 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
 }
 
 template <int N>
-__device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, int path)
+__device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, int path, int u)
 {
-    constexpr int UN = N == 64 ? 32 : N, UNITS = N == 64 ? 4 : 1;
+    constexpr int UN = N == 64 ? 32 : N;
     const int tid = threadIdx.x;
     const uint8_t *src = p.src[0] + (size_t)j.y0 * p.width + j.x0;
     // merge candidates: both workgroups of the job come to the same selection
@@ -217,20 +223,14 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     const uint8_t *pr = plane_block(p, j.x0, j.y0, mvx, mvy);
     int16_t *level = reinterpret_cast<int16_t *>(p.out + (path ? j.out_level_me : j.out_level_merge));
     uint8_t *rec = p.out + (path ? j.out_rec_me : j.out_rec_merge), *pred_out = path ? nullptr : p.out + j.out_pred_merge;
-    uint32_t ssd_total = 0;
-#pragma unroll 1
-    for (int u = 0; u < UNITS; u++) {
-        const int ux = (u & 1) * 32, uy = (u >> 1) * 32;
-        const size_t o = (size_t)uy * N + ux;
-        uint32_t sum, ssd;
-        chain_unit<UN>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
-                       pred_out ? pred_out + o : nullptr, N, sum, ssd);
-        ssd_total += ssd;
-        if (tid == 0) (path ? head->sum_me : head->sum_merge)[u] = sum;
-    }
+    const int ux = (u & 1) * 32, uy = (u >> 1) * 32;      // u is 0 unless the CU is 64x64
+    const size_t o = (size_t)uy * N + ux;
+    uint32_t sum, ssd;
+    chain_unit<UN>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
+                   pred_out ? pred_out + o : nullptr, N, sum, ssd);
     if (tid == 0) {
-        if (path) head->ssd_me = ssd_total;
-        else head->ssd_merge = ssd_total;
+        (path ? head->sum_me : head->sum_merge)[u] = sum;
+        (path ? head->ssd_me : head->ssd_merge)[u] = ssd;
     }
 }
 
@@ -289,17 +289,18 @@ __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p
     __shared__ RoundLds L;
     __shared__ uint8_t s_cpred[16 * 16];
     const int b = blockIdx.x;
-    if (b < 2 * p.ncu) {
-        const LumaJob j = p.jobs[b >> 1];
+    if (b < p.nluma) {
+        const LumaGroup g = p.groups[b];
+        const LumaJob j = p.jobs[g.job];
         switch (j.size) {
-        case 8: luma_job<8>(p, L, j, b & 1); break;
-        case 16: luma_job<16>(p, L, j, b & 1); break;
-        case 32: luma_job<32>(p, L, j, b & 1); break;
-        case 64: luma_job<64>(p, L, j, b & 1); break;
+        case 8: luma_job<8>(p, L, j, g.path, 0); break;
+        case 16: luma_job<16>(p, L, j, g.path, 0); break;
+        case 32: luma_job<32>(p, L, j, g.path, 0); break;
+        case 64: luma_job<64>(p, L, j, g.path, g.unit & 3); break;
         default: break;
         }
-    } else if (b - 2 * p.ncu < p.nchroma) {
-        const ChromaJob j = p.cjobs[b - 2 * p.ncu];
+    } else if (b - p.nluma < p.nchroma) {
+        const ChromaJob j = p.cjobs[b - p.nluma];
         switch (j.n) {
         case 4: chroma_job<4>(p, L, j, s_cpred); break;
         case 8: chroma_job<8>(p, L, j, s_cpred); break;
@@ -322,20 +323,31 @@ __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+constexpr int kMaxLanes = 8;
+
 class GpuEvaluator : public Evaluator {
 public:
-    int w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0;
+    struct ChromaPlace {
+        size_t sum, rec[2], level[2];
+    };
+    // what one lane of the analysis loop owns: its round trips overlap those of the other lanes
+    struct LaneRes {
+        hipStream_t st = nullptr;
+        unsigned *d_counter = nullptr;
+        uint8_t *h_jobs = nullptr, *h_out = nullptr;       // pinned, mapped; the kernel reads / writes them in place
+        unsigned *h_flag = nullptr;
+        uint8_t *g_jobs = nullptr, *g_out = nullptr;       // the same buffers as the GPU addresses them
+        unsigned *g_flag = nullptr;
+        unsigned issued = 0, seq = 0;
+        std::vector<ChromaPlace> place;
+        char err[256] = "";
+    };
+    int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0;
     uint8_t *d_src[3] = {}, *d_ref[3] = {}, *d_planes = nullptr;
-    unsigned *d_counter = nullptr;
-    uint8_t *h_jobs = nullptr, *h_out = nullptr;       // pinned, mapped; the kernel reads / writes them in place
-    unsigned *h_flag = nullptr;
-    uint8_t *g_jobs = nullptr, *g_out = nullptr;       // the same buffers as the GPU addresses them
-    unsigned *g_flag = nullptr;
-    size_t jobs_bytes = 0, out_bytes = 0;
-    unsigned issued = 0, seq = 0;
-    hipStream_t st = nullptr;
+    LaneRes lane[kMaxLanes];
+    size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0;
+    hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
-    char err[256] = "";
 
     ~GpuEvaluator() override { release(); }
 
@@ -347,24 +359,27 @@ public:
             d_src[i] = d_ref[i] = nullptr;
         }
         if (d_planes) (void)hipFree(d_planes), d_planes = nullptr;
-        if (d_counter) (void)hipFree(d_counter), d_counter = nullptr;
-        if (h_jobs) (void)hipHostFree(h_jobs), h_jobs = nullptr;
-        if (h_out) (void)hipHostFree(h_out), h_out = nullptr;
-        if (h_flag) (void)hipHostFree(h_flag), h_flag = nullptr;
+        release_lanes();
         if (st) (void)hipStreamDestroy(st), st = nullptr;
     }
 
-    int init(int width, int height)
+    void release_lanes()
+    {
+        for (LaneRes &l : lane) {
+            if (l.d_counter) (void)hipFree(l.d_counter), l.d_counter = nullptr;
+            if (l.h_jobs) (void)hipHostFree(l.h_jobs), l.h_jobs = nullptr;
+            if (l.h_out) (void)hipHostFree(l.h_out), l.h_out = nullptr;
+            if (l.h_flag) (void)hipHostFree(l.h_flag), l.h_flag = nullptr;
+            if (l.st) (void)hipStreamDestroy(l.st), l.st = nullptr;
+        }
+    }
+
+    int init(int width, int height, int nlanes)
     {
         w = width, h = height;
+        XMI_HIP(hipGetDevice(&device));
         stride = w + 2 * kPad, rows = h + 2 * kPad, stride_c = w / 2 + 2 * kPadC, rows_c = h / 2 + 2 * kPadC;
-        max_cu = h / 64;                      // one CU request per CTU row and round
-        max_chroma = (h / 64) * 64 * 2;       // per CTU at most 64 CUs of 8x8, two planes
         const size_t plane = (size_t)stride * rows, plane_c = (size_t)stride_c * rows_c;
-        jobs_bytes = align_up(sizeof(LumaJob) * max_cu) + align_up(sizeof(ChromaJob) * max_chroma);
-        // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
-        // sums and four blocks, each rounded up to the 256-byte grid of the area
-        out_bytes = (size_t)max_cu * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)(h / 64) * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[0]), (size_t)w * h));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[1]), (size_t)w * h / 4));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_src[2]), (size_t)w * h / 4));
@@ -372,19 +387,44 @@ public:
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_ref[1]), plane_c));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_ref[2]), plane_c));
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_planes), 16 * plane));
-        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_counter), 256));
-        const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
-        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_jobs), jobs_bytes, flags));
-        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_out), out_bytes, flags));
-        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_flag), 256, flags));
-        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_jobs), h_jobs, 0));
-        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_out), h_out, 0));
-        XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g_flag), h_flag, 0));
-        std::memset(h_out, 0, out_bytes);
-        *h_flag = 0;
         XMI_HIP(hipStreamCreate(&st));
         XMI_HIP(hipMemsetAsync(d_planes, 0, 16 * plane, st));
-        XMI_HIP(hipMemsetAsync(d_counter, 0, 256, st));
+        XMI_HIP(hipStreamSynchronize(st));
+        return set_lanes(nlanes);
+    }
+
+    // (re)creates what the lanes own; rows are dealt to lanes round robin, so a lane serves at most ceil(rows / lanes) of them
+    int set_lanes(int nlanes)
+    {
+        XMI_ARG(nlanes >= 1 && nlanes <= kMaxLanes, "analysis: %d lanes (1..%d)", nlanes, kMaxLanes);
+        release_lanes();
+        lanes = nlanes;
+        const int lane_rows = (h / 64 + lanes - 1) / lanes;
+        max_cu = lane_rows;                   // one CU request per CTU row and round
+        max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
+        off_groups = align_up(sizeof(LumaJob) * max_cu);
+        off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
+        jobs_bytes = off_cjobs + align_up(sizeof(ChromaJob) * max_chroma);
+        // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
+        // sums and four blocks, each rounded up to the 256-byte grid of the area
+        out_bytes = (size_t)max_cu * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
+        const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+        for (int i = 0; i < lanes; i++) {
+            LaneRes &l = lane[i];
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_counter), 256));
+            XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_jobs), jobs_bytes, flags));
+            XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_out), out_bytes, flags));
+            XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_flag), 256, flags));
+            XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_jobs), l.h_jobs, 0));
+            XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_out), l.h_out, 0));
+            XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_flag), l.h_flag, 0));
+            std::memset(l.h_out, 0, out_bytes);
+            *l.h_flag = 0;
+            XMI_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
+            XMI_HIP(hipMemsetAsync(l.d_counter, 0, 256, st));
+            l.issued = l.seq = 0;
+            l.err[0] = 0;
+        }
         XMI_HIP(hipStreamSynchronize(st));
         return XMI_OK;
     }
@@ -405,25 +445,41 @@ public:
         return XMI_OK;
     }
 
-    int evaluate(CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
+    int evaluate(int ln, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
     {
-        const int rc = run(cu, ncu, ch, nch);
-        if (rc != XMI_OK) snprintf(err, sizeof err, "%s", xmi_last_error());
+        if (ln < 0 || ln >= lanes) return XMI_ERR_ARG;
+        // the lanes run on threads of the analysis loop, which start with the default device current
+        thread_local int bound = -1;
+        if (bound != device) {
+            if (hipSetDevice(device) != hipSuccess) {
+                snprintf(lane[ln].err, sizeof lane[ln].err, "hipSetDevice(%d) failed on a lane thread", device);
+                return XMI_ERR_HIP;
+            }
+            bound = device;
+        }
+        const int rc = run(lane[ln], cu, ncu, ch, nch);
+        if (rc != XMI_OK) snprintf(lane[ln].err, sizeof lane[ln].err, "%s", xmi_last_error());
         return rc;
     }
 
-private:
-    struct ChromaPlace {
-        size_t sum, rec[2], level[2];
-    };
-    std::vector<ChromaPlace> place;
+    const char *first_error() const
+    {
+        for (int i = 0; i < lanes; i++)
+            if (lane[i].err[0]) return lane[i].err;
+        return "";
+    }
 
-    int run(CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
+private:
+    int run(LaneRes &R, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
     {
         XMI_ARG(ncu <= max_cu, "analysis: %d CU requests exceed the round capacity %d", ncu, max_cu);
+        uint8_t *const h_jobs = R.h_jobs, *const h_out = R.h_out;
+        std::vector<ChromaPlace> &place = R.place;
         LumaJob *jobs = reinterpret_cast<LumaJob *>(h_jobs);
-        ChromaJob *cjobs = reinterpret_cast<ChromaJob *>(h_jobs + align_up(sizeof(LumaJob) * max_cu));
+        LumaGroup *groups = reinterpret_cast<LumaGroup *>(h_jobs + off_groups);
+        ChromaJob *cjobs = reinterpret_cast<ChromaJob *>(h_jobs + off_cjobs);
         size_t out = 0;
+        int nluma = 0;
         for (int i = 0; i < ncu; i++) {
             const CuEval &q = *cu[i];
             LumaJob &j = jobs[i];
@@ -454,6 +510,8 @@ private:
             j.out_rec_me = (uint32_t)out, out = align_up(out + px);
             j.out_level_merge = (uint32_t)out, out = align_up(out + 2 * px);
             j.out_level_me = (uint32_t)out, out = align_up(out + 2 * px);
+            for (int path = 0; path < 2; path++)
+                for (int u = 0; u < (q.size == 64 ? 4 : 1); u++) groups[nluma++] = { (uint16_t)i, (uint8_t)path, (uint8_t)u };
         }
         int nc = 0;
         place.resize(nch);
@@ -484,27 +542,29 @@ private:
         XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
 
         RoundParams p;
-        p.jobs = reinterpret_cast<const LumaJob *>(g_jobs);
-        p.cjobs = reinterpret_cast<const ChromaJob *>(g_jobs + align_up(sizeof(LumaJob) * max_cu));
-        p.ncu = ncu, p.nchroma = nc;
+        p.jobs = reinterpret_cast<const LumaJob *>(R.g_jobs);
+        p.groups = reinterpret_cast<const LumaGroup *>(R.g_jobs + off_groups);
+        p.cjobs = reinterpret_cast<const ChromaJob *>(R.g_jobs + off_cjobs);
+        p.nluma = nluma, p.nchroma = nc;
         for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
         p.planes = d_planes;
         p.ref_c[0] = d_ref[1] + (size_t)kPadC * stride_c + kPadC, p.ref_c[1] = d_ref[2] + (size_t)kPadC * stride_c + kPadC;
         p.width = w, p.stride = stride, p.rows = rows, p.stride_c = stride_c;
         p.qp = cur_qp, p.qpc = cur_qpc;
-        p.out = g_out;
-        const unsigned groups = (unsigned)(2 * ncu + nc);
-        issued += groups;
-        seq++;
-        p.counter = d_counter, p.target = issued, p.flag = g_flag, p.seq = seq;
+        p.out = R.g_out;
+        const unsigned ngroups = (unsigned)(nluma + nc);
+        R.issued += ngroups;
+        R.seq++;
+        const unsigned seq = R.seq;
+        p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
-        hipLaunchKernelGGL(analysis_round_kernel, dim3(groups), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
         XMI_HIP(hipGetLastError());
         // spin on the completion word; look at the stream now and then so that a failed launch cannot hang the host
-        volatile unsigned *flag = h_flag;
+        volatile unsigned *flag = R.h_flag;
         for (unsigned spins = 0; *flag != seq; spins++) {
             if ((spins & 0xfffff) == 0xfffff) {
-                const hipError_t q = hipStreamQuery(st);
+                const hipError_t q = hipStreamQuery(R.st);
                 if (q == hipSuccess) {
                     if (*flag == seq) break;
                     xmi::set_error("analysis: the round kernel finished without reporting completion");
@@ -522,10 +582,14 @@ private:
             CuEval &q = *cu[i];
             const LumaJob &j = jobs[i];
             const LumaHead &hd = *reinterpret_cast<const LumaHead *>(h_out + j.out_head);
-            q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip, q.ssd_merge = hd.ssd_merge;
+            q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
             q.mv_me = { hd.mv[0], hd.mv[1] };
-            q.ssd_me = hd.ssd_me;
-            for (int u = 0; u < 4; u++) q.sum_merge[u] = hd.sum_merge[u], q.sum_me[u] = hd.sum_me[u];
+            q.ssd_merge = q.ssd_me = 0;
+            for (int u = 0; u < 4; u++) {
+                const bool used = u < (q.size == 64 ? 4 : 1);
+                q.sum_merge[u] = used ? hd.sum_merge[u] : 0, q.sum_me[u] = used ? hd.sum_me[u] : 0;
+                q.ssd_merge += used ? hd.ssd_merge[u] : 0, q.ssd_me += used ? hd.ssd_me[u] : 0;
+            }
             q.pred_merge = h_out + j.out_pred_merge, q.rec_merge = h_out + j.out_rec_merge, q.rec_me = h_out + j.out_rec_me;
             q.level_merge = reinterpret_cast<const int16_t *>(h_out + j.out_level_merge);
             q.level_me = reinterpret_cast<const int16_t *>(h_out + j.out_level_me);
@@ -566,7 +630,7 @@ xmi_analysis *xmi_analysis_create(int width, int height)
         xmi::set_error("xmi_analysis_create: out of host memory");
         return nullptr;
     }
-    if (a->ev.init(width, height) != XMI_OK) {
+    if (a->ev.init(width, height, a->an.lanes) != XMI_OK) {
         delete a;
         return nullptr;
     }
@@ -574,6 +638,16 @@ xmi_analysis *xmi_analysis_create(int width, int height)
 }
 
 void xmi_analysis_destroy(xmi_analysis *a) { delete a; }
+
+int xmi_analysis_configure(xmi_analysis *a, int lanes)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(a, "xmi_analysis_configure: null handle");
+    rc = a->ev.set_lanes(lanes);
+    if (rc == XMI_OK) a->an.lanes = lanes;
+    return rc;
+}
 
 int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits)
 {
@@ -606,7 +680,7 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
     rc = a->an.p_picture(qp, a->ev, a->res);
     if (rc != 0) {
         if (rc == -2) xmi::set_error("xmi_analysis_p_picture: the wavefront stalled");
-        else xmi::set_error("xmi_analysis_p_picture: %s", a->ev.err);
+        else xmi::set_error("xmi_analysis_p_picture: %s", a->ev.first_error());
         return rc < 0 ? rc : XMI_ERR_HIP;
     }
     const PictureResult &r = a->res;

@@ -351,7 +351,8 @@ struct Row {
     int qp = 0, ctu_x = 0;
     CuEval cu_req;
     std::vector<ChromaEval> chroma_req;
-    bool pending = false;
+    bool pending = false;       // blocked on a request
+    bool in_flight = false;     // ... that is part of the call its lane is making right now
     int need = -1;
 
     uint8_t &M(int r, int c) { return mode[(r + 1) * 18 + c + 1]; }
@@ -368,12 +369,21 @@ struct Row {
     void evaluate_chroma();
 };
 
-struct Shared {
-    std::mutex m;
-    std::condition_variable cv_rows, cv_main;
-    int running = 0, finished = 0, error = 0;
+// Rows are dealt to lanes (row y -> lane y % lanes). A lane is the unit of one round trip: its rows block, their requests go to
+// the evaluator together, they wake together - while the rows of the other lanes are busy on the host or waiting for
+// their own round trip, so that host work and evaluator latency overlap.
+struct Lane {
+    std::condition_variable cv_main;
+    int running = 0, rows = 0, finished = 0;
     std::vector<CuEval *> cu;
     std::vector<ChromaEval *> chroma;
+};
+
+struct Shared {
+    std::mutex m;
+    std::condition_variable cv_rows;
+    int error = 0;
+    std::vector<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row
     std::vector<Row> rows;
     std::vector<Ctx> saved;         // contexts after CTU 1 of a row: where the row below starts (cabacRdoSaved, src/encode.cpp:5481)
@@ -681,9 +691,10 @@ void Row::chroma_pass()
 void Row::evaluate_cu()
 {
     std::unique_lock<std::mutex> lk(sh->m);
-    sh->cu.push_back(&cu_req);
+    Lane &ln = sh->lanes[y % sh->lanes.size()];
+    ln.cu.push_back(&cu_req);
     pending = true;
-    if (--sh->running == 0) sh->cv_main.notify_one();
+    if (--ln.running == 0) ln.cv_main.notify_one();
     sh->cv_rows.wait(lk, [&] { return !pending; });
     if (sh->error) throw Abort();
 }
@@ -691,9 +702,10 @@ void Row::evaluate_cu()
 void Row::evaluate_chroma()
 {
     std::unique_lock<std::mutex> lk(sh->m);
-    for (ChromaEval &c : chroma_req) sh->chroma.push_back(&c);
+    Lane &ln = sh->lanes[y % sh->lanes.size()];
+    for (ChromaEval &c : chroma_req) ln.chroma.push_back(&c);
     pending = true;
-    if (--sh->running == 0) sh->cv_main.notify_one();
+    if (--ln.running == 0) ln.cv_main.notify_one();
     sh->cv_rows.wait(lk, [&] { return !pending; });
     if (sh->error) throw Abort();
 }
@@ -719,7 +731,8 @@ void Row::run()
                 std::unique_lock<std::mutex> lk(S.m);
                 if (S.done[y - 1] < need) {
                     this->need = need;
-                    if (--S.running == 0) S.cv_main.notify_one();
+                    Lane &ln = S.lanes[y % S.lanes.size()];
+                    if (--ln.running == 0) ln.cv_main.notify_one();
                     S.cv_rows.wait(lk, [&] { return this->need < 0; });
                     if (S.error) throw Abort();
                 }
@@ -781,7 +794,7 @@ void Row::run()
                     Row &below = S.rows[y + 1];
                     if (below.need >= 0 && S.done[y] >= below.need) {
                         below.need = -1;
-                        S.running++;
+                        S.lanes[(y + 1) % S.lanes.size()].running++;
                         S.cv_rows.notify_all();
                     }
                 }
@@ -791,8 +804,9 @@ void Row::run()
     }
     S.an->frac_bits[y] = rate.frac;
     std::lock_guard<std::mutex> lk(S.m);
-    S.finished++;
-    if (--S.running == 0) S.cv_main.notify_one();
+    Lane &ln = S.lanes[y % S.lanes.size()];
+    ln.finished++;
+    if (--ln.running == 0) ln.cv_main.notify_one();
 }
 
 }  // namespace
@@ -851,39 +865,54 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     S.saved.resize(rows_);
     init_contexts(1, qp, S.start.m);
     S.rows.resize(rows_);
-    S.running = rows_;
-    for (int y = 0; y < rows_; y++) S.rows[y].sh = &S, S.rows[y].y = y;
+    const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
+    S.lanes = std::vector<Lane>(nl);
+    for (int y = 0; y < rows_; y++) {
+        S.rows[y].sh = &S, S.rows[y].y = y;
+        S.lanes[y % nl].rows++, S.lanes[y % nl].running++;
+    }
     std::vector<std::thread> threads;
-    threads.reserve(rows_);
+    threads.reserve(rows_ + nl);
     for (int y = 0; y < rows_; y++) threads.emplace_back([&S, y] { S.rows[y].run(); });
 
-    std::vector<CuEval *> cu;
-    std::vector<ChromaEval *> chroma;
-    {
+    // one coordinator per lane: when none of its rows is busy on the host, whatever they asked for goes out in one call
+    auto coordinate = [&S, &ev, &out, nl](int lane) {
+        Lane &ln = S.lanes[lane];
+        std::vector<CuEval *> cu;
+        std::vector<ChromaEval *> chroma;
         std::unique_lock<std::mutex> lk(S.m);
         for (;;) {
-            S.cv_main.wait(lk, [&] { return S.running == 0; });
-            if (S.finished == rows_) break;
-            cu.swap(S.cu), chroma.swap(S.chroma);
-            S.cu.clear(), S.chroma.clear();
+            ln.cv_main.wait(lk, [&] { return ln.running == 0 && (!ln.cu.empty() || !ln.chroma.empty() || ln.finished == ln.rows || S.error); });
+            if (ln.finished == ln.rows) break;
+            cu.swap(ln.cu), chroma.swap(ln.chroma);
+            ln.cu.clear(), ln.chroma.clear();
+            // the rows this call serves: a row that another lane's progress wakes during the call asks for the next one
+            for (Row &r : S.rows)
+                if (r.y % nl == lane && r.pending) r.in_flight = true;
             int rc = 0;
-            if (cu.empty() && chroma.empty()) {
-                rc = -2;      // every row waits for a neighbour: cannot happen with a sound dependency order
-            } else if (!S.error) {
+            if (!S.error && (!cu.empty() || !chroma.empty())) {
                 lk.unlock();
-                rc = ev.evaluate(cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
+                rc = ev.evaluate(lane, cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
                 lk.lock();
                 out.evaluator_calls++, out.cu_requests += cu.size(), out.chroma_requests += chroma.size();
             }
             if (rc && !S.error) S.error = rc;
             for (Row &r : S.rows) {
-                if (r.pending) r.pending = false, S.running++;
-                if (S.error && r.need >= 0) r.need = -1, S.running++;
+                Lane &rl = S.lanes[r.y % nl];
+                if (r.y % nl == lane && r.in_flight) r.in_flight = r.pending = false, ln.running++;
+                if (S.error && r.need >= 0) {       // an error ends the picture: rows waiting for a neighbour leave as well
+                    r.need = -1, rl.running++;
+                    rl.cv_main.notify_one();
+                }
             }
+            if (S.error)
+                for (Lane &o : S.lanes) o.cv_main.notify_one();
             cu.clear(), chroma.clear();
             S.cv_rows.notify_all();
         }
-    }
+    };
+    for (int l = 1; l < nl; l++) threads.emplace_back(coordinate, l);
+    coordinate(0);
     for (std::thread &t : threads) t.join();
     return S.error;
 }

@@ -61,8 +61,10 @@ struct ChromaEval {
 class Evaluator {
 public:
     virtual ~Evaluator() {}
-    // fills the result fields of every request; returns 0, or an error code that ends the picture
-    virtual int evaluate(CuEval *const *cu, int ncu, ChromaEval *const *chroma, int nchroma) = 0;
+    // Fills the result fields of every request; returns 0, or an error code that ends the picture. Calls with different
+    // `lane` values (0 .. Analyser::lanes - 1) come from different threads and may overlap; calls of one lane never do,
+    // and the blocks a call hands out stay valid until the next call of the same lane.
+    virtual int evaluate(int lane, CuEval *const *cu, int ncu, ChromaEval *const *chroma, int nchroma) = 0;
 };
 
 // What a picture leaves behind, picture-level arrays (CTU caches of the reference laid side by side):
@@ -95,6 +97,10 @@ public:
     std::vector<double> sum_cost, avg_cost;   // [row][col][5]
     std::vector<int32_t> count;
     std::vector<uint64_t> frac_bits;          // [row]
+
+    // Rows are dealt to `lanes` groups (row y -> y % lanes); each group makes its own round trips to the evaluator, so the
+    // host work of one group overlaps the evaluator latency of the others. Results do not depend on it.
+    int lanes = 1;
 
     // One P picture: decisions and reconstruction of every CTU, rows advancing as a wavefront (a CTU starts when its
     // left neighbour and the CTU above and to the right are done). The evaluator is bound to the picture pair (source,
