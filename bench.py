@@ -180,7 +180,12 @@ def analysis_rate(L, qp=32, pictures=4):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import bench_analysis
-        return bench_analysis.run(1920, 1080, qp, pictures, lib=L)
+        out = bench_analysis.run(1920, 1080, qp, pictures, lib=L)
+        # GOP segments are independent (each starts at an I picture), so several are analysed at the same time on one GPU,
+        # one handle and one host thread group each; the aggregate is what a segment-parallel encode sees
+        seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L)
+        out["analysis_fps_8_segments"] = seg.get("analysis_fps", seg.get("error"))
+        return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}
 
