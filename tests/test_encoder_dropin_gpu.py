@@ -185,7 +185,8 @@ def test_bitstream_identical_with_row_threads_on_gpu_primitives(tmp_path):
 
 
 @needs_ref("x265_gpu_me", how="make -C oracle trace")
-@pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao", "gpu_bs")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock"))])
+@pytest.mark.parametrize("key,variants", [("1920x1080_f4_q32", ("gpu_me", "gpu_planes", "gpu_deblock", "gpu_sao", "gpu_bs")), ("1920x1080_f3_q22", ("gpu_me", "gpu_deblock")),
+                                          ("1920x1080_f3_q27", ("gpu_me", "gpu_deblock")), ("1920x1080_f3_q37", ("gpu_me", "gpu_deblock"))])
 def test_bitstream_identical_at_1080p_with_gpu_services(tmp_path, key, variants):
     """The geometry the headline metric is quoted on (1920x1080, coded 1920x1088, 510 CTUs; generator seed 7): the
     reference's encoder with the GPU motion search / quarter-pel planes / deblocking / SAO statistics writes the stream
