@@ -156,6 +156,15 @@ def test_gop_segments_on_two_ranks_with_gpu_motion_search():
     assert res["parity"] == "identical" and res["ranks"] == 2
 
 
+@needs_ref("x265_gpu_me_2160p", how="make -C oracle enc_2160p")
+def test_2160p_segments_on_two_ranks_with_gpu_motion_search():
+    """The 3840x2160 segment fixture (tests/golden/segment_md5_2160p.json, recorded by the CPU build of the same
+    height-patched sources): two ranks, one 2-frame segment each, every motion search on the GPU."""
+    from tests.test_segments_gloo import UHD, run_segment_encode
+    res = run_segment_encode("gpu_me_2160p", 2, clip=UHD)
+    assert res["parity"] == "identical" and res["ranks"] == 2 and set(res["segments"]) == {"0-2", "2-4"}
+
+
 @needs_ref("x265_gpu_all", how="make -C oracle trace")
 @pytest.mark.parametrize("variant", ["gpu", "gpu_all"])
 def test_scene_change_detection_on_gpu_sad(tmp_path, variant):

@@ -74,15 +74,18 @@ def test_gather_world2_gloo(tmp_path):
 REFSSE = os.path.join(ROOT, "oracle", "_ref", "x265_refsse")
 
 
-def run_segment_encode(variant, nproc, extra_env=None):
+UHD = ["--width", "3840", "--height", "2160", "--frames", "4", "--gop", "2", "--seed", "11",
+       "--golden", os.path.join(ROOT, "tests", "golden", "segment_md5_2160p.json")]
+
+
+def run_segment_encode(variant, nproc, extra_env=None, clip=("--frames", "16", "--gop", "8")):
     import json
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, OMP_NUM_THREADS="1", XMI_BENCH_BACKEND="gloo", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tools", "encode_segments.py"), "--variant", variant, "--frames", "16",
-           "--gop", "8", "--check"]
+           "--master-port", str(port), os.path.join(ROOT, "tools", "encode_segments.py"), "--variant", variant, *clip, "--check"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [x for x in res.stdout.splitlines() if x.startswith("{")][-1]
@@ -97,3 +100,12 @@ def test_gop_segments_on_two_ranks_join_into_the_per_segment_reference_streams()
     assert two["parity"] == "identical" and two["ranks"] == 2 and set(two["segments"]) == {"0-8", "8-16"}
     one = run_segment_encode("refsse", 1)
     assert one["md5"] == two["md5"] and one["bytes"] == two["bytes"]
+
+
+@needs_ref("x265_refsse_2160p", how="make -C oracle enc_2160p")
+def test_2160p_segments_on_two_ranks():
+    """3840x2160 (coded 3840x2176, 2 040 CTUs), the first two of the eight 2-frame segments recorded in
+    tests/golden/segment_md5_2160p.json, one per rank. The encoder is the reference's sources built against a header copy
+    whose MAX_HEIGHT reads 2176 (oracle/Makefile, enc_2160p): the unmodified constant refuses this height."""
+    two = run_segment_encode("refsse_2160p", 2, clip=UHD)
+    assert two["parity"] == "identical" and two["ranks"] == 2 and set(two["segments"]) == {"0-2", "2-4"}

@@ -82,21 +82,23 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("XMI_BENCH_BACKEND", "nccl"))
     ap.add_argument("--out")
     ap.add_argument("--check", action="store_true", help="compare every segment's md5 with tests/golden/segment_md5.json")
-    ap.add_argument("--write-golden", action="store_true", help="single process: record the md5 of every GOP with x265_refsse")
+    ap.add_argument("--write-golden", action="store_true", help="single process: record the md5 of every GOP with x265_refsse (or the refsse* variant named)")
+    ap.add_argument("--golden", default=GOLD, help="fixture file of --check / --write-golden")
     args = ap.parse_args()
     w, h = args.width, args.height
     key = f"{w}x{h}_q{args.qp}_seed{args.seed}_gop{args.gop}"
 
     if args.write_golden:
         frames = clip_frames(w, h, args.frames, args.seed)
-        gold = json.load(open(GOLD)) if os.path.exists(GOLD) else {}
+        gold = json.load(open(args.golden)) if os.path.exists(args.golden) else {}
+        writer = args.variant if args.variant.startswith("refsse") else "refsse"
         with tempfile.TemporaryDirectory() as d:
             for b in range(0, args.frames, args.gop):
                 e = min(b + args.gop, args.frames)
-                data, _ = encode("refsse", frames[b:e], w, h, args.qp, d)
+                data, _ = encode(writer, frames[b:e], w, h, args.qp, d)
                 gold.setdefault(key, {})[f"{b}-{e}"] = {"md5": hashlib.md5(data).hexdigest(), "bytes": len(data)}
-        json.dump(gold, open(GOLD, "w"), indent=1, sort_keys=True)
-        print("wrote", GOLD)
+        json.dump(gold, open(args.golden, "w"), indent=1, sort_keys=True)
+        print("wrote", args.golden)
         return
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -117,7 +119,7 @@ def main():
     frames = clip_frames(w, h, e, args.seed)[b:e]
     # one encoder run per GOP of the span (fresh state each), on this rank's GPU
     env_dev = os.environ.get("HIP_VISIBLE_DEVICES")
-    if args.variant != "refsse" and args.backend == "nccl" and world > 1 and env_dev is None:
+    if not args.variant.startswith("refsse") and args.backend == "nccl" and world > 1 and env_dev is None:
         os.environ["HIP_VISIBLE_DEVICES"] = str(local)
     stream, secs, md5s, recs = b"", 0.0, {}, []
     with tempfile.TemporaryDirectory() as d:
@@ -154,9 +156,9 @@ def main():
     res = {"variant": args.variant, "ranks": world, "frames": args.frames, "gop": args.gop, "bytes": len(whole), "md5": hashlib.md5(whole).hexdigest(),
            "segments": got, "encode_seconds_max_rank": round(wall, 3), "fps": round(args.frames / wall, 3) if wall > 0 else None}
     if args.check:
-        want = json.load(open(GOLD))[key]
+        want = json.load(open(args.golden))[key]
         bad = {k: (v, want.get(k)) for k, v in got.items() if want.get(k) != v}
-        res["parity"] = "identical" if not bad and len(got) == len(want) else f"DIFFERS: {bad or 'segment count'}"
+        res["parity"] = "identical" if not bad and len(got) == args.frames // args.gop else f"DIFFERS: {bad or 'segment count'}"
     print(json.dumps(res), flush=True)
     if args.check and res["parity"] != "identical":
         sys.exit(1)
