@@ -193,13 +193,17 @@ def analysis_rate(L, qp=32, pictures=4):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed back-to-back launches after the warm-up steps until this much time has passed: the first ~30 ms of a "
+                         "burst run at boost clocks and then through a throttling overshoot (380 -> 530 -> 360 us per launch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--range", type=int, default=64)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="diagnostic runs: leave out the satd and analysis blocks")
     args = ap.parse_args()
     global PAD
     PAD = max(PAD, args.range + 16)
@@ -272,6 +276,12 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    t_settle, n_settle = time.perf_counter(), 0
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for i in range(32):
+            step(n_settle + i)
+        n_settle += 32
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -335,8 +345,19 @@ def main():
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),
                          "kernel_ms_min": round(kern_ms[0], 4)},
         }
-        out["satd"] = satd_rates(L, capi, torch, dev, stream)
-        out["analysis"] = analysis_rate(L)
+        # the same kernel against its arithmetic bound: every (pixel, MV) pair is one absolute difference, and the SAD
+        # instructions of gfx950 retire 64 of them per clock and SIMD (v_qsad_pk_u16_u8: 16 per lane every 16 clocks,
+        # tools/microbench/qsad_cycles.hip); 1024 SIMDs at the 2.4 GHz peak clock. Streaming stores of this shape top out at
+        # 5.4 TB/s (tools/microbench/store_pitch4.hip), so the two bounds lie within 25 % of each other.
+        absdiff = float(w) * h * nmv1 * nmv1
+        valu_peak = 256 * 4 * 64 * 2.4
+        out["roofline_valu_sad"] = {"bound": "valu_sad", "achieved": round(absdiff / (kern_avg_ms * 1e-3) / 1e9, 1), "peak": valu_peak,
+                                    "unit": "G abs-diff/s", "frac": round(absdiff / (kern_avg_ms * 1e-3) / 1e9 / valu_peak, 4), "clock_ghz": 2.4,
+                                    "store_ceiling_GBps": 5400.0}
+        out["config"]["settle_ms"] = args.settle_ms
+        if not args.headline_only:
+            out["satd"] = satd_rates(L, capi, torch, dev, stream)
+            out["analysis"] = analysis_rate(L)
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

@@ -56,9 +56,11 @@ const char *xmi_version(void);
  * box xCuMvClip allows, src/encode.cpp:3794-3812) and every square PU of the quad-tree
  * (64 8x8 + 16 16x16 + 4 32x32 + 1 64x64 = 85 per MV) the exact SAD.
  *
- * Output planes: sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32, exactly 180 bytes per (CTU, MV) in total. The
+ * Output planes: sad8/sad16 are uint16 (max 65280), sad32/sad64 uint32, 180 bytes of results per (CTU, MV) in total. The
  * layout is tiled so that the GPU writes whole cache lines: main part, dx in [-R, R-1]: per (ctu, dy) one row of R/8
- * tiles of 16 consecutive dx, each tile holding all blocks of the level ([block slot][dx % 16]); the dx = +R column of
+ * tiles of 16 consecutive dx, each tile holding all blocks of the level ([block slot][dx % 16]), followed by a few
+ * cache lines of padding that are never written (3 % of the plane; rows a power of two apart stream to memory 15 %
+ * slower); the dx = +R column of
  * every (ctu, dy) follows after the main part of the same plane ([ctu][dy][block slot]). ctu is raster order in the
  * frame. Use xmi_sad_surface_index() for the element index of (level, ctu, blk, dy, dx) with blk in raster order
  * inside the CTU (8x8: by*8+bx; 16x16: by*4+bx; 32x32: by*2+bx; 64x64: 0).

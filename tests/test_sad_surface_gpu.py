@@ -117,7 +117,8 @@ def _pyramid_checks(torch, planes, nctu, rng, ctu_lo, ctu_hi):
     """levels must sum exactly, checked on the device in the tiled layout: slot c*16+z of sad8 -> slot z of sad16,
     z = 4q+b -> quadrant q of sad32 -> sad64; main part [ctu][dy][tile][slot][16] and the dx = +R part [ctu][dy][slot]"""
     nmv, t = 2 * rng + 1, rng // 8
-    main = [nctu * nmv * t * nb * 16 for nb in layout.NBLK]
+    pitch = [layout.row_pitch(rng, lvl) for lvl in range(4)]      # payload t * nb * 16 elements + padding nobody writes
+    main = [nctu * nmv * pitch[lvl] for lvl in range(4)]
     for lo in range(ctu_lo, ctu_hi, 32):          # chunks of CTUs bound the int32 temporaries
         hi = min(lo + 32, ctu_hi)
         n = hi - lo
@@ -126,7 +127,10 @@ def _pyramid_checks(torch, planes, nctu, rng, ctu_lo, ctu_hi):
             nb = layout.NBLK[lvl]
             if edge:
                 return planes[lvl][main[lvl] + lo * nmv * nb:main[lvl] + hi * nmv * nb].view(n, nmv, 1, nb, 1).to(torch.int32)
-            return planes[lvl][lo * nmv * t * nb * 16:hi * nmv * t * nb * 16].view(n, nmv, t, nb, 16).to(torch.int32)
+            rows = planes[lvl][lo * nmv * pitch[lvl]:hi * nmv * pitch[lvl]].view(n, nmv, pitch[lvl])
+            if lvl == 0 and lo == ctu_lo:
+                assert bool((rows[:, :, t * nb * 16:].to(torch.int32) == 0xAAAA).all()), "the padding between rows was written"
+            return rows[:, :, :t * nb * 16].reshape(n, nmv, t, nb, 16).to(torch.int32)
 
         for edge in (False, True):
             s8, s16, s32, s64 = (part(lvl, edge) for lvl in range(4))

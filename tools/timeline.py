@@ -23,10 +23,15 @@ nctu = (W // 64) * (H // 64)
 planes = [torch.empty(layout.plane_elems(nctu, R, lv), dtype=torch.int16 if lv < 2 else torch.int32, device="cuda") for lv in range(4)]
 geom = capi.SadGeom(W, H, W, W + 2 * PAD, R)
 s = torch.cuda.current_stream().cuda_stream
-for it in range(30):     # sustained load, the last launch is analysed
+import time
+torch.cuda.synchronize()
+n_launch = int(os.environ.get("LAUNCHES", "30"))
+wall0 = time.perf_counter()
+for it in range(n_launch):     # sustained load, the last launch is analysed
     capi.check(L.xmi_sad_surface_dev(C.byref(geom), cur.data_ptr(), ref.data_ptr() + PAD * (W + 2 * PAD) + PAD, planes[0].data_ptr(),
                                      planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), 0, nctu, s))
 torch.cuda.synchronize()
+print(f"{n_launch} launches back to back: {(time.perf_counter() - wall0) / n_launch * 1e6:.1f} us per launch (host clock)")
 buf = (C.c_uint64 * (6 * nctu))()
 L.xmi_debug_timeline.argtypes = [C.c_void_p, C.c_int]
 assert L.xmi_debug_timeline(buf, nctu) == 0

@@ -18,8 +18,8 @@
 //   The dx = +R column (one more than a multiple of 4) is produced by a short v_sad_u8 pass at the end.
 //
 // Output layout (chosen so that every store instruction of a wavefront writes one contiguous run):
-//   main part, dx in [-R, R-1]: per (ctu, dy) a row of R/8 tiles of 16 consecutive dx (rows are
-//   multiples of 128 bytes, so every row starts on a cache line):
+//   main part, dx in [-R, R-1]: per (ctu, dy) a row of R/8 tiles of 16 consecutive dx; rows start on cache lines,
+//   xmi::surface_row_pitch elements apart (the payload plus a few unwritten lines, see xmi_common.h):
 //     sad8 : [ctu][dy][tile][c*16 + z][dx % 16]   c = (by8&1)*2 + (bx8&1), z = z-order of the parent 16x16
 //     sad16: [ctu][dy][tile][z][dx % 16]
 //     sad32: [ctu][dy][tile][q][dx % 16]          q = raster index of the 32x32 quadrant
@@ -55,7 +55,7 @@ constexpr int kCurLdsBytes = 16 * 16 * 16;  // [row in 16x16 block][z][16 bytes]
 
 // blocks per level, and elements per (ctu, dy) row of the main part of each level's plane
 constexpr int level_blocks(int level) { return xmi::surface_level_blocks(level); }
-constexpr int row_elems(int R, int level) { return xmi::surface_row_elems(R, level); }
+constexpr int row_pitch(int R, int level) { return xmi::surface_row_pitch(R, level); }
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
@@ -85,9 +85,14 @@ __device__ unsigned long long g_timeline[4096 * 6];   // per workgroup: s_memtim
 
 // Workgroup = one CTU x one band of dy rows; R/8 wavefronts.
 // lane = q*16 + gl*4 + b: q = 32x32 quadrant (raster), b = 16x16 block inside it (raster), gl = dx group of the wavefront.
+// Up to R = 64 a lane keeps the 16 rows of its 16x16 block of the current CTU in 64 VGPRs (about 190 in all: two
+// wavefronts per SIMD, one workgroup of R = 64 per CU at a time); with R = 128 a workgroup is 16 wavefronts, which leaves
+// 128 VGPRs each, and the rows are read from LDS in every step instead. Measured at 1080p, R = 64, steady state:
+// 380 us per launch with the LDS reads, 359 us with the rows in registers.
 template <int R>
-__global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p)
+__global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(const SadParams p)
 {
+    constexpr bool kCurInRegs = R <= 64;
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *cur_lds = lds;
     unsigned char *ref_lds = lds + kCurLdsBytes;
@@ -148,7 +153,7 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
     const u32 xor32_addr = (u32)((lane ^ 32) * 4);            // ds_bpermute address of the lane 32 away
 
     // output rows (uniform per workgroup and step) and per-lane byte offsets inside a row
-    constexpr int ROW8 = row_elems(R, 0), ROW16 = row_elems(R, 1), ROW32 = row_elems(R, 2), ROW64 = row_elems(R, 3);
+    constexpr int ROW8 = row_pitch(R, 0), ROW16 = row_pitch(R, 1), ROW32 = row_pitch(R, 2), ROW64 = row_pitch(R, 3);   // elements between rows
     const size_t row0 = (size_t)ctu * nmv + seg_base;
     char *o8 = reinterpret_cast<char *>(p.sad8 + row0 * ROW8);
     char *o16 = reinterpret_cast<char *>(p.sad16 + row0 * ROW16);
@@ -159,6 +164,11 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
     const u32 off32 = (u32)(wave * 64 + q * 16 + gl * 4 + b) * 4u; // lane b stores the sum for dx = 4*gl + b
     const u32 off64 = (u32)(wave * 16 + gl * 4 + b) * 4u;
 
+    uint4 creg[kCurInRegs ? 16 : 1];
+    if constexpr (kCurInRegs) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) creg[r] = *reinterpret_cast<const uint4 *>(cur_lds + z * 16 + r * 256);
+    }
     u64 acc[4][8];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -176,8 +186,8 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int s = s0 + u;
-            // The current-CTU rows are loop invariant; holding them would cost 64 VGPRs. Launder the LDS
-            // address every step so the reads stay inside the step (LDS bandwidth is plentiful).
+            // Without kCurInRegs: the current-CTU rows are loop invariant and holding them would cost 64 VGPRs. Launder
+            // the LDS address every step so the reads stay inside the step.
             u32 cur_off = (u32)z * 16u;
             asm volatile("" : "+v"(cur_off));
             const unsigned char *cl = cur_lds + cur_off;
@@ -189,13 +199,18 @@ __global__ void __launch_bounds__(8 * R, 4) sad_surface_kernel(const SadParams p
                 const u64 p01 = pack64(w0, w1), p12 = pack64(w1, w2), p23 = pack64(w2, w3), p34 = pack64(w3, w4);
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-#ifndef XMI_EXP_NOSCHEDBAR
-                    asm volatile("" ::: "memory");  // bound the live range of the current-pixel registers:
-                    __builtin_amdgcn_sched_barrier(0);  // neither the compiler nor the scheduler may hoist these reads
-#endif
                     uint4 c[4];
+                    if constexpr (kCurInRegs) {
 #pragma unroll
-                    for (int yy = 0; yy < 4; yy++) c[yy] = *reinterpret_cast<const uint4 *>(cl + (cy * 8 + h * 4 + yy) * 256);
+                        for (int yy = 0; yy < 4; yy++) c[yy] = creg[cy * 8 + h * 4 + yy];
+                    } else {
+#ifndef XMI_EXP_NOSCHEDBAR
+                        asm volatile("" ::: "memory");  // bound the live range of the current-pixel registers:
+                        __builtin_amdgcn_sched_barrier(0);  // neither the compiler nor the scheduler may hoist these reads
+#endif
+#pragma unroll
+                        for (int yy = 0; yy < 4; yy++) c[yy] = *reinterpret_cast<const uint4 *>(cl + (cy * 8 + h * 4 + yy) * 256);
+                    }
 #pragma unroll
                     for (int yy = 0; yy < 4; yy++) {
                         const int y = h * 4 + yy;
@@ -347,7 +362,7 @@ size_t xmi_sad_surface_elems(const xmi_sad_geom *g, int level)
 {
     if (!g || level < 0 || level > 3 || !range_ok(g->range)) return 0;
     const size_t nctu = (size_t)(g->width / 64) * (size_t)(g->height / 64);
-    return nctu * (size_t)(2 * g->range + 1) * (size_t)(row_elems(g->range, level) + level_blocks(level));
+    return nctu * (size_t)(2 * g->range + 1) * (size_t)(row_pitch(g->range, level) + level_blocks(level));
 }
 
 #ifdef XMI_EXP_TIMELINE

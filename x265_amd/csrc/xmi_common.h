@@ -45,8 +45,16 @@ std::mutex &picture_call_mutex();
 // ---- layout of the SAD surface planes (sad_surface.hip writes it, me_search.hip reads it) ----
 // level 0..3 = 8x8 / 16x16 / 32x32 / 64x64 blocks of a CTU; blk = raster index of the block at that level.
 // Main part, dx in [-R, R-1]: [ctu][dy][dx / 16][slot][dx % 16]; edge part, dx = +R: after the main part, [ctu][dy][slot].
+// The (ctu, dy) rows of the main part are surface_row_pitch elements apart: the payload (a power of two bytes) plus a few
+// cache lines that nobody writes. Hundreds of workgroups stream rows at the same time; with a power-of-two distance
+// between them the streaming-store rate of the chip drops from 5.4 to 4.6 TB/s (tools/microbench/store_pitch.hip).
 __host__ __device__ constexpr int surface_level_blocks(int level) { return level == 0 ? 64 : level == 1 ? 16 : level == 2 ? 4 : 1; }
 __host__ __device__ constexpr int surface_row_elems(int R, int level) { return (R / 8) * surface_level_blocks(level) * 16; }
+__host__ __device__ constexpr int surface_row_pitch(int R, int level)
+{
+    const int esize = level < 2 ? 2 : 4, bytes = surface_row_elems(R, level) * esize;
+    return (bytes + (bytes / 32 > 128 ? bytes / 32 : 128)) / esize;
+}
 
 __host__ __device__ inline int surface_slot(int level, int blk)
 {
@@ -67,8 +75,8 @@ __host__ __device__ inline size_t surface_index(int R, size_t nctu, int level, i
     const int dxi = dx + R, dyi = dy + R, slot = surface_slot(level, blk);
     const size_t nmv = (size_t)(2 * R + 1), nb = (size_t)surface_level_blocks(level);
     const size_t row = (size_t)ctu * nmv + (size_t)dyi;
-    if (dxi == 2 * R) return nctu * nmv * (size_t)surface_row_elems(R, level) + row * nb + (size_t)slot;
-    return row * (size_t)surface_row_elems(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
+    if (dxi == 2 * R) return nctu * nmv * (size_t)surface_row_pitch(R, level) + row * nb + (size_t)slot;
+    return row * (size_t)surface_row_pitch(R, level) + ((size_t)(dxi >> 4) * nb + (size_t)slot) * 16 + (size_t)(dxi & 15);
 }
 
 // Bound on the integer displacement (either axis, either sign) of every block one motion search can read: predictors
