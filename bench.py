@@ -172,7 +172,7 @@ def satd_rates(L, capi, torch, dev, stream, reps=10):
     return out
 
 
-def analysis_rate(L, qp=32, pictures=4):
+def analysis_rate(L, qp=32, pictures=4, segments=True):
     """The encode-side half of the headline metric with this library's code only: P pictures per second of
     xmi_analysis_p_picture (mode decision + reconstruction of every CTU of a 1080p picture: the reference's xEncodeCUs for
     inter pictures, host decision logic + GPU pixel work). Outside the timed region, rank 0. The reference's own encoder on
@@ -183,8 +183,9 @@ def analysis_rate(L, qp=32, pictures=4):
         out = bench_analysis.run(1920, 1080, qp, pictures, lib=L)
         # GOP segments are independent (each starts at an I picture), so several are analysed at the same time on one GPU,
         # one handle and one host thread group each; the aggregate is what a segment-parallel encode sees
-        seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L)
-        out["analysis_fps_8_segments"] = seg.get("analysis_fps", seg.get("error"))
+        if segments:
+            seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L)
+            out["analysis_fps_8_segments"] = seg.get("analysis_fps", seg.get("error"))
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}
@@ -204,6 +205,10 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames kept resident per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="diagnostic runs: leave out the satd and analysis blocks")
+    ap.add_argument("--no-analysis", action="store_true", help="leave out the analysis block")
+    ap.add_argument("--no-segments", action="store_true",
+                    help="leave out the 8-segment leg of the analysis block (rocprofv3's kernel trace crashes inside hipLaunchKernel when "
+                         "eight host threads launch at once)")
     args = ap.parse_args()
     global PAD
     PAD = max(PAD, args.range + 16)
@@ -357,7 +362,8 @@ def main():
         out["config"]["settle_ms"] = args.settle_ms
         if not args.headline_only:
             out["satd"] = satd_rates(L, capi, torch, dev, stream)
-            out["analysis"] = analysis_rate(L)
+            if not args.no_analysis:
+                out["analysis"] = analysis_rate(L, segments=not args.no_segments)
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

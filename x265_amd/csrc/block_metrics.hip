@@ -82,8 +82,11 @@ __device__ __forceinline__ u32 tile_value(const uint8_t *a, const uint8_t *b, in
 // columns and handed to xmi::hadamard_abs_sum_packed. Returns the same value as tile_value<T, M_SATD_*>.
 using xmi::s16x2;
 
+// swz: row r is read from a + ((r ^ swz) * n). A Hadamard transform of rows permuted by r -> r ^ swz is the transform of
+// the rows in order with some output rows negated (its rows are characters of the group (Z2)^k: h(i, j ^ g) = h(i, j)
+// h(i, g)), so the sum of magnitudes does not change; callers use it to spread their LDS reads over the banks.
 template <int T, int METRIC>
-__device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t *b, int n)
+__device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t *b, int n, int swz = 0)
 {
     constexpr int P = T / 2;                  // column pairs per row
     s16x2 d[T][P];
@@ -91,7 +94,7 @@ __device__ __forceinline__ u32 tile_satd_packed(const uint8_t *a, const uint8_t 
     for (int r = 0; r < T; r++) {
         u32 wa[T / 4], wb[T / 4];
         if (T == 8) {
-            const uint2 va = *reinterpret_cast<const uint2 *>(a + r * n), vb = *reinterpret_cast<const uint2 *>(b + r * n);
+            const uint2 va = *reinterpret_cast<const uint2 *>(a + (r ^ swz) * n), vb = *reinterpret_cast<const uint2 *>(b + (r ^ swz) * n);
             wa[0] = va.x;
             wa[T / 4 - 1] = va.y;
             wb[0] = vb.x;
@@ -206,51 +209,68 @@ int launch_sum_n(int n, const uint8_t *a, const uint8_t *b, u32 *out, int count,
 }
 
 // SATD with coalesced loads: a wavefront takes 64 transform tiles (whole blocks) per step. Each lane loads 16
-// consecutive bytes of both operands per KB of the chunk and scatters them into a tile-major LDS patch (tile t at
-// t * PITCH bytes, rows of T bytes; the pitch leaves every row read and write free of bank conflicts); then
-// lane t reads tile t back and transforms it in registers as metric_kernel does.
+// consecutive bytes of both operands per KB of the chunk and scatters them into a tile-major LDS patch; then lane p reads
+// the tile at position p and transforms it in registers as metric_kernel does. The tiles of a block occupy the positions
+// of that block in some order; the block sum does not care which. Bank layout (8-byte LDS stores are served in groups of
+// 16 lanes over 32 banks, 8-byte loads in groups of 16 or 32 lanes over 32 or 64 banks):
+//   8x8 tiles: 64 bytes per tile, no padding, so a tile covers half of the banks, the half chosen by the parity of its
+//     position. A store instruction writes 8 rows to each of two tiles whose indices differ by 2: tile t sits at position
+//     t ^ ((t >> 1) & 1), which gives the two different parities. With N = 64 it writes 4 rows to each of four tiles, and
+//     w(t) moves the rows of every other tile pair to slots r ^ 4. Lane p loads slot s ^ f(p) into register row s, with
+//     f different among the lanes that share banks. Both are XOR permutations of the rows, which SATD does not see
+//     (tile_satd_packed).
+//   4x4 tiles of 8x8 blocks: 16 bytes per tile, no padding: a lane's two row pairs go out as two 8-byte stores, a tile
+//     comes back as one 16-byte load; tile t sits at position t ^ ((t >> 3) & 1) so that blocks two apart use different
+//     banks. 4x4 tiles of 16x16 blocks keep a 20-byte pitch (dword stores and loads, conflict free as they are).
 template <int T, int METRIC, int N>
 __global__ void __launch_bounds__(256) satd_staged_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int count)
 {
-    constexpr int PITCH = T == 8 ? 72 : 20;
+    constexpr int PITCH = T == 8 ? 64 : N == 8 ? 16 : 20;
     constexpr int TPR = N / T, TILES = TPR * TPR;              // tiles per block row / per block
-    constexpr int CHUNK = 64 * T * T;                          // bytes per operand and step
-    constexpr int PIECES = CHUNK / 1024;                       // 16-byte pieces per lane and step
+    constexpr int SUB = T == 8 ? 1 : 4;                        // patches per loop iteration: eight 16-byte loads in flight per lane either way
+    constexpr int CHUNK = 64 * T * T;                          // bytes per operand and patch
+    constexpr int PIECES = CHUNK / 1024;                       // 16-byte pieces per lane and patch
     __shared__ __align__(16) uint8_t s_patch[4][2][64 * PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint8_t *pa = s_patch[wave][0], *pb = s_patch[wave][1];
     const size_t total = (size_t)count * N * N;
-    const size_t nchunk = (total + CHUNK - 1) / CHUNK;
+    const size_t nchunk = (total + CHUNK * SUB - 1) / (CHUNK * SUB);
+    auto wswz = [](int t) { return N == 64 ? ((t >> 2) & 1) * 4 : 0; };       // store-side row permutation of 8x8 tiles
     for (size_t c = (size_t)blockIdx.x * 4 + wave; c < nchunk; c += (size_t)gridDim.x * 4) {
-        const size_t base = c * CHUNK;
+        uint4 ra[SUB][PIECES], rb[SUB][PIECES];
+#pragma unroll
+        for (int u = 0; u < SUB; u++)
+#pragma unroll
+            for (int k = 0; k < PIECES; k++) {
+                const size_t e = (c * SUB + u) * CHUNK + k * 1024 + lane * 16;
+                if (e < total) ra[u][k] = *reinterpret_cast<const uint4 *>(a + e), rb[u][k] = *reinterpret_cast<const uint4 *>(b + e);
+            }
+#pragma unroll
+      for (int u = 0; u < SUB; u++) {
+        const size_t base = (c * SUB + u) * CHUNK;
 #pragma unroll
         for (int k = 0; k < PIECES; k++) {
-            const int o = k * 1024 + lane * 16;                // byte offset inside the chunk
+            const int o = k * 1024 + lane * 16;                // byte offset inside the patch
             if (base + o >= total) continue;
-            const uint4 va = *reinterpret_cast<const uint4 *>(a + base + o), vb = *reinterpret_cast<const uint4 *>(b + base + o);
+            const uint4 va = ra[u][k], vb = rb[u][k];
             const int bi = o / (N * N), ob = o % (N * N), row = ob / N, col = ob % N;
-            if (T == 8 && N == 8) {                            // two rows of one tile
-                const int at = bi * PITCH + row * 8;
-                *reinterpret_cast<uint2 *>(pa + at) = make_uint2(va.x, va.y);
-                *reinterpret_cast<uint2 *>(pa + at + 8) = make_uint2(va.z, va.w);
-                *reinterpret_cast<uint2 *>(pb + at) = make_uint2(vb.x, vb.y);
-                *reinterpret_cast<uint2 *>(pb + at + 8) = make_uint2(vb.z, vb.w);
+            if (T == 8 && N == 8) {                            // two rows of one tile: the patch is the chunk itself
+                *reinterpret_cast<uint4 *>(pa + o) = va;
+                *reinterpret_cast<uint4 *>(pb + o) = vb;
             } else if (T == 8) {                               // one row piece of two neighbouring tiles
-                const int at = (bi * TILES + (row / 8) * TPR + col / 8) * PITCH + (row % 8) * 8;
-                *reinterpret_cast<uint2 *>(pa + at) = make_uint2(va.x, va.y);
-                *reinterpret_cast<uint2 *>(pa + at + PITCH) = make_uint2(va.z, va.w);
-                *reinterpret_cast<uint2 *>(pb + at) = make_uint2(vb.x, vb.y);
-                *reinterpret_cast<uint2 *>(pb + at + PITCH) = make_uint2(vb.z, vb.w);
+                const int t = bi * TILES + (row / 8) * TPR + col / 8, flip = (t >> 1) & 1;      // t is even
+                const int slot = ((row % 8) ^ wswz(t)) * 8, at0 = (t ^ flip) * PITCH + slot, at1 = ((t + 1) ^ flip) * PITCH + slot;
+                *reinterpret_cast<uint2 *>(pa + at0) = make_uint2(va.x, va.y);
+                *reinterpret_cast<uint2 *>(pa + at1) = make_uint2(va.z, va.w);
+                *reinterpret_cast<uint2 *>(pb + at0) = make_uint2(vb.x, vb.y);
+                *reinterpret_cast<uint2 *>(pb + at1) = make_uint2(vb.z, vb.w);
             } else if (N == 8) {                               // 4x4 tiles of an 8x8 block: two rows x two tiles
-                const int at = (bi * TILES + (row / 4) * TPR) * PITCH + (row % 4) * 4;
-                *reinterpret_cast<u32 *>(pa + at) = va.x;
-                *reinterpret_cast<u32 *>(pa + at + PITCH) = va.y;
-                *reinterpret_cast<u32 *>(pa + at + 4) = va.z;
-                *reinterpret_cast<u32 *>(pa + at + PITCH + 4) = va.w;
-                *reinterpret_cast<u32 *>(pb + at) = vb.x;
-                *reinterpret_cast<u32 *>(pb + at + PITCH) = vb.y;
-                *reinterpret_cast<u32 *>(pb + at + 4) = vb.z;
-                *reinterpret_cast<u32 *>(pb + at + PITCH + 4) = vb.w;
+                const int t = bi * TILES + (row / 4) * TPR, flip = (t >> 3) & 1;                // t is even
+                const int at0 = (t ^ flip) * PITCH + (row % 4) * 4, at1 = ((t + 1) ^ flip) * PITCH + (row % 4) * 4;
+                *reinterpret_cast<uint2 *>(pa + at0) = make_uint2(va.x, va.z);
+                *reinterpret_cast<uint2 *>(pa + at1) = make_uint2(va.y, va.w);
+                *reinterpret_cast<uint2 *>(pb + at0) = make_uint2(vb.x, vb.z);
+                *reinterpret_cast<uint2 *>(pb + at1) = make_uint2(vb.y, vb.w);
             } else {                                           // 4x4 tiles of a 16x16 block: one row x four tiles
                 const int at = (bi * TILES + (row / 4) * TPR) * PITCH + (row % 4) * 4;
                 *reinterpret_cast<u32 *>(pa + at) = va.x;
@@ -264,18 +284,55 @@ __global__ void __launch_bounds__(256) satd_staged_kernel(const uint8_t *a, cons
             }
         }
         __builtin_amdgcn_wave_barrier();
-        u32 v = tile_satd_packed<T, METRIC>(pa + lane * PITCH, pb + lane * PITCH, T);
+        u32 v = tile_satd_packed<T, METRIC>(pa + lane * PITCH, pb + lane * PITCH, T, T == 8 ? ((lane >> 1) & 7) ^ ((lane >> 4) & 1) : 0);
         __builtin_amdgcn_wave_barrier();
         v = (u32)group_sum_to_last_lane<TILES>((int)v);
         const size_t blk = (base + (size_t)lane * T * T) / ((size_t)N * N);
         if ((lane & (TILES - 1)) == TILES - 1 && blk < (size_t)count) out[blk] = METRIC == M_SATD_X264 ? v >> 1 : v;
+      }
     }
+}
+
+// 4x4 blocks: a tile is 16 consecutive bytes, so a lane's 16-byte load is its tile. Eight tiles per lane and iteration (sixteen
+// loads in flight), grid-stride: a one-tile-per-thread launch is a stream of very short wavefronts and reads 15 % slower.
+template <int METRIC>
+__global__ void __launch_bounds__(256) satd4_kernel(const uint8_t *a, const uint8_t *b, u32 *out, int count)
+{
+    constexpr int K = 8;            // tiles per lane and iteration
+    const int lane = threadIdx.x & 63;
+    const size_t n = (size_t)count, nwaves = (size_t)gridDim.x * 4;
+    for (size_t t0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 * K); t0 < n; t0 += nwaves * (64 * K)) {
+        uint4 va[K], vb[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t t = t0 + k * 64 + lane;
+            va[k] = vb[k] = make_uint4(0, 0, 0, 0);
+            if (t < n) va[k] = *reinterpret_cast<const uint4 *>(a + t * 16), vb[k] = *reinterpret_cast<const uint4 *>(b + t * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const size_t t = t0 + k * 64 + lane;
+            const u32 v = tile_satd_packed<4, METRIC>(reinterpret_cast<const uint8_t *>(&va[k]), reinterpret_cast<const uint8_t *>(&vb[k]), 4);
+            if (t < n) out[t] = METRIC == M_SATD_X264 ? v >> 1 : v;
+        }
+    }
+}
+
+template <int METRIC>
+int launch_satd4(const uint8_t *a, const uint8_t *b, u32 *out, int count, hipStream_t st)
+{
+    const size_t iters = ((size_t)count + 511) / 512;
+    const unsigned blocks = (unsigned)((iters + 3) / 4 < 16384 ? (iters + 3) / 4 : 16384);
+    hipLaunchKernelGGL((satd4_kernel<METRIC>), dim3(blocks), dim3(256), 0, st, a, b, out, count);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
 }
 
 template <int T, int METRIC, int N>
 int launch_staged(const uint8_t *a, const uint8_t *b, u32 *out, int count, hipStream_t st)
 {
-    const size_t nchunk = ((size_t)count * N * N + 64 * T * T - 1) / (64 * T * T);
+    constexpr size_t per_iter = (size_t)64 * T * T * (T == 8 ? 1 : 4);
+    const size_t nchunk = ((size_t)count * N * N + per_iter - 1) / per_iter;
     const unsigned blocks = (unsigned)((nchunk + 3) / 4 < 8192 ? (nchunk + 3) / 4 : 8192);
     hipLaunchKernelGGL((satd_staged_kernel<T, METRIC, N>), dim3(blocks), dim3(256), 0, st, a, b, out, count);
     XMI_HIP(hipGetLastError());
@@ -317,6 +374,8 @@ extern "C" int xmi_block_metric_batch_dev(int metric, int n, int count, const ui
         if (metric == XMI_METRIC_SATD_HM && n == 16) return launch_staged<8, M_SATD_HM, 16>(d_a, d_b, d_out, count, st);
         if (metric == XMI_METRIC_SATD_HM && n == 32) return launch_staged<8, M_SATD_HM, 32>(d_a, d_b, d_out, count, st);
         if (metric == XMI_METRIC_SATD_HM && n == 64) return launch_staged<8, M_SATD_HM, 64>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_X264 && n == 4) return launch_satd4<M_SATD_X264>(d_a, d_b, d_out, count, st);
+        if (metric == XMI_METRIC_SATD_HM && n == 4) return launch_satd4<M_SATD_HM>(d_a, d_b, d_out, count, st);
         if (metric == XMI_METRIC_SATD_X264 && n == 8) return launch_staged<4, M_SATD_X264, 8>(d_a, d_b, d_out, count, st);
         if (metric == XMI_METRIC_SATD_X264 && n == 16) return launch_staged<4, M_SATD_X264, 16>(d_a, d_b, d_out, count, st);
     }
