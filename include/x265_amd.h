@@ -208,6 +208,15 @@ typedef struct xmi_intra_result {
 } xmi_intra_result;
 int xmi_intra_search_batch_dev(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_samples,
                                const xmi_intra_request *d_req, int n, xmi_intra_result *d_res, void *stream);
+/* The step in front of the search, src/encode.cpp:3965-3974 (availability) and :4010-4015 (samples): for every request
+ * (x0, y0, size filled in) the 4*size+1 neighbouring samples out of the reconstruction plane d_rec (width x height, rows
+ * rec_stride apart) into row i of d_ref_samples, and the availability bits into the request's valids, from d_coded: one
+ * byte per 4x4 unit of the picture (rows coded_stride apart), nonzero where the unit is reconstructed - what the
+ * reference asks of its mode cache (aucModeY != MODE_INVALID). A segment is available when its first unit is (bottom-left:
+ * the unit under the left column; top-right: the unit right of the top row), as in the reference; units outside the
+ * picture are not. Samples of unavailable segments are written as 0x80; the search pads over them (xPaddingRef). */
+int xmi_intra_gather_dev(const uint8_t *d_rec, int rec_stride, int width, int height, const uint8_t *d_coded, int coded_stride,
+                         xmi_intra_request *d_req, int n, uint8_t *d_ref_samples, void *stream);
 
 /* ---- intra chroma mode search --------------------------------------------------------------------
  * The candidate loop of xEncodeChromaCU (src/encode.cpp:4326-4365) for a batch of CUs: candidates planar, vertical (26),

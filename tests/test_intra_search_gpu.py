@@ -135,6 +135,79 @@ def test_intra_search_replays_encoder_trace(L):
             assert res[i].best_mode == int(np.argmin(cost)) and res[i].best_cost == cost.min()
 
 
+def test_neighbour_gather_feeds_the_search(L):
+    """xmi_intra_gather_dev on the searches of tests/golden/intra_trace.npz: every PU is placed in a picture whose
+    reconstruction holds the samples the reference had around it (raw, as recorded before xPaddingRef) and whose map of
+    reconstructed 4x4 units says what the reference's mode cache said (valids). The kernel must return those availability
+    bits and those samples for the available segments, 0x80 elsewhere, and the search run on its output must give the
+    recorded SATDs. PUs in the picture's corners and on its edges cover neighbours outside the picture."""
+    torch = pytest.importorskip("torch")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "intra_trace.npz"))
+    for n in (4, 8, 16, 32):
+        t = f"n{n}_"
+        src, raw, want, valids = g[t + "src"], g[t + "raw"], g[t + "satd"], g[t + "valids"]
+        nc, per_row, cell = len(src), 32, 96                       # one PU per 96x96 cell, at (4, 4) inside it
+        rows = (nc + per_row - 1) // per_row
+        w, h = per_row * cell, rows * cell
+        frame = np.zeros((h, w), np.uint8)
+        rec = np.full((h, w), 0x11, np.uint8)
+        coded = np.zeros((h // 4, w // 4), np.uint8)
+        reqs = (capi.IntraRequest * nc)()
+        for i in range(nc):
+            y0, x0 = (i // per_row) * cell + 4, (i % per_row) * cell + 4
+            frame[y0:y0 + n, x0:x0 + n] = src[i]
+            rec[y0:y0 + 2 * n, x0 - 1] = raw[i][:2 * n][::-1]
+            rec[y0 - 1, x0 - 1:x0 + 2 * n] = raw[i][2 * n:]
+            v = int(valids[i])
+            for bit, (ux, uy) in enumerate(((x0 - 4, y0 + n), (x0 - 4, y0), (x0 - 4, y0 - 4), (x0, y0 - 4), (x0 + n, y0 - 4))):
+                coded[uy // 4, ux // 4] = (v >> bit) & 1
+            rq = reqs[i]
+            rq.x0, rq.y0, rq.size, rq.valids = x0, y0, n, 0xff
+            rq.strong_smoothing = int(g[t + "strong"][i])
+            rq.mpm[0], rq.mpm[1], rq.mpm[2] = 0, 1, 26
+            rq.sqrt_lambda = 4.7
+        d_rec, d_coded = torch.from_numpy(rec).cuda(), torch.from_numpy(coded).cuda()
+        d_req = torch.from_numpy(np.frombuffer(reqs, np.uint8).copy()).cuda()
+        d_refs = torch.zeros((nc, capi.INTRA_REF_PITCH), dtype=torch.uint8, device="cuda")
+        capi.check(L.xmi_intra_gather_dev(d_rec.data_ptr(), w, w, h, d_coded.data_ptr(), w // 4, d_req.data_ptr(), nc, d_refs.data_ptr(), None))
+        torch.cuda.synchronize()
+        got_req = (capi.IntraRequest * nc).from_buffer_copy(d_req.cpu().numpy().tobytes())
+        refs = d_refs.cpu().numpy()
+        seg = [(0, n), (n, 2 * n), (2 * n, 2 * n + 1), (2 * n + 1, 3 * n + 1), (3 * n + 1, 4 * n + 1)]
+        for i in range(nc):
+            assert got_req[i].valids == int(valids[i]), f"{n}x{n} search {i}"
+            for bit, (lo, hi) in enumerate(seg):
+                expect = raw[i][lo:hi] if (int(valids[i]) >> bit) & 1 else np.full(hi - lo, 0x80, np.uint8)
+                np.testing.assert_array_equal(refs[i, lo:hi], expect, err_msg=f"{n}x{n} search {i} segment {bit}")
+        res = run_gpu(L, frame, got_req, refs)
+        for i in range(nc):
+            np.testing.assert_array_equal(np.array(res[i].satd[:], np.uint32), want[i], err_msg=f"{n}x{n} search {i}")
+    # neighbours outside the picture: a 64x64 picture, everything reconstructed
+    w = h = 64
+    rng = np.random.default_rng(5)
+    rec = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    coded = np.ones((h // 4, w // 4), np.uint8)
+    cases = [(0, 0, 32, 0), (32, 0, 32, 0b00011), (0, 32, 32, 0b11000), (32, 32, 32, 0b01110), (16, 16, 16, 0b11111), (48, 48, 16, 0b01110),
+             (60, 4, 4, 0b01111), (4, 60, 4, 0b11110)]
+    reqs = (capi.IntraRequest * len(cases))()
+    for i, (x0, y0, n, _) in enumerate(cases):
+        reqs[i].x0, reqs[i].y0, reqs[i].size = x0, y0, n
+    d_rec, d_coded = torch.from_numpy(rec).cuda(), torch.from_numpy(coded).cuda()
+    d_req = torch.from_numpy(np.frombuffer(reqs, np.uint8).copy()).cuda()
+    d_refs = torch.zeros((len(cases), capi.INTRA_REF_PITCH), dtype=torch.uint8, device="cuda")
+    capi.check(L.xmi_intra_gather_dev(d_rec.data_ptr(), w, w, h, d_coded.data_ptr(), w // 4, d_req.data_ptr(), len(cases), d_refs.data_ptr(), None))
+    torch.cuda.synchronize()
+    got_req = (capi.IntraRequest * len(cases)).from_buffer_copy(d_req.cpu().numpy().tobytes())
+    refs = d_refs.cpu().numpy()
+    for i, (x0, y0, n, v) in enumerate(cases):
+        assert got_req[i].valids == v, f"case {i}"
+        for k in range(4 * n + 1):
+            x, y = (x0 - 1, y0 + 2 * n - 1 - k) if k < 2 * n else (x0 - 1 + k - 2 * n, y0 - 1)
+            bit = 0 if k < n else 1 if k < 2 * n else 2 if k == 2 * n else 3 if k <= 3 * n else 4
+            inside = 0 <= x < w and 0 <= y < h
+            assert refs[i, k] == (rec[y, x] if (v >> bit) & 1 and inside else 0x80), f"case {i} sample {k}"
+
+
 def test_percall_intra_search_equals_batch(L):
     """xmi_intra_search (host pointers, source rows 64 bytes apart as in the encoder's CTU cache) returns what the
     batch entry point returns for the same search."""

@@ -127,6 +127,9 @@ def load():
         L.xmi_frame_intra_search.argtypes = [vp, vp, vp, i, vp]
         L.xmi_frame_tu_chain.restype = i
         L.xmi_frame_tu_chain.argtypes = [vp, i, i, vp, vp, vp, vp, vp, vp, vp]
+    if hasattr(L, "xmi_intra_gather_dev"):
+        L.xmi_intra_gather_dev.restype = i
+        L.xmi_intra_gather_dev.argtypes = [vp, i, i, i, vp, i, vp, i, vp, vp]
     if hasattr(L, "xmi_intra_search_batch_dev"):
         L.xmi_intra_search_batch_dev.restype = i
         L.xmi_intra_search_batch_dev.argtypes = [vp, i, vp, vp, i, vp, vp]

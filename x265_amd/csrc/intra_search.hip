@@ -419,6 +419,65 @@ int launch_search(const uint8_t *d_src, int src_stride, const uint8_t *d_ref_sam
 
 }  // namespace
 
+// ---- neighbour gather -------------------------------------------------------------------------------------------
+// One wavefront per PU: the 4 size + 1 neighbouring samples in the order of src/encode.cpp:4010-4015 (left column from
+// the bottom up, top-left, top row, top-right) out of the reconstruction plane, and the five availability bits of
+// :3965-3974 out of the map of reconstructed 4x4 units. Samples of a segment that is not available are set to 0x80 (the
+// reference leaves whatever its cache holds there and xPaddingRef overwrites them).
+namespace {
+struct GatherParams {
+    const uint8_t *rec;
+    const uint8_t *coded;
+    xmi_intra_request *req;
+    uint8_t *refs;
+    int stride, width, height, coded_stride, n;
+};
+
+__global__ void __launch_bounds__(256) intra_gather_kernel(const GatherParams p)
+{
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (idx >= p.n) return;
+    const xmi_intra_request rq = p.req[idx];
+    const int n = rq.size, x0 = rq.x0, y0 = rq.y0;
+    auto unit = [&](int x, int y) -> bool {       // is the 4x4 unit that holds sample (x, y) reconstructed?
+        return x >= 0 && y >= 0 && x < p.width && y < p.height && p.coded[(size_t)(y >> 2) * p.coded_stride + (x >> 2)] != 0;
+    };
+    const bool lb = unit(x0 - 1, y0 + n), l = unit(x0 - 1, y0), lt = unit(x0 - 1, y0 - 1), t = unit(x0, y0 - 1), tr = unit(x0 + n, y0 - 1);
+    uint8_t *out = p.refs + (size_t)idx * XMI_INTRA_REF_PITCH;
+    for (int i = lane; i < 4 * n + 1; i += 64) {
+        int x, y;
+        bool ok;
+        if (i < 2 * n) {
+            x = x0 - 1, y = y0 + 2 * n - 1 - i;
+            ok = i < n ? lb : l;
+        } else {
+            x = x0 - 1 + (i - 2 * n), y = y0 - 1;
+            ok = i == 2 * n ? lt : i <= 3 * n ? t : tr;
+        }
+        // a segment is flagged by its first unit; the part of it that leaves the picture reads as 0x80
+        ok = ok && x >= 0 && y >= 0 && x < p.width && y < p.height;
+        out[i] = ok ? p.rec[(size_t)y * p.stride + x] : (uint8_t)0x80;
+    }
+    if (lane == 0) p.req[idx].valids = (uint8_t)((lb ? 1 : 0) | (l ? 2 : 0) | (lt ? 4 : 0) | (t ? 8 : 0) | (tr ? 16 : 0));
+}
+}  // namespace
+
+extern "C" int xmi_intra_gather_dev(const uint8_t *d_rec, int rec_stride, int width, int height, const uint8_t *d_coded, int coded_stride,
+                                    xmi_intra_request *d_req, int n, uint8_t *d_ref_samples, void *stream)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(n >= 0, "xmi_intra_gather_dev: negative count");
+    if (n == 0) return XMI_OK;
+    XMI_ARG(d_rec && d_coded && d_req && d_ref_samples, "xmi_intra_gather_dev: null argument");
+    XMI_ARG(width > 0 && height > 0 && width % 4 == 0 && height % 4 == 0 && rec_stride >= width && coded_stride >= width / 4,
+            "xmi_intra_gather_dev: %dx%d, strides %d / %d", width, height, rec_stride, coded_stride);
+    GatherParams p = { d_rec, d_coded, d_req, d_ref_samples, rec_stride, width, height, coded_stride, n };
+    hipLaunchKernelGGL(intra_gather_kernel, dim3((n + 3) / 4), dim3(256), 0, xmi::as_stream(stream), p);
+    XMI_HIP(hipGetLastError());
+    return XMI_OK;
+}
+
 extern "C" int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_intra_pred_request *d_req, int n, uint8_t *d_pred, void *stream)
 {
     int rc = xmi::require_device();
