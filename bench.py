@@ -310,18 +310,32 @@ def main():
     kern_ms = sorted(kern_ms_raw)
     kern_avg_ms = sum(kern_ms) / len(kern_ms)
 
-    # end-of-segment exchange (outside the timed region): one statistics record per processed frame, gathered
-    # on every rank - the only collective of the path (RCCL when world > 1)
+    # end-of-segment exchange (outside the timed region), the only collective of the path (RCCL when world > 1): one
+    # statistics record per processed frame, gathered on every rank. No bitstream exists in this loop, so the column
+    # that carries coded bits in an encode (tools/encode_segments.py) carries the frame's matching cost here: the sum
+    # over its CTUs of the smallest 64x64 SAD in the window, read back from the surface the step produced. A second
+    # set of records carries the kernel time of every step.
     from x265_amd import segments
+    pitch64, nmain = layout.row_pitch(R, 3), nctu * nmv1 * layout.row_pitch(R, 3)
+    cost = {}
+    for t in range(1, args.frames):
+        step(t - 1)
+        torch.cuda.synchronize()
+        main = s64[:nmain].view(nctu, nmv1, pitch64)[:, :, :2 * R].reshape(nctu, -1).min(dim=1).values
+        edge = s64[nmain:nmain + nctu * nmv1].view(nctu, nmv1).min(dim=1).values
+        cost[t] = int(torch.minimum(main, edge).sum().item())
     fr = np.arange(args.steps) + rank * args.steps
-    rec = segments.make_records(fr, np.ones(args.steps), np.full(args.steps, 32), np.zeros(args.steps),
-                                np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
+    qp = 32
+    rec = segments.make_records(fr, np.ones(args.steps), np.full(args.steps, qp), np.full(args.steps, 0.578 * 2 ** ((qp - 12) / 3.0)),
+                                np.zeros(args.steps), np.array([cost[1 + i % (args.frames - 1)] for i in range(args.steps)], np.float64))
     allrec = segments.gather_records(rec, device=comm_dev)
-    assert allrec.shape[0] == args.steps * world
+    assert allrec.shape[0] == args.steps * world and bool((allrec[:, 5] > 0).all())
+    trec = segments.make_records(fr, np.ones(args.steps), np.zeros(args.steps), np.zeros(args.steps), np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
+    alltime = segments.gather_records(trec, device=comm_dev)
     # per-rank view of the same records: average kernel time and the device each rank ran on
     per_rank = []
     for r in range(world):
-        mine = allrec[(allrec[:, 0] >= r * args.steps) & (allrec[:, 0] < (r + 1) * args.steps)]
+        mine = alltime[(alltime[:, 0] >= r * args.steps) & (alltime[:, 0] < (r + 1) * args.steps)]
         per_rank.append(round(float(mine[:, 5].mean()) * 1e-3, 4))
     devs = [None] * world
     if world > 1:
@@ -344,7 +358,8 @@ def main():
             "config": {"workload": f"{args.width}x{args.height} 8-bit luma (coded {w}x{h}, {nctu} CTUs), IPPP P-frame SAD pyramid, "
                                    f"search range {R} ({nmv1}x{nmv1} integer MVs), {args.frames} resident frames per GPU",
                        "cands_per_step": cands, "frames_per_s": round(args.steps * world / elapsed, 2),
-                       "parallelism": f"gop-segments x{world}", "rank_devices": devs, "rank_kernel_ms_avg": per_rank},
+                       "parallelism": f"gop-segments x{world}", "rank_devices": devs, "rank_kernel_ms_avg": per_rank,
+                       "gathered_records": int(allrec.shape[0]), "matching_cost_per_frame_mean": round(float(allrec[:, 5].mean()), 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(w, h, R),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),

@@ -36,3 +36,31 @@ def test_bench_line():
     assert r["traffic"] is None or r["traffic"] >= 0.95 * r["algorithmic_bytes_per_launch"]
     for name, row in d["satd"].items():
         assert 0.2 < row["frac"] < 1.0, (name, row)
+
+
+def run_ranks(extra_env=None):
+    env = dict(os.environ, **(extra_env or {}))
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--settle-ms", "0",
+                          "--no-cpu-baseline", "--headline-only"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_share_this_gpu_over_gloo():
+    """`bench.py --gpus 2` started by hand launches its two ranks itself; with XMI_BENCH_BACKEND=gloo both use the one GPU
+    of this box: the line must carry the records of both ranks and say that the device is shared."""
+    d = run_ranks({"XMI_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["config"]["gathered_records"] == 12 and len(d["config"]["rank_kernel_ms_avg"]) == 2
+    assert all("shared" in x for x in d["config"]["rank_devices"])
+    assert d["config"]["matching_cost_per_frame_mean"] > 0
+
+
+def test_two_ranks_over_rccl_on_two_gpus():
+    """The same with the default backend (nccl = RCCL) where two devices exist: one device per rank."""
+    torch = pytest.importorskip("torch")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU on this box: the RCCL launch needs two")
+    d = run_ranks()
+    assert d["n_gpus"] == 2 and d["config"]["rank_devices"] == ["cuda:0", "cuda:1"] and d["config"]["gathered_records"] == 12
