@@ -329,7 +329,7 @@ def main():
     rec = segments.make_records(fr, np.ones(args.steps), np.full(args.steps, qp), np.full(args.steps, 0.578 * 2 ** ((qp - 12) / 3.0)),
                                 np.zeros(args.steps), np.array([cost[1 + i % (args.frames - 1)] for i in range(args.steps)], np.float64))
     allrec = segments.gather_records(rec, device=comm_dev)
-    assert allrec.shape[0] == args.steps * world and bool((allrec[:, 5] > 0).all())
+    assert allrec.shape[0] == args.steps * world
     trec = segments.make_records(fr, np.ones(args.steps), np.zeros(args.steps), np.zeros(args.steps), np.zeros(args.steps), np.array(kern_ms_raw) * 1e3)
     alltime = segments.gather_records(trec, device=comm_dev)
     # per-rank view of the same records: average kernel time and the device each rank ran on

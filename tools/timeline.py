@@ -42,6 +42,10 @@ rs, re_ = t[:, 4] - r0, t[:, 5] - r0
 first = dur < np.median(dur)
 qsad_cycles = 8 * 136 * 64 * 16 // 4     # per SIMD for one workgroup: 8 wavefronts x 136 steps x 64 qsad x 16 cycles, over 4 SIMDs
 print(f"kernel span {re_.max() / 100:.1f} us; workgroups start within {rs.max() / 100:.2f} us")
+q = [0, 10, 25, 50, 75, 90, 100]
+print("start times, us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(rs, q)))
+print("end times,   us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(re_, q)))
+print("durations,   us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(re_ - rs, q)))
 for name, m in (("first workgroup of a CU", first), ("second workgroup of a CU", ~first)):
     print(f"{name}: n {m.sum()}  ends at {re_[m].mean() / 100:.1f} us  core cycles: total {int(dur[m].mean())}  staging {int(stg[m].mean())}  "
           f"main loop {int(loop[m].mean())}  dx=+R pass {int(tail[m].mean())}  core clock {float((dur[m] / ((t[m, 5] - t[m, 4]) * 10.0)).mean()):.3f} GHz")

@@ -58,6 +58,8 @@ constexpr int level_blocks(int level) { return xmi::surface_level_blocks(level);
 constexpr int row_pitch(int R, int level) { return xmi::surface_row_pitch(R, level); }
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 as_u32x2(u64 v) { return __builtin_bit_cast(u32x2, v); }
 
 template <int CTRL>
 __device__ __forceinline__ u32 dpp_mov(u32 x)
@@ -83,16 +85,20 @@ __device__ __forceinline__ u32 quad_reduce_scatter(u32 lo, u32 hi, int b)
 __device__ unsigned long long g_timeline[4096 * 6];   // per workgroup: s_memtime at start / staged / main loop done / end, s_memrealtime at start / end
 #endif
 
-// Workgroup = one CTU x one band of dy rows; R/8 wavefronts.
-// lane = q*16 + gl*4 + b: q = 32x32 quadrant (raster), b = 16x16 block inside it (raster), gl = dx group of the wavefront.
-// Up to R = 64 a lane keeps the 16 rows of its 16x16 block of the current CTU in 64 VGPRs (about 190 in all: two
-// wavefronts per SIMD, one workgroup of R = 64 per CU at a time); with R = 128 a workgroup is 16 wavefronts, which leaves
-// 128 VGPRs each, and the rows are read from LDS in every step instead. Measured at 1080p, R = 64, steady state:
-// 380 us per launch with the LDS reads, 359 us with the rows in registers.
-template <int R>
-__global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(const SadParams p)
+// Workgroup = one CTU x one band of dy rows x one slice of the dx range (blockIdx.z of SPLIT); R/8/SPLIT wavefronts, each
+// producing 16 consecutive dx. lane = q*16 + gl*4 + b: q = 32x32 quadrant (raster), b = 16x16 block inside it (raster),
+// gl = dx group of the wavefront.
+// A lane keeps the 16 rows of its 16x16 block of the current CTU in 64 VGPRs (about 190 in all: two wavefronts per SIMD).
+// SPLIT is chosen so that a workgroup is four wavefronts, one per SIMD: two workgroups share a CU, the older one has issue
+// priority and runs as if alone, the younger one fills its gaps and the staging / last-column phases of its neighbours.
+// Measured at 1080p, R = 64, steady state: rows re-read from LDS in every step (128 VGPRs, 8 wavefronts) 380 us per
+// launch; rows in registers, 8 wavefronts (one workgroup per CU at a time, its last wavefronts run alone) 359 us.
+template <int R, int SPLIT>
+__global__ void __launch_bounds__(8 * R / SPLIT, 2) sad_surface_kernel(const SadParams p)
 {
-    constexpr bool kCurInRegs = R <= 64;
+    constexpr bool kCurInRegs = true;
+    constexpr int NT = 8 * R / SPLIT;                          // threads of the workgroup
+    const int part = SPLIT > 1 ? (int)blockIdx.z : 0;          // dx slice: [-R + part * 2R/SPLIT, ... + 2R/SPLIT)
     extern __shared__ __align__(16) unsigned char lds[];
     unsigned char *cur_lds = lds;
     unsigned char *ref_lds = lds + kCurLdsBytes;
@@ -101,20 +107,21 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
 #ifdef XMI_EXP_TIMELINE
     const unsigned long long t_start = __builtin_amdgcn_s_memtime(), r_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr int nwaves = R / 8;
+    constexpr int nwaves = R / 8 / SPLIT;
+    const int wave_g = part * nwaves + wave;                   // index of the wavefront's 16-dx tile in the row
     const int ctu = p.ctu_begin + blockIdx.x;
     const int cx0 = (ctu % p.wc) * 64, cy0 = (ctu / p.wc) * 64;
     constexpr int nmv = 2 * R + 1;
 
-    // window geometry: rows [dy band] + 63, columns [-R, R+67] (the last 4 bytes serve the dx = +R column)
+    // window geometry: rows [dy band] + 63, columns [first dx of the slice, last dx + 67] (the last 4 bytes serve the dx = +R column)
     const int seg_base = (int)blockIdx.y * p.seg_len;          // first dy index of this workgroup
     const int ndy = min(p.seg_len, nmv - seg_base);            // dy rows of this workgroup
     const int valid_rows = ndy + 63;
-    constexpr int wb_dw = R / 2 + 17;                          // window width in dwords (odd: conflict-free pitch)
+    constexpr int wb_dw = R / 2 / SPLIT + 17;                  // window width in dwords (odd: conflict-free pitch)
     constexpr int rls = wb_dw * 4;
 
     // ---- stage current CTU: cur_lds[(r16*16 + z)*16 + byte], z = q*4 + b ----
-    for (int idx = tid; idx < 1024; idx += 8 * R) {
+    for (int idx = tid; idx < 1024; idx += NT) {
         const int row = idx >> 4, cd = idx & 15;
         const int bx16 = cd >> 2, by16 = row >> 4, r16 = row & 15;
         const int zz = ((((by16 >> 1) * 2 + (bx16 >> 1)) << 2) | ((by16 & 1) * 2 + (bx16 & 1)));
@@ -123,19 +130,19 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
     }
     // ---- stage the reference window; flat dword index, 8 independent loads in flight per thread ----
     {
-        const uint8_t *src0 = p.ref + (ptrdiff_t)(cy0 - R + seg_base) * p.ref_stride + cx0 - R;
+        const uint8_t *src0 = p.ref + (ptrdiff_t)(cy0 - R + seg_base) * p.ref_stride + cx0 - R + part * (2 * R / SPLIT);
         const int total = valid_rows * wb_dw;
-        for (int base = tid; base < total; base += 8 * (8 * R)) {
+        for (int base = tid; base < total; base += 8 * NT) {
             u32 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int idx = base + k * (8 * R);
+                const int idx = base + k * NT;
                 const int row = idx / wb_dw, col = idx - row * wb_dw;
                 v[k] = idx < total ? *reinterpret_cast<const u32 *>(src0 + (ptrdiff_t)row * p.ref_stride + col * 4) : 0u;
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
-                const int idx = base + k * (8 * R);
+                const int idx = base + k * NT;
                 const int row = idx / wb_dw, col = idx - row * wb_dw;
                 if (idx < total) *reinterpret_cast<u32 *>(ref_lds + row * rls + col * 4) = v[k];
             }
@@ -147,7 +154,7 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
     const int b = lane & 3, gl = (lane >> 2) & 3, q = lane >> 4;
     const int z = q * 4 + b;
     const int bx16 = (q & 1) * 2 + (b & 1), by16 = (q >> 1) * 2 + (b >> 1);
-    const int g = wave * 4 + gl;                              // dx group: dx = -R + 4g .. +3
+    const int g = wave * 4 + gl;                              // dx group inside the slice: dx = first dx of the slice + 4g .. +3
     const int nsteps = (ndy + 7 + 7) & ~7;
     const unsigned char *ref_lane = ref_lds + (by16 * 16) * rls + (bx16 * 4 + g) * 4;
     const u32 xor32_addr = (u32)((lane ^ 32) * 4);            // ds_bpermute address of the lane 32 away
@@ -159,10 +166,16 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
     char *o16 = reinterpret_cast<char *>(p.sad16 + row0 * ROW16);
     char *o32 = reinterpret_cast<char *>(p.sad32 + row0 * ROW32);
     char *o64 = reinterpret_cast<char *>(p.sad64 + row0 * ROW64);
-    const u32 off8 = (u32)(wave * 1024 + z * 16 + gl * 4) * 2u;   // child c adds c*512 bytes
-    const u32 off16 = (u32)(wave * 256 + z * 16 + gl * 4) * 2u;
-    const u32 off32 = (u32)(wave * 64 + q * 16 + gl * 4 + b) * 4u; // lane b stores the sum for dx = 4*gl + b
-    const u32 off64 = (u32)(wave * 16 + gl * 4 + b) * 4u;
+    const u32 off8 = (u32)(wave_g * 1024 + z * 16 + gl * 4) * 2u;   // child c adds c*512 bytes
+    const u32 off16 = (u32)(wave_g * 256 + z * 16 + gl * 4) * 2u;
+    const u32 off32 = (u32)(wave_g * 64 + q * 16 + gl * 4 + b) * 4u; // lane b stores the sum for dx = 4*gl + b
+    const u32 off64 = (u32)(wave_g * 16 + gl * 4 + b) * 4u;
+
+    // buffer resources over this workgroup's rows of the four planes (at most 257 rows of 33 KiB: far below the 4 GiB range)
+    const __amdgpu_buffer_rsrc_t rs8 = __builtin_amdgcn_make_buffer_rsrc(o8, 0, ndy * (ROW8 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs16 = __builtin_amdgcn_make_buffer_rsrc(o16, 0, ndy * (ROW16 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs32 = __builtin_amdgcn_make_buffer_rsrc(o32, 0, ndy * (ROW32 * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs64 = __builtin_amdgcn_make_buffer_rsrc(o64, 0, ndy * (ROW64 * 4), 0x00020000);
 
     uint4 creg[kCurInRegs ? 16 : 1];
     if constexpr (kCurInRegs) {
@@ -244,14 +257,15 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
 #else
             if (dyl >= 0 && dyl < ndy) {
 #endif
-                char *r8 = o8 + (size_t)dyl * (ROW8 * 2);      // uniform row bases + 32-bit lane offsets
-                *reinterpret_cast<u64 *>(r8 + off8) = v0;
-                *reinterpret_cast<u64 *>(r8 + off8 + 512) = v1;
-                *reinterpret_cast<u64 *>(r8 + off8 + 1024) = v2;
-                *reinterpret_cast<u64 *>(r8 + off8 + 1536) = v3;
-                *reinterpret_cast<u64 *>(o16 + (size_t)dyl * (ROW16 * 2) + off16) = v16;
-                *reinterpret_cast<u32 *>(o32 + (size_t)dyl * (ROW32 * 4) + off32) = r32;
-                if (q == 0) *reinterpret_cast<u32 *>(o64 + (size_t)dyl * (ROW64 * 4) + off64) = t64;
+                // buffer stores: the row offset is uniform (an SGPR), the lane offset a loop-invariant VGPR: no address arithmetic
+                const int dyo = __builtin_amdgcn_readfirstlane(dyl);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v0), rs8, off8, dyo * (ROW8 * 2), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v1), rs8, off8 + 512, dyo * (ROW8 * 2), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v2), rs8, off8 + 1024, dyo * (ROW8 * 2), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v3), rs8, off8 + 1536, dyo * (ROW8 * 2), 0);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v16), rs16, off16, dyo * (ROW16 * 2), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(r32, rs32, off32, dyo * (ROW32 * 4), 0);
+                if (q == 0) __builtin_amdgcn_raw_buffer_store_b32(t64, rs64, off64, dyo * (ROW64 * 4), 0);
             }
         }
     };
@@ -273,10 +287,10 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
 #endif
     // ---- the dx = +R column: one more than a multiple of 4, so it gets a plain v_sad_u8 pass of its own.
     // lane (z, gl) of wavefront w takes the band rows d = (4w + gl), +4*nwaves, ...; the reference bytes of
-    // dx = +R start at window dword R/2 + 4*bx16, already staged.
-    {
+    // dx = +R start at dword R/2/SPLIT + 4*bx16 of the last slice's window, already staged.
+    if (part == SPLIT - 1) {
         constexpr int nlan = 4 * nwaves;
-        const unsigned char *ref_e = ref_lds + (by16 * 16) * rls + (R / 2 + bx16 * 4) * 4;
+        const unsigned char *ref_e = ref_lds + (by16 * 16) * rls + (R / 2 / SPLIT + bx16 * 4) * 4;
         const unsigned char *cl = cur_lds + z * 16;
         const size_t rows_main = (size_t)p.nctu_total * nmv;
         uint16_t *e8 = p.sad8 + rows_main * ROW8 + row0 * 64;
@@ -314,8 +328,11 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
         }
     }
 #ifdef XMI_EXP_TIMELINE
-    if (tid == 0 && blockIdx.x < 4096) {
-        unsigned long long *t = g_timeline + blockIdx.x * 6;
+#ifdef XMI_EXP_TIMELINE_DRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the end stamps then include this wavefront's outstanding stores
+#endif
+    if (tid == 0 && blockIdx.x * SPLIT + part < 4096) {
+        unsigned long long *t = g_timeline + (blockIdx.x * SPLIT + part) * 6;
         t[0] = t_start;
         t[1] = t_staged;
         t[2] = t_loop;
@@ -326,17 +343,20 @@ __global__ void __launch_bounds__(8 * R, R <= 64 ? 2 : 4) sad_surface_kernel(con
 #endif
 }
 
+constexpr int split_of(int R) { return R >= 64 ? R / 32 : 1; }      // four wavefronts per workgroup from R = 32 on
+
 size_t lds_bytes(int R, int seg_len)
 {
     const int nsteps = (seg_len + 7 + 7) & ~7;
     const int rows = nsteps + 56;
-    return kCurLdsBytes + (size_t)rows * ((R / 2 + 17) * 4);
+    return kCurLdsBytes + (size_t)rows * ((R / 2 / split_of(R) + 17) * 4);
 }
 
 template <int R>
 int launch_surface(const SadParams &p, int n, int nseg, size_t lds, hipStream_t st)
 {
-    hipLaunchKernelGGL((sad_surface_kernel<R>), dim3(n, nseg), dim3(8 * R), lds, st, p);
+    constexpr int SPLIT = split_of(R);
+    hipLaunchKernelGGL((sad_surface_kernel<R, SPLIT>), dim3(n, nseg, SPLIT), dim3(8 * R / SPLIT), lds, st, p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
@@ -347,10 +367,10 @@ int launch_surface(const SadParams &p, int n, int nseg, size_t lds, hipStream_t 
 // binding (under the library mutex), never from a launch path, so no launch touches function attributes.
 int xmi::sad_surface_prepare_device()
 {
-    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<16, split_of(16)>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<32, split_of(32)>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<64, split_of(64)>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sad_surface_kernel<128, split_of(128)>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return XMI_OK;
 }
 
@@ -416,9 +436,9 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
     hipStream_t st = xmi::as_stream(stream);
     const int n = ctu_end - ctu_begin;
 
-    // one workgroup per CTU; split the dy range into bands when there are too few CTUs to fill 256 CUs
+    // split the dy range into bands when there are too few CTUs to give every CU its two workgroups
     int nseg = 1;
-    while (n * nseg < 256 && nseg < 8) nseg *= 2;
+    while (n * nseg * split_of(R) < 512 && nseg < 8) nseg *= 2;
     p.seg_len = (nmv + nseg - 1) / nseg;
     nseg = (nmv + p.seg_len - 1) / p.seg_len;
     const size_t lds = lds_bytes(R, p.seg_len);
