@@ -387,7 +387,9 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
  * xmi_analysis_create: width, height = coded size (multiples of 64). NULL on failure (xmi_last_error()).
  * xmi_analysis_configure: lanes (1..8) = groups the CTU rows are dealt to (row y -> lane y % lanes). Each lane batches the
  *   requests of its rows and makes its own round trips to the GPU, on a stream of its own, so the host work of one lane
- *   overlaps the GPU time of another. Results do not depend on the number of lanes. Not while a picture is in flight.
+ *   overlaps the GPU time of another. spin_us: how long the host threads of the loop poll for a result before they go to
+ *   sleep (a round trip takes about 30 us, waking a sleeping thread 10 more); 0, the default, sleeps at once and is the
+ *   choice when several handles share the host's cores. Results depend on neither. Not while a picture is in flight.
  *   (The reference has no counterpart: its -t option sets the number of row threads, src/encode.cpp:5800-5860.)
  * xmi_analysis_state : the state the reference carries from picture to picture and never resets - per CTU and depth the
  *   FAST_MD cost statistics (dSumOfRdCosts, nRdCounts, dAverageRdCosts, inc/x265.h:379-381: (height/64) x (width/64) x 5
@@ -403,7 +405,11 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
 typedef struct xmi_analysis xmi_analysis;
 xmi_analysis *xmi_analysis_create(int width, int height);
 void xmi_analysis_destroy(xmi_analysis *a);
-int xmi_analysis_configure(xmi_analysis *a, int lanes);
+int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us);
+/* Measurement aid (no counterpart in the reference): where the round trips of this handle have spent their time so far,
+ * summed over its lanes: out = { ns writing job tables, ns in the launch call, ns waiting for the GPU, ns reading results
+ * back, round trips }. What is left of a picture's wall time is the host's decision work and its thread hand-overs. */
+int xmi_analysis_timing(xmi_analysis *a, uint64_t out[5]);
 int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits);
 int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, const uint8_t *ref_y,
                            const uint8_t *ref_u, const uint8_t *ref_v, int pad, int qp, uint16_t *info0, uint8_t *info1, int16_t *mv,

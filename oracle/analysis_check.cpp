@@ -142,10 +142,11 @@ struct Handle {
 extern "C" {
 
 void *orc_analysis_create(int width, int height) { return new Handle(width, height); }
-int orc_analysis_configure(void *h, int lanes)
+int orc_analysis_configure(void *h, int lanes, int spin_us)
 {
-    if (lanes < 1 || lanes > 8) return -1;
+    if (lanes < 1 || lanes > 8 || spin_us < 0) return -1;
     static_cast<Handle *>(h)->an.lanes = lanes;
+    static_cast<Handle *>(h)->an.spin_us = spin_us;
     return 0;
 }
 void orc_analysis_destroy(void *h) { delete static_cast<Handle *>(h); }

@@ -98,7 +98,7 @@ def p(a):
 class Runner:
     """create / state / p_picture of either library, same argument lists (prefix orc_analysis_ or xmi_analysis_)."""
 
-    def __init__(self, lib, prefix, w, h, lanes=None):
+    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0):
         self.lib, self.w, self.h = lib, w, h
         self.create, self.destroy = getattr(lib, prefix + "create"), getattr(lib, prefix + "destroy")
         self.state, self.picture = getattr(lib, prefix + "state"), getattr(lib, prefix + "p_picture")
@@ -110,12 +110,12 @@ class Runner:
         self.picture.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 15
         self.handle = self.create(w, h)
         assert self.handle
-        if lanes is not None:
+        if lanes is not None or spin_us:
             conf = getattr(lib, prefix + "configure")
             conf.restype = C.c_int
-            conf.argtypes = [C.c_void_p, C.c_int]
-            rc = conf(self.handle, lanes)
-            assert rc == 0, f"configure({lanes}) returned {rc}"
+            conf.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            rc = conf(self.handle, lanes or 1, spin_us)
+            assert rc == 0, f"configure({lanes}, {spin_us}) returned {rc}"
 
     def close(self):
         self.destroy(self.handle)

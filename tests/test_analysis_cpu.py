@@ -108,10 +108,11 @@ def test_recorded_pictures_are_reproduced(lib, tag):
     check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h), tag)
 
 
-@pytest.mark.parametrize("lanes,tag", [(2, "416x240_q32_p2"), (3, "416x240_q22_p1"), (4, "416x240_q32_p7")])
-def test_row_lanes_do_not_change_the_result(lib, lanes, tag):
-    """rows dealt to several lanes, each with its own round trips to the evaluator: same picture, more calls"""
-    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes), tag)
+@pytest.mark.parametrize("lanes,spin,tag", [(2, 0, "416x240_q32_p2"), (3, 50, "416x240_q22_p1"), (4, 0, "416x240_q32_p7"), (1, 50, "416x240_q32_p1")])
+def test_row_lanes_and_polling_do_not_change_the_result(lib, lanes, spin, tag):
+    """rows dealt to several lanes, each with its own round trips to the evaluator, and waiters that poll before they
+    sleep: same picture, more calls"""
+    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin), tag)
 
 
 @needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")

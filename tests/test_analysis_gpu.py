@@ -26,9 +26,9 @@ def test_recorded_pictures_are_reproduced(L, tag):
     assert out["counters"][0] > 0
 
 
-@pytest.mark.parametrize("lanes,tag", [(1, "416x240_q32_p2"), (2, "416x240_q32_p2"), (3, "416x240_q22_p1"), (4, "416x240_q32_p7")])
-def test_row_lanes_do_not_change_the_result(L, lanes, tag):
-    check_fixture_picture(lambda w, h: T.Runner(L, "xmi_analysis_", w, h, lanes), tag)
+@pytest.mark.parametrize("lanes,spin,tag", [(1, 200, "416x240_q32_p2"), (2, 0, "416x240_q32_p2"), (3, 20, "416x240_q22_p1"), (4, 200, "416x240_q32_p7")])
+def test_row_lanes_and_polling_do_not_change_the_result(L, lanes, spin, tag):
+    check_fixture_picture(lambda w, h: T.Runner(L, "xmi_analysis_", w, h, lanes, spin), tag)
 
 
 @needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")
@@ -36,7 +36,7 @@ def test_row_lanes_do_not_change_the_result(L, lanes, tag):
                                                       (1920, 1080, 3, 27, 7, 3), (1920, 1080, 2, 22, 7, 1), (1920, 1080, 2, 37, 7, 4)])
 def test_fresh_trace_with_carried_statistics(L, tmp_path, w, h, frames, qp, seed, lanes):
     pics, _ = T.record_trace(str(tmp_path), w, h, frames, qp, seed)
-    r = T.Runner(L, "xmi_analysis_", pics[0]["w"], pics[0]["h"], lanes)
+    r = T.Runner(L, "xmi_analysis_", pics[0]["w"], pics[0]["h"], lanes, 200 if lanes in (None, 1) else 0)
     try:
         r.set_state(pics[0], pics[1])
         for k in range(1, len(pics)):
@@ -59,8 +59,8 @@ def test_bad_arguments_are_refused(L):
     assert b"multiple of 64" in L.xmi_last_error()
     a = L.xmi_analysis_create(128, 128)
     assert a
-    L.xmi_analysis_configure.argtypes = [C.c_void_p, C.c_int]
-    assert L.xmi_analysis_configure(a, 0) != 0 and L.xmi_analysis_configure(a, 9) != 0
-    assert L.xmi_analysis_configure(a, 2) == 0
+    L.xmi_analysis_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    assert L.xmi_analysis_configure(a, 0, 0) != 0 and L.xmi_analysis_configure(a, 9, 0) != 0 and L.xmi_analysis_configure(a, 1, -1) != 0
+    assert L.xmi_analysis_configure(a, 2, 50) == 0
     L.xmi_analysis_destroy.argtypes = [C.c_void_p]
     L.xmi_analysis_destroy(a)

@@ -25,7 +25,7 @@ def synth(w, h, t, seed):
     return y, u, v
 
 
-def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=None, lib=None):
+def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=None, spin_us=0, lib=None):
     """`segments` independent GOP segments analysed at the same time on one GPU (one handle, one host thread each; the C
     call releases the interpreter lock): aggregate P pictures per second."""
     import threading
@@ -36,7 +36,7 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
     w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     clips = [[synth(w, h, t, 7 + s) for t in range(pictures + 1)] for s in range(segments)]
     refs = [[tuple(np.pad(p, 80 if i == 0 else 40, mode="edge") for i, p in enumerate(f)) for f in clip] for clip in clips]
-    runners = [T.Runner(L, "xmi_analysis_", w, h, lanes) for _ in range(segments)]
+    runners = [T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us) for _ in range(segments)]
     errs = []
 
     def work(s, lo, hi):
@@ -66,14 +66,14 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
             "what": f"{segments} GOP segments of {width}x{height} analysed concurrently on one GPU, aggregate P pictures per second"}
 
 
-def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, lib=None):
+def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=200, lib=None):
     from x265_amd import capi
     from tests import ctu_trace as T
     L = lib or capi.load()
     capi.check(L.xmi_init(0))
     w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     frames = [synth(w, h, t, seed) for t in range(pictures + 1)]
-    r = T.Runner(L, "xmi_analysis_", w, h, lanes)
+    r = T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us)
     times, rounds, cus = [], [], []
     try:
         for t in range(1, pictures + 1):
@@ -84,11 +84,25 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, lib=None
             times.append(time.perf_counter() - t0)
             rounds.append(int(out["counters"][0]))
             cus.append(int(out["counters"][1]))
+        tm = (C.c_uint64 * 5)()
+        L.xmi_analysis_timing.argtypes = [C.c_void_p, C.c_void_p]
+        L.xmi_analysis_timing(r.handle, tm)
+        if hasattr(L, "xmi_debug_round_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING)
+            tk = (C.c_uint64 * 32)()
+            L.xmi_debug_round_ticks(tk)
+            for si, n in enumerate((8, 16, 32, 64)):
+                for path, name in enumerate(("merge path", "search path")):
+                    m, sr, ch, cnt = (tk[(si * 2 + path) * 4 + k] for k in range(4))
+                    if cnt:
+                        print(f"{n}x{n} {name}: {cnt} workgroups, us each: merge selection {m / cnt / 100:.2f}, search {sr / cnt / 100:.2f}, "
+                              f"chain {ch / cnt / 100:.2f}", file=sys.stderr)
     finally:
         r.close()
     steady = times[1:] if len(times) > 1 else times
     return {"analysis_fps": round(len(steady) / sum(steady), 3), "ms_per_picture": [round(x * 1e3, 2) for x in times], "round_trips": rounds,
-            "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp, "lanes": lanes,
+            "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp, "lanes": lanes, "spin_us": spin_us,
+            "us_per_round_trip_parts": {"job_tables": round(tm[0] / max(1, tm[4]) / 1e3, 1), "launch_call": round(tm[1] / max(1, tm[4]) / 1e3, 1),
+                                        "gpu_wait": round(tm[2] / max(1, tm[4]) / 1e3, 1), "read_back": round(tm[3] / max(1, tm[4]) / 1e3, 1)},
             "what": f"{width}x{height} synthetic P pictures, decision + reconstruction of every CTU; includes the host copies of the call "
                     "(planes up, result arrays down)"}
 
@@ -101,8 +115,9 @@ if __name__ == "__main__":
     ap.add_argument("--pictures", type=int, default=6)
     ap.add_argument("--segments", type=int, default=1)
     ap.add_argument("--lanes", type=int, default=None)
+    ap.add_argument("--spin-us", type=int, default=None)
     a = ap.parse_args()
     if a.segments > 1:
-        print(json.dumps(run_segments(a.width, a.height, a.qp, a.pictures, a.segments, a.lanes)))
+        print(json.dumps(run_segments(a.width, a.height, a.qp, a.pictures, a.segments, a.lanes, a.spin_us or 0)))
     else:
-        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes)))
+        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes, spin_us=200 if a.spin_us is None else a.spin_us)))

@@ -17,6 +17,7 @@
 // four 32x32 units one after the other.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -92,6 +93,7 @@ struct __align__(16) RoundLds {
     uint8_t pix[32 * 32], pred[32 * 32];
     uint8_t win[(64 + 16) * (64 + 24)];
     uint32_t red[4];
+    uint32_t red5[4][5];
     uint32_t acc[2];
     xmi_me_result me;
 };
@@ -100,16 +102,6 @@ __device__ __forceinline__ const uint8_t *plane_block(const RoundParams &p, int 
 {
     const size_t plane = (size_t)((mvy & 3) * 4 + (mvx & 3)) * (size_t)p.stride * p.rows;
     return p.planes + plane + (size_t)(kPad + y0 + (mvy >> 2)) * p.stride + kPad + x0 + (mvx >> 2);
-}
-
-__device__ __forceinline__ uint32_t block_sum(uint32_t v, uint32_t *red)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
 }
 
 // xSubDctQuantRec (src/encode.cpp:3005-3021) of one N x N unit by the whole workgroup, P-slice rounding, DCT:
@@ -175,30 +167,57 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
     __syncthreads();
 }
 
+#ifdef XMI_EXP_ROUND_TIMING
+// measurement build: per CU size (8, 16, 32, 64) and path, 100 MHz ticks spent in merge selection / search / chain, and counts
+__device__ unsigned long long g_round_ticks[4][2][4];
+#define XMI_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define XMI_STAMP(var)
+#endif
+
 template <int N>
 __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, int path, int u)
 {
+    XMI_STAMP(t_begin);
     constexpr int UN = N == 64 ? 32 : N;
     const int tid = threadIdx.x;
     const uint8_t *src = p.src[0] + (size_t)j.y0 * p.width + j.x0;
-    // merge candidates: both workgroups of the job come to the same selection
+    // merge candidates: both workgroups of the job come to the same selection. The candidates do not depend on each other:
+    // their loads go out together and one reduction serves all of them.
+    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+    const uint8_t *cand[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) cand[k] = (k < j.n_merge && j.merge_ok[k]) ? plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]) : nullptr;
+    for (int i = tid * 4; i < N * N; i += 1024) {
+        const int y = i / N, x = i - y * N;
+        const uchar4 a = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.width + x);
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            if (!cand[k]) continue;
+            const uint8_t *b = cand[k] + (size_t)y * p.stride + x;
+            const int d0 = (int)a.x - b[0], d1 = (int)a.y - b[1], d2 = (int)a.z - b[2], d3 = (int)a.w - b[3];
+            acc[k] += (uint32_t)(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 5; k++) L.red5[tid >> 6][k] = acc[k];
+    __syncthreads();
     uint32_t best_ssd = 0xffffffffu;
     int best = -1;
-    for (int k = 0; k < j.n_merge; k++) {
-        if (!j.merge_ok[k]) continue;
-        const uint8_t *pr = plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]);
-        uint32_t acc = 0;
-        for (int i = tid * 4; i < N * N; i += 1024) {
-            const int y = i / N, x = i - y * N;
-            const uchar4 a = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.width + x);
-            const uint8_t *b = pr + (size_t)y * p.stride + x;
-            const int d0 = (int)a.x - b[0], d1 = (int)a.y - b[1], d2 = (int)a.z - b[2], d3 = (int)a.w - b[3];
-            acc += (uint32_t)(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
-        }
-        const uint32_t ssd = block_sum(acc, L.red);
-        if (ssd < best_ssd) best_ssd = ssd, best = k;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t ssd = L.red5[0][k] + L.red5[1][k] + L.red5[2][k] + L.red5[3][k];
+        if (cand[k] && ssd < best_ssd) best_ssd = ssd, best = k;      // the first smallest (src/encode.cpp:3281)
     }
     LumaHead *head = reinterpret_cast<LumaHead *>(p.out + j.out_head);
+    XMI_STAMP(t_merge);
     int mvx, mvy;
     if (path == 0) {
         if (tid == 0) head->best_merge = best, head->ssd_skip = best_ssd;
@@ -220,6 +239,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         mvx = L.me.mv[0], mvy = L.me.mv[1];
         if (tid == 0) head->mv[0] = (int16_t)mvx, head->mv[1] = (int16_t)mvy;
     }
+    XMI_STAMP(t_search);
     const uint8_t *pr = plane_block(p, j.x0, j.y0, mvx, mvy);
     int16_t *level = reinterpret_cast<int16_t *>(p.out + (path ? j.out_level_me : j.out_level_merge));
     uint8_t *rec = p.out + (path ? j.out_rec_me : j.out_rec_merge), *pred_out = path ? nullptr : p.out + j.out_pred_merge;
@@ -231,6 +251,14 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     if (tid == 0) {
         (path ? head->sum_me : head->sum_merge)[u] = sum;
         (path ? head->ssd_me : head->ssd_merge)[u] = ssd;
+#ifdef XMI_EXP_ROUND_TIMING
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        constexpr int si = N == 8 ? 0 : N == 16 ? 1 : N == 32 ? 2 : 3;
+        atomicAdd(&g_round_ticks[si][path][0], t_merge - t_begin);
+        atomicAdd(&g_round_ticks[si][path][1], t_search - t_merge);
+        atomicAdd(&g_round_ticks[si][path][2], t_end - t_search);
+        atomicAdd(&g_round_ticks[si][path][3], 1ull);
+#endif
     }
 }
 
@@ -340,6 +368,8 @@ public:
         unsigned *g_flag = nullptr;
         unsigned issued = 0, seq = 0;
         std::vector<ChromaPlace> place;
+        // where a round trip's time goes, nanoseconds (xmi_analysis_counters): table set-up, launch call, wait, result read-back
+        uint64_t t_prepare = 0, t_launch = 0, t_wait = 0, t_collect = 0, rounds = 0;
         char err[256] = "";
     };
     int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0;
@@ -473,6 +503,7 @@ private:
     int run(LaneRes &R, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
     {
         XMI_ARG(ncu <= max_cu, "analysis: %d CU requests exceed the round capacity %d", ncu, max_cu);
+        const auto t0 = std::chrono::steady_clock::now();
         uint8_t *const h_jobs = R.h_jobs, *const h_out = R.h_out;
         std::vector<ChromaPlace> &place = R.place;
         LumaJob *jobs = reinterpret_cast<LumaJob *>(h_jobs);
@@ -558,8 +589,10 @@ private:
         const unsigned seq = R.seq;
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
+        const auto t1 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
         XMI_HIP(hipGetLastError());
+        const auto t2 = std::chrono::steady_clock::now();
         // spin on the completion word; look at the stream now and then so that a failed launch cannot hang the host
         volatile unsigned *flag = R.h_flag;
         for (unsigned spins = 0; *flag != seq; spins++) {
@@ -577,6 +610,7 @@ private:
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
+        const auto t3 = std::chrono::steady_clock::now();
 
         for (int i = 0; i < ncu; i++) {
             CuEval &q = *cu[i];
@@ -603,6 +637,9 @@ private:
             c.rec_u = h_out + pl.rec[0], c.rec_v = h_out + pl.rec[1];
             c.level_u = reinterpret_cast<const int16_t *>(h_out + pl.level[0]), c.level_v = reinterpret_cast<const int16_t *>(h_out + pl.level[1]);
         }
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+        R.t_prepare += ns(t0, t1), R.t_launch += ns(t1, t2), R.t_wait += ns(t2, t3), R.t_collect += ns(t3, t4), R.rounds++;
         return XMI_OK;
     }
 };
@@ -639,14 +676,33 @@ xmi_analysis *xmi_analysis_create(int width, int height)
 
 void xmi_analysis_destroy(xmi_analysis *a) { delete a; }
 
-int xmi_analysis_configure(xmi_analysis *a, int lanes)
+int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 {
     int rc = xmi::require_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(a, "xmi_analysis_configure: null handle");
-    rc = a->ev.set_lanes(lanes);
-    if (rc == XMI_OK) a->an.lanes = lanes;
+    XMI_ARG(spin_us >= 0 && spin_us <= 1000000, "xmi_analysis_configure: spin_us %d", spin_us);
+    if (lanes != a->ev.lanes) {
+        rc = a->ev.set_lanes(lanes);
+        if (rc == XMI_OK) a->an.lanes = lanes;
+    }
+    if (rc == XMI_OK) a->an.spin_us = spin_us;
     return rc;
+}
+
+#ifdef XMI_EXP_ROUND_TIMING
+int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+#endif
+
+int xmi_analysis_timing(xmi_analysis *a, uint64_t out[5])
+{
+    XMI_ARG(a && out, "xmi_analysis_timing: null argument");
+    for (int k = 0; k < 5; k++) out[k] = 0;
+    for (int i = 0; i < a->ev.lanes; i++) {
+        const GpuEvaluator::LaneRes &l = a->ev.lane[i];
+        out[0] += l.t_prepare, out[1] += l.t_launch, out[2] += l.t_wait, out[3] += l.t_collect, out[4] += l.rounds;
+    }
+    return XMI_OK;
 }
 
 int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits)

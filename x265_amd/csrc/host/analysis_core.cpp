@@ -8,7 +8,11 @@
 #include "analysis_core.h"
 
 #include <cmath>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -351,7 +355,7 @@ struct Row {
     int qp = 0, ctu_x = 0;
     CuEval cu_req;
     std::vector<ChromaEval> chroma_req;
-    bool pending = false;       // blocked on a request
+    std::atomic<bool> pending{ false };   // blocked on a request (cleared by the lane's coordinator; the row may watch it without the lock)
     bool in_flight = false;     // ... that is part of the call its lane is making right now
     int need = -1;
 
@@ -367,6 +371,7 @@ struct Row {
     void run();
     void evaluate_cu();
     void evaluate_chroma();
+    void await_results(std::unique_lock<std::mutex> &lk);
 };
 
 // Rows are dealt to lanes (row y -> lane y % lanes). A lane is the unit of one round trip: its rows block, their requests go to
@@ -374,7 +379,8 @@ struct Row {
 // their own round trip, so that host work and evaluator latency overlap.
 struct Lane {
     std::condition_variable cv_main;
-    int running = 0, rows = 0, finished = 0;
+    std::atomic<int> running{ 0 };      // rows of the lane that are busy on the host (changed under the lock)
+    int rows = 0, finished = 0;
     std::vector<CuEval *> cu;
     std::vector<ChromaEval *> chroma;
 };
@@ -382,10 +388,11 @@ struct Lane {
 struct Shared {
     std::mutex m;
     std::condition_variable cv_rows;
-    int error = 0;
-    std::vector<Lane> lanes;
+    std::atomic<int> error{ 0 };
+    int spin_us = 0;                // how long a waiter polls before it blocks
+    std::deque<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row
-    std::vector<Row> rows;
+    std::deque<Row> rows;
     std::vector<Ctx> saved;         // contexts after CTU 1 of a row: where the row below starts (cabacRdoSaved, src/encode.cpp:5481)
     Ctx start;                      // contexts of the slice start
     Analyser *an = nullptr;
@@ -688,6 +695,30 @@ void Row::chroma_pass()
     }
 }
 
+// A round trip takes tens of microseconds, and a thread that sleeps on a condition variable needs about ten more to come
+// back (longer when its core has gone idle): waiters poll for spin_us first and block only when nothing came.
+static inline bool poll_until(int spin_us, const std::function<bool()> &ready)
+{
+    if (spin_us <= 0) return ready();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int i = 0; i < 64; i++) {
+            if (ready()) return true;
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) return ready();
+    }
+}
+
+void Row::await_results(std::unique_lock<std::mutex> &lk)
+{
+    lk.unlock();
+    const bool got = poll_until(sh->spin_us, [&] { return !pending.load(std::memory_order_acquire); });
+    lk.lock();
+    if (!got) sh->cv_rows.wait(lk, [&] { return !pending.load(std::memory_order_acquire); });
+    if (sh->error) throw Abort();
+}
+
 void Row::evaluate_cu()
 {
     std::unique_lock<std::mutex> lk(sh->m);
@@ -695,8 +726,7 @@ void Row::evaluate_cu()
     ln.cu.push_back(&cu_req);
     pending = true;
     if (--ln.running == 0) ln.cv_main.notify_one();
-    sh->cv_rows.wait(lk, [&] { return !pending; });
-    if (sh->error) throw Abort();
+    await_results(lk);
 }
 
 void Row::evaluate_chroma()
@@ -706,8 +736,7 @@ void Row::evaluate_chroma()
     for (ChromaEval &c : chroma_req) ln.chroma.push_back(&c);
     pending = true;
     if (--ln.running == 0) ln.cv_main.notify_one();
-    sh->cv_rows.wait(lk, [&] { return !pending; });
-    if (sh->error) throw Abort();
+    await_results(lk);
 }
 
 // the row loop of xEncodeCUs (src/encode.cpp:5233-5590), P slices
@@ -864,9 +893,10 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     S.done.assign(rows_, 0);
     S.saved.resize(rows_);
     init_contexts(1, qp, S.start.m);
-    S.rows.resize(rows_);
+    S.rows = std::deque<Row>(rows_);
+    S.spin_us = spin_us;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
-    S.lanes = std::vector<Lane>(nl);
+    S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {
         S.rows[y].sh = &S, S.rows[y].y = y;
         S.lanes[y % nl].rows++, S.lanes[y % nl].running++;
@@ -882,6 +912,9 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
         std::vector<ChromaEval *> chroma;
         std::unique_lock<std::mutex> lk(S.m);
         for (;;) {
+            lk.unlock();
+            poll_until(S.spin_us, [&] { return ln.running.load(std::memory_order_acquire) == 0; });
+            lk.lock();
             ln.cv_main.wait(lk, [&] { return ln.running == 0 && (!ln.cu.empty() || !ln.chroma.empty() || ln.finished == ln.rows || S.error); });
             if (ln.finished == ln.rows) break;
             cu.swap(ln.cu), chroma.swap(ln.chroma);
@@ -899,7 +932,11 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
             if (rc && !S.error) S.error = rc;
             for (Row &r : S.rows) {
                 Lane &rl = S.lanes[r.y % nl];
-                if (r.y % nl == lane && r.in_flight) r.in_flight = r.pending = false, ln.running++;
+                if (r.y % nl == lane && r.in_flight) {
+                    ln.running++;
+                    r.in_flight = false;
+                    r.pending.store(false, std::memory_order_release);
+                }
                 if (S.error && r.need >= 0) {       // an error ends the picture: rows waiting for a neighbour leave as well
                     r.need = -1, rl.running++;
                     rl.cv_main.notify_one();
@@ -914,7 +951,7 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     for (int l = 1; l < nl; l++) threads.emplace_back(coordinate, l);
     coordinate(0);
     for (std::thread &t : threads) t.join();
-    return S.error;
+    return S.error.load();
 }
 
 }  // namespace analysis

@@ -101,6 +101,10 @@ public:
     // Rows are dealt to `lanes` groups (row y -> y % lanes); each group makes its own round trips to the evaluator, so the
     // host work of one group overlaps the evaluator latency of the others. Results do not depend on it.
     int lanes = 1;
+    // Rows waiting for results, and the coordinators waiting for their rows, poll for this many microseconds before they
+    // block: a round trip is shorter than the time a sleeping thread needs to come back. 0 = block at once (the choice when
+    // many analysers share the host's cores).
+    int spin_us = 0;
 
     // One P picture: decisions and reconstruction of every CTU, rows advancing as a wavefront (a CTU starts when its
     // left neighbour and the CTU above and to the right are done). The evaluator is bound to the picture pair (source,
