@@ -94,6 +94,7 @@ struct __align__(16) RoundLds {
     uint8_t win[(64 + 16) * (64 + 24)];
     uint32_t red[4];
     uint32_t red5[4][5];
+    uint32_t red36[4 * 9];
     uint32_t acc[2];
     xmi_me_result me;
 };
@@ -224,16 +225,18 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         if (best < 0) return;
         mvx = j.merge_mv[best][0], mvy = j.merge_mv[best][1];
     } else {
-        if (tid < 64) {
-            xmi_me_request rq;
-            rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N;
-            rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
-            rq.zero_mv_tested = best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0;
-            rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
-            rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
-            rq.sqrt_lambda = j.sqrt_lambda;
-            MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
-            search<N, false>(mp, rq, 0, tid, L.win);
+        xmi_me_request rq;
+        rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N;
+        rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
+        rq.zero_mv_tested = best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0;
+        rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
+        rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
+        rq.sqrt_lambda = j.sqrt_lambda;
+        MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+        if constexpr (N >= 32) {
+            search<N, false, false, 4>(mp, rq, 0, tid, L.win, L.red36);      // the whole workgroup shares the block
+        } else {
+            if (tid < 64) search<N, false>(mp, rq, 0, tid, L.win);
         }
         __syncthreads();
         mvx = L.me.mv[0], mvy = L.me.mv[1];

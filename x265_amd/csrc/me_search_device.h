@@ -62,23 +62,48 @@ __device__ __forceinline__ u32 row_sum(u32 x)
 // PACK (8x8 only): the block's 16 dwords occupy a quarter of the wavefront, so four searches share one - each row of 16
 // lanes runs its own request (idx, rq and everything derived from them differ per row; the rows diverge where their
 // searches do), and SADs are summed per row.
-template <int N, bool SURF, bool PACK = false>
-__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win)
+// WAVES = 4 (32x32 and 64x64 only): the whole workgroup of 256 threads runs one search - every thread of it must call, with
+// the same request - and the partial sums of its wavefronts meet in s_red (4 x 9 words of LDS); a 64x64 candidate is then 4
+// dwords per thread instead of 16, and a stage's candidates fit in registers together.
+template <int N, bool SURF, bool PACK = false, int WAVES = 1>
+__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win, u32 *s_red = nullptr)
 {
     static_assert(!PACK || N == 8, "only 8x8 blocks fit four to a wavefront");
+    static_assert(WAVES == 1 || (WAVES == 4 && N >= 32 && !PACK), "a workgroup search is for the large blocks");
+    constexpr int GT = PACK ? 16 : 64 * WAVES;       // threads that share the block
     constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
-    constexpr int J = DW < 64 ? 1 : DW / 64;         // block dwords per lane
+    constexpr int J = DW < GT ? 1 : DW / GT;         // block dwords per lane
     constexpr int KC = J == 1 ? 9 : J == 4 ? 4 : 1;  // candidates evaluated together (bounds the registers)
     const int lane = PACK ? (wave_lane & 15) : wave_lane;
-    const bool live = DW >= 64 || lane < DW;
+    const bool live = DW >= GT || lane < DW;
     const size_t plane_bytes = (size_t)p.rows * p.stride;
     u32 cur[J];
-    // the lane's dwords: d = lane + 64 j -> row lane / DPR + j * (64 / DPR), column dword lane % DPR
+    // the lane's dwords: d = lane + GT j -> row lane / DPR + j * (GT / DPR), column dword lane % DPR
+    constexpr int JR = GT / DPR > 0 ? GT / DPR : 1;  // rows between a lane's dwords
     const int row0 = live ? lane / DPR : 0, c40 = live ? lane % DPR : 0;
-    const int off0 = row0 * p.stride + c40 * 4, joff = (64 / DPR) * p.stride;    // byte offsets inside a reference block
+    const int off0 = row0 * p.stride + c40 * 4, joff = JR * p.stride;    // byte offsets inside a reference block
 #pragma unroll
     for (int j = 0; j < J; j++)
-        cur[j] = live ? *reinterpret_cast<const u32 *>(p.cur + (size_t)(rq.y0 + row0 + j * (64 / DPR)) * p.cur_stride + rq.x0 + c40 * 4) : 0u;
+        cur[j] = live ? *reinterpret_cast<const u32 *>(p.cur + (size_t)(rq.y0 + row0 + j * JR) * p.cur_stride + rq.x0 + c40 * 4) : 0u;
+    // sums of CNT partial values over the threads that share the block, uniform in all of them
+    auto reduce = [&](auto cnt_tag, u32 *v) {
+        constexpr int CNT = decltype(cnt_tag)::value;
+        if constexpr (WAVES == 1) {
+#pragma unroll
+            for (int k = 0; k < CNT; k++) v[k] = PACK ? row_sum(v[k]) : wave_sum(v[k]);
+        } else {
+            const int w = wave_lane >> 6;
+#pragma unroll
+            for (int k = 0; k < CNT; k++) v[k] = wave_sum(v[k]);
+            __syncthreads();                          // the previous sums have been read
+            if ((wave_lane & 63) == 0)
+#pragma unroll
+                for (int k = 0; k < CNT; k++) s_red[w * 9 + k] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CNT; k++) v[k] = s_red[k] + s_red[9 + k] + s_red[18 + k] + s_red[27 + k];
+        }
+    };
     // SADs of COUNT candidate blocks (top-left pointers, any byte alignment) against the current block
     // (candidates are byte offsets into the plane buffer: 32-bit arithmetic, and loads of the form uniform base + lane offset)
     auto eval = [&](auto count_tag, const u32 *cand, u32 *out) {
@@ -99,14 +124,18 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
                     hi[k][j] = w.y;
                 }
             }
+            u32 part[KC];
 #pragma unroll
             for (int k = 0; k < KC; k++) {
+                part[k] = 0;
                 if (k0 + k >= COUNT) continue;
-                u32 s = 0;
 #pragma unroll
-                for (int j = 0; j < J; j++) s = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi[k][j], lo[k][j], sh[k]), cur[j], s);
-                out[k0 + k] = PACK ? row_sum(s) : wave_sum(s);
+                for (int j = 0; j < J; j++) part[k] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi[k][j], lo[k][j], sh[k]), cur[j], part[k]);
             }
+            reduce(std::integral_constant<int, KC>{}, part);
+#pragma unroll
+            for (int k = 0; k < KC; k++)
+                if (k0 + k < COUNT) out[k0 + k] = part[k];
         }
     };
     const u32 ref_off = (u32)((p.pad + rq.y0) * p.stride + p.pad + rq.x0), plane_u32 = (u32)plane_bytes;
@@ -118,37 +147,41 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     // reads only, and the walk reloads it around its current position when it reaches the rim. Rows are WP bytes apart
     // and start at the dword that holds the window's first sample (offset win_sh into it); dwords outside the plane
     // buffer are not read (no candidate lies there).
-    constexpr int WR = 8, WH = N + 2 * WR, WP = N + 2 * WR + 8, WPD = WP / 4, GL = PACK ? 16 : 64;
+    constexpr int WR = 8, WH = N + 2 * WR, WP = N + 2 * WR + 8, WPD = WP / 4, GL = GT;
+    auto group_barrier = [&] {
+        if constexpr (WAVES == 1) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
+    };
     int win_cx = 0, win_cy = 0, win_sh = 0;
     bool win_ok = false;
     auto win_load = [&](int cx, int cy) {
         const int gy0 = p.pad + rq.y0 + cy - WR, gx = p.pad + rq.x0 + cx - WR, gxb = gx & ~3;
-        __builtin_amdgcn_wave_barrier();      // reads of the previous window are done
+        group_barrier();                      // reads of the previous window are done
         for (int e = lane; e < WH * WPD; e += GL) {
             const int r = e / WPD, c = e - r * WPD, y = gy0 + r, x = gxb + 4 * c;
             u32 v = 0;
             if (y >= 0 && y < p.rows && x >= 0 && x + 4 <= p.stride) v = *reinterpret_cast<const u32 *>(p.planes + (size_t)y * p.stride + x);
             reinterpret_cast<u32 *>(s_win)[e] = v;
         }
-        __builtin_amdgcn_wave_barrier();
+        group_barrier();
         win_cx = cx;
         win_cy = cy;
         win_sh = gx & 3;
         win_ok = true;
     };
     auto win_has = [&](int cx, int cy, int x, int y) { return abs(x - cx) <= WR && abs(y - cy) <= WR; };
-    auto win_sad = [&](int x, int y) -> u32 {
+    auto win_sad = [&](int x, int y) -> u32 {   // this thread's part of the SAD
         const int bo = x - win_cx + WR + win_sh, d0 = (bo >> 2) + c40;
         const u32 sh = (u32)(bo & 3);
         const u32 *row = reinterpret_cast<const u32 *>(s_win) + (y - win_cy + WR + row0) * WPD + d0;
         u32 acc = 0;
 #pragma unroll
         for (int j = 0; j < J; j++) {
-            const u32 *q = row + j * (64 / DPR) * WPD;
+            const u32 *q = row + j * JR * WPD;
             acc = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(q[1], q[0], sh), cur[j], acc);
         }
         if (!live) acc = 0;      // an 8x8 block on a whole wavefront: the lanes beyond its 16 dwords hold no samples
-        return PACK ? row_sum(acc) : wave_sum(acc);
+        return acc;
     };
     const u32 lam = rq.sqrt_lambda;
     // surface coordinates of this PU (wave-uniform)
@@ -227,6 +260,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
             if (win_ok && all_in(win_cx, win_cy)) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) s4[k] = win_sad(tx[k], ty[k]);
+                reduce(std::integral_constant<int, 4>{}, s4);
             } else {      // the clip box keeps the candidates away from the walk's position
                 eval(std::integral_constant<int, 4>{}, c, s4);
             }
@@ -285,7 +319,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         bmy += bdy;
         step >>= 1;
     }
-    if (lane == 0) {
+    if (wave_lane == 0 || (PACK && lane == 0)) {
         xmi_me_result out;
         out.mv[0] = (int16_t)bmx;
         out.mv[1] = (int16_t)bmy;
