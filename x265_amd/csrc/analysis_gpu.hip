@@ -433,14 +433,14 @@ public:
         release_lanes();
         lanes = nlanes;
         const int lane_rows = (h / 64 + lanes - 1) / lanes;
-        max_cu = lane_rows;                   // one CU request per CTU row and round
+        max_cu = 4 * lane_rows;               // per CTU row and round a CU and its chain of first children (64, 32, 16, 8)
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(sizeof(LumaJob) * max_cu);
         off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
         jobs_bytes = off_cjobs + align_up(sizeof(ChromaJob) * max_chroma);
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
-        out_bytes = (size_t)max_cu * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
+        out_bytes = (size_t)lane_rows * 2 * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
         const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
         for (int i = 0; i < lanes; i++) {
             LaneRes &l = lane[i];

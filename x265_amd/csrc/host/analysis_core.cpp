@@ -353,7 +353,11 @@ struct Row {
     Mv min_ipel, max_ipel;
     double lambda = 0;
     int qp = 0, ctu_x = 0;
-    CuEval cu_req;
+    // Requests per CU size 8 / 16 / 32 / 64. A CU's request takes the requests of its first child, that child's first child
+    // and so on along: they sit at the same corner, so their neighbours are the CU's own and nothing the CU decides
+    // changes what they ask for. A child that finds its answer waiting (spec_ok) saves the round trip.
+    CuEval cu_spec[4];
+    bool spec_ok[4] = { false, false, false, false };
     std::vector<ChromaEval> chroma_req;
     std::atomic<bool> pending{ false };   // blocked on a request (cleared by the lane's coordinator; the row may watch it without the lock)
     bool in_flight = false;     // ... that is part of the call its lane is making right now
@@ -369,7 +373,7 @@ struct Row {
     void chroma_pass();
     void collect_cus(int px, int py, int size, std::vector<int> &list);
     void run();
-    void evaluate_cu();
+    void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
     void await_results(std::unique_lock<std::mutex> &lk);
 };
@@ -390,6 +394,7 @@ struct Shared {
     std::condition_variable cv_rows;
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
+    bool speculate = true;          // a CU's request carries those of its chain of first children
     std::deque<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row
     std::deque<Row> rows;
@@ -456,17 +461,39 @@ uint32_t Row::decide(int px, int py, int size, int depth)
     const bool skip_above = (I1(r4 - 1, c4) & kMaskSkip) && M(r4 - 1, c4 + b4 - 1) != kInvalid;
     const int ctx_skip = kCtxSkip + (skip_left ? 1 : 0) + (skip_above ? 1 : 0);
 
-    CuEval &q = cu_req;
-    q.x0 = ctu_x * 64 + px, q.y0 = y * 64 + py, q.size = size;
-    q.n_merge = nmerge;
-    for (int k = 0; k < nmerge; k++) {
-        q.merge_mv[k] = mg[k];
-        q.merge_ok[k] = mg[k].x >= qmin_x && mg[k].x <= qmax_x && mg[k].y >= qmin_y && mg[k].y <= qmax_y;
+    CuEval &q = cu_spec[li];
+    auto fill = [&](CuEval &r, const Mv *cnd, int nm, int sz) {
+        r.x0 = ctu_x * 64 + px, r.y0 = y * 64 + py, r.size = sz;
+        r.n_merge = nm;
+        for (int k = 0; k < nm; k++) {
+            r.merge_mv[k] = cnd[2 + k];
+            r.merge_ok[k] = cnd[2 + k].x >= qmin_x && cnd[2 + k].x <= qmax_x && cnd[2 + k].y >= qmin_y && cnd[2 + k].y <= qmax_y;
+        }
+        r.amvp[0] = cnd[0], r.amvp[1] = cnd[1];
+        r.mv_min_ipel = min_ipel, r.mv_max_ipel = max_ipel;
+        r.lambda = lambda, r.qp = qp;
+    };
+    auto same_request = [&](const CuEval &r) {      // was the waiting answer asked for with what this CU sees now?
+        if (r.x0 != ctu_x * 64 + px || r.y0 != y * 64 + py || r.size != size || r.n_merge != nmerge) return false;
+        for (int k = 0; k < nmerge; k++)
+            if (r.merge_mv[k].x != mg[k].x || r.merge_mv[k].y != mg[k].y) return false;
+        return r.amvp[0].x == cand[0].x && r.amvp[0].y == cand[0].y && r.amvp[1].x == cand[1].x && r.amvp[1].y == cand[1].y;
+    };
+    if (!(spec_ok[li] && same_request(q))) {
+        CuEval *list[4];
+        int n = 0;
+        fill(q, cand, nmerge, size);
+        list[n++] = &q;
+        for (int sz = size / 2, l = li - 1; sh->speculate && sz >= 8; sz /= 2, l--) {
+            Mv c2[7];
+            const int nm2 = fill_candidates(c2, r4, c4, r8, c8, sz);
+            fill(cu_spec[l], c2, nm2, sz);
+            spec_ok[l] = true;
+            list[n++] = &cu_spec[l];
+        }
+        evaluate_cus(list, n);
     }
-    q.amvp[0] = cand[0], q.amvp[1] = cand[1];
-    q.mv_min_ipel = min_ipel, q.mv_max_ipel = max_ipel;
-    q.lambda = lambda, q.qp = qp;
-    evaluate_cu();
+    spec_ok[li] = false;
 
     double best = kDoubleMax;
     int merge_idx = 0, skip = 0;
@@ -545,6 +572,8 @@ uint32_t Row::decide(int px, int py, int size, int depth)
     }
 
     bool replace = size == 8 || skip;
+    if (skip)
+        for (int l = 0; l < li; l++) spec_ok[l] = false;      // no children: their answers are dropped
     if (size > 8 && !skip) {
         Analyser &an = *sh->an;
         const int cols = sh->cols;
@@ -566,6 +595,7 @@ uint32_t Row::decide(int px, int py, int size, int depth)
             if (best < avg && avg > 0) {
                 replace = true;
                 descend = false;
+                for (int l = 0; l < li; l++) spec_ok[l] = false;
             }
         }
         if (descend) {
@@ -719,11 +749,11 @@ void Row::await_results(std::unique_lock<std::mutex> &lk)
     if (sh->error) throw Abort();
 }
 
-void Row::evaluate_cu()
+void Row::evaluate_cus(CuEval *const *list, int n)
 {
     std::unique_lock<std::mutex> lk(sh->m);
     Lane &ln = sh->lanes[y % sh->lanes.size()];
-    ln.cu.push_back(&cu_req);
+    for (int i = 0; i < n; i++) ln.cu.push_back(list[i]);
     pending = true;
     if (--ln.running == 0) ln.cv_main.notify_one();
     await_results(lk);
@@ -755,6 +785,7 @@ void Row::run()
     try {
         for (int x = 0; x < cols; x++) {
             ctu_x = x;
+            spec_ok[0] = spec_ok[1] = spec_ok[2] = spec_ok[3] = false;
             if (y > 0) {   // top-right neighbour done (or the whole row above)
                 const int need = x + 2 < cols ? x + 2 : cols;
                 std::unique_lock<std::mutex> lk(S.m);
@@ -895,6 +926,7 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     init_contexts(1, qp, S.start.m);
     S.rows = std::deque<Row>(rows_);
     S.spin_us = spin_us;
+    S.speculate = speculate;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
     S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {
