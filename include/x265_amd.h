@@ -408,8 +408,9 @@ void xmi_analysis_destroy(xmi_analysis *a);
 int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us);
 /* Measurement aid (no counterpart in the reference): where the round trips of this handle have spent their time so far,
  * summed over its lanes: out = { ns writing job tables, ns in the launch call, ns waiting for the GPU, ns reading results
- * back, round trips }. What is left of a picture's wall time is the host's decision work and its thread hand-overs. */
-int xmi_analysis_timing(xmi_analysis *a, uint64_t out[5]);
+ * back, round trips, and for the last picture: ns the CTU-row threads spent on decision work between their requests,
+ * requests they made }. What is left of a picture's wall time is thread hand-over. */
+int xmi_analysis_timing(xmi_analysis *a, uint64_t out[7]);
 int xmi_analysis_state(xmi_analysis *a, int set, double *sum_cost, int32_t *count, double *avg_cost, uint64_t *frac_bits);
 int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, const uint8_t *ref_y,
                            const uint8_t *ref_u, const uint8_t *ref_v, int pad, int qp, uint16_t *info0, uint8_t *info1, int16_t *mv,

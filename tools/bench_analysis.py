@@ -84,7 +84,7 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=
             times.append(time.perf_counter() - t0)
             rounds.append(int(out["counters"][0]))
             cus.append(int(out["counters"][1]))
-        tm = (C.c_uint64 * 5)()
+        tm = (C.c_uint64 * 7)()
         L.xmi_analysis_timing.argtypes = [C.c_void_p, C.c_void_p]
         L.xmi_analysis_timing(r.handle, tm)
         if hasattr(L, "xmi_debug_round_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING)
@@ -103,6 +103,7 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=
             "cu_requests": cus, "us_per_round_trip": round(sum(steady) / sum(rounds[-len(steady):]) * 1e6, 1), "qp": qp, "lanes": lanes, "spin_us": spin_us,
             "us_per_round_trip_parts": {"job_tables": round(tm[0] / max(1, tm[4]) / 1e3, 1), "launch_call": round(tm[1] / max(1, tm[4]) / 1e3, 1),
                                         "gpu_wait": round(tm[2] / max(1, tm[4]) / 1e3, 1), "read_back": round(tm[3] / max(1, tm[4]) / 1e3, 1)},
+            "row_thread_us_per_request": round(tm[5] / max(1, tm[6]) / 1e3, 1), "row_requests_last_picture": int(tm[6]),
             "what": f"{width}x{height} synthetic P pictures, decision + reconstruction of every CTU; includes the host copies of the call "
                     "(planes up, result arrays down)"}
 

@@ -697,10 +697,11 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 #endif
 
-int xmi_analysis_timing(xmi_analysis *a, uint64_t out[5])
+int xmi_analysis_timing(xmi_analysis *a, uint64_t out[7])
 {
     XMI_ARG(a && out, "xmi_analysis_timing: null argument");
     for (int k = 0; k < 5; k++) out[k] = 0;
+    out[5] = a->res.row_busy_ns, out[6] = a->res.row_requests;      // of the last picture
     for (int i = 0; i < a->ev.lanes; i++) {
         const GpuEvaluator::LaneRes &l = a->ev.lane[i];
         out[0] += l.t_prepare, out[1] += l.t_launch, out[2] += l.t_wait, out[3] += l.t_collect, out[4] += l.rounds;

@@ -358,6 +358,10 @@ struct Row {
     // changes what they ask for. A child that finds its answer waiting (spec_ok) saves the round trip.
     CuEval cu_spec[4];
     bool spec_ok[4] = { false, false, false, false };
+    // host time of the row between two requests (nanoseconds) and the number of requests: what a round trip waits for
+    // besides the evaluator
+    uint64_t busy_ns = 0, requests = 0;
+    std::chrono::steady_clock::time_point t_resume = std::chrono::steady_clock::now();
     std::vector<ChromaEval> chroma_req;
     std::atomic<bool> pending{ false };   // blocked on a request (cleared by the lane's coordinator; the row may watch it without the lock)
     bool in_flight = false;     // ... that is part of the call its lane is making right now
@@ -751,6 +755,12 @@ void Row::await_results(std::unique_lock<std::mutex> &lk)
 
 void Row::evaluate_cus(CuEval *const *list, int n)
 {
+    busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
+    requests++;
+    struct Resume {
+        Row *r;
+        ~Resume() { r->t_resume = std::chrono::steady_clock::now(); }
+    } resume{ this };
     std::unique_lock<std::mutex> lk(sh->m);
     Lane &ln = sh->lanes[y % sh->lanes.size()];
     for (int i = 0; i < n; i++) ln.cu.push_back(list[i]);
@@ -761,6 +771,12 @@ void Row::evaluate_cus(CuEval *const *list, int n)
 
 void Row::evaluate_chroma()
 {
+    busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
+    requests++;
+    struct Resume {
+        Row *r;
+        ~Resume() { r->t_resume = std::chrono::steady_clock::now(); }
+    } resume{ this };
     std::unique_lock<std::mutex> lk(sh->m);
     Lane &ln = sh->lanes[y % sh->lanes.size()];
     for (ChromaEval &c : chroma_req) ln.chroma.push_back(&c);
@@ -793,7 +809,9 @@ void Row::run()
                     this->need = need;
                     Lane &ln = S.lanes[y % S.lanes.size()];
                     if (--ln.running == 0) ln.cv_main.notify_one();
+                    const auto t0 = std::chrono::steady_clock::now();
                     S.cv_rows.wait(lk, [&] { return this->need < 0; });
+                    t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
                     if (S.error) throw Abort();
                 }
             }
@@ -983,6 +1001,8 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     for (int l = 1; l < nl; l++) threads.emplace_back(coordinate, l);
     coordinate(0);
     for (std::thread &t : threads) t.join();
+    out.row_busy_ns = out.row_requests = 0;
+    for (const Row &r : S.rows) out.row_busy_ns += r.busy_ns, out.row_requests += r.requests;
     return S.error.load();
 }
 

@@ -81,6 +81,7 @@ struct PictureResult {
     std::vector<uint32_t> rd_cost;
     std::vector<uint8_t> ctx_in, ctx_out;
     uint64_t evaluator_calls = 0, cu_requests = 0, chroma_requests = 0;
+    uint64_t row_busy_ns = 0, row_requests = 0;      // host time of the row threads between their requests, and how many they made
 };
 
 class Analyser {
