@@ -363,8 +363,14 @@ struct Row {
     uint64_t busy_ns = 0, requests = 0;
     std::chrono::steady_clock::time_point t_resume = std::chrono::steady_clock::now();
     std::vector<ChromaEval> chroma_req;
-    std::atomic<bool> pending{ false };   // blocked on a request (cleared by the lane's coordinator; the row may watch it without the lock)
-    bool in_flight = false;     // ... that is part of the call its lane is making right now
+    // The request hand-over takes no lock: the row fills its own slots, raises `pending` and counts itself out of its
+    // lane's `running`; the lane's coordinator reads the slots of the rows it finds pending, and lowers `pending` when the
+    // answers are in place. Only a waiter whose polling time has run out takes the mutex, to sleep.
+    std::atomic<bool> pending{ false };
+    bool in_flight = false;     // (coordinator only) ... that is part of the call its lane is making right now
+    CuEval *req_cu[4] = {};
+    int n_req_cu = 0;
+    bool req_chroma = false;     // ... that is part of the call its lane is making right now
     int need = -1;
 
     uint8_t &M(int r, int c) { return mode[(r + 1) * 18 + c + 1]; }
@@ -379,7 +385,7 @@ struct Row {
     void run();
     void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
-    void await_results(std::unique_lock<std::mutex> &lk);
+    void post_and_wait();
 };
 
 // Rows are dealt to lanes (row y -> lane y % lanes). A lane is the unit of one round trip: its rows block, their requests go to
@@ -387,10 +393,10 @@ struct Row {
 // their own round trip, so that host work and evaluator latency overlap.
 struct Lane {
     std::condition_variable cv_main;
-    std::atomic<int> running{ 0 };      // rows of the lane that are busy on the host (changed under the lock)
-    int rows = 0, finished = 0;
-    std::vector<CuEval *> cu;
-    std::vector<ChromaEval *> chroma;
+    std::atomic<int> running{ 0 };      // rows of the lane that are busy on the host
+    std::atomic<int> posted{ 0 };       // rows of the lane with a request the coordinator has not picked up yet
+    std::atomic<int> finished{ 0 };
+    int rows = 0;
 };
 
 struct Shared {
@@ -744,45 +750,42 @@ static inline bool poll_until(int spin_us, const std::function<bool()> &ready)
     }
 }
 
-void Row::await_results(std::unique_lock<std::mutex> &lk)
+void Row::post_and_wait()
 {
-    lk.unlock();
-    const bool got = poll_until(sh->spin_us, [&] { return !pending.load(std::memory_order_acquire); });
-    lk.lock();
-    if (!got) sh->cv_rows.wait(lk, [&] { return !pending.load(std::memory_order_acquire); });
+    busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
+    requests++;
+    Lane &ln = sh->lanes[y % sh->lanes.size()];
+    // `pending` goes up last: a coordinator that sees it finds the two counters already moved
+    ln.posted.fetch_add(1, std::memory_order_acq_rel);
+    const bool last = ln.running.fetch_sub(1, std::memory_order_acq_rel) == 1;
+    pending.store(true, std::memory_order_release);
+    if (last) {      // the last busy row of the lane: its coordinator may be asleep
+        { std::lock_guard<std::mutex> lk(sh->m); }
+        ln.cv_main.notify_one();
+    }
+    if (!poll_until(sh->spin_us, [&] { return !pending.load(std::memory_order_acquire); })) {
+        std::unique_lock<std::mutex> lk(sh->m);
+        sh->cv_rows.wait(lk, [&] { return !pending.load(std::memory_order_acquire); });
+    }
+    t_resume = std::chrono::steady_clock::now();
     if (sh->error) throw Abort();
 }
 
 void Row::evaluate_cus(CuEval *const *list, int n)
 {
-    busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
-    requests++;
-    struct Resume {
-        Row *r;
-        ~Resume() { r->t_resume = std::chrono::steady_clock::now(); }
-    } resume{ this };
-    std::unique_lock<std::mutex> lk(sh->m);
-    Lane &ln = sh->lanes[y % sh->lanes.size()];
-    for (int i = 0; i < n; i++) ln.cu.push_back(list[i]);
-    pending = true;
-    if (--ln.running == 0) ln.cv_main.notify_one();
-    await_results(lk);
+    for (int i = 0; i < n; i++) req_cu[i] = list[i];
+    n_req_cu = n;
+    req_chroma = false;
+    post_and_wait();
+    n_req_cu = 0;
 }
 
 void Row::evaluate_chroma()
 {
-    busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
-    requests++;
-    struct Resume {
-        Row *r;
-        ~Resume() { r->t_resume = std::chrono::steady_clock::now(); }
-    } resume{ this };
-    std::unique_lock<std::mutex> lk(sh->m);
-    Lane &ln = sh->lanes[y % sh->lanes.size()];
-    for (ChromaEval &c : chroma_req) ln.chroma.push_back(&c);
-    pending = true;
-    if (--ln.running == 0) ln.cv_main.notify_one();
-    await_results(lk);
+    n_req_cu = 0;
+    req_chroma = true;
+    post_and_wait();
+    req_chroma = false;
 }
 
 // the row loop of xEncodeCUs (src/encode.cpp:5233-5590), P slices
@@ -808,7 +811,7 @@ void Row::run()
                 if (S.done[y - 1] < need) {
                     this->need = need;
                     Lane &ln = S.lanes[y % S.lanes.size()];
-                    if (--ln.running == 0) ln.cv_main.notify_one();
+                    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
                     const auto t0 = std::chrono::steady_clock::now();
                     S.cv_rows.wait(lk, [&] { return this->need < 0; });
                     t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
@@ -883,8 +886,8 @@ void Row::run()
     S.an->frac_bits[y] = rate.frac;
     std::lock_guard<std::mutex> lk(S.m);
     Lane &ln = S.lanes[y % S.lanes.size()];
-    ln.finished++;
-    if (--ln.running == 0) ln.cv_main.notify_one();
+    ln.finished.fetch_add(1);
+    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
 }
 
 }  // namespace
@@ -960,41 +963,47 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
         Lane &ln = S.lanes[lane];
         std::vector<CuEval *> cu;
         std::vector<ChromaEval *> chroma;
-        std::unique_lock<std::mutex> lk(S.m);
+        std::vector<Row *> served;
+        // nothing of the lane is busy on the host, and there is something to do about it
+        auto ready = [&] {
+            return ln.running.load(std::memory_order_acquire) == 0 &&
+                   (ln.posted.load(std::memory_order_acquire) > 0 || ln.finished.load() == ln.rows || S.error.load() != 0);
+        };
         for (;;) {
-            lk.unlock();
-            poll_until(S.spin_us, [&] { return ln.running.load(std::memory_order_acquire) == 0; });
-            lk.lock();
-            ln.cv_main.wait(lk, [&] { return ln.running == 0 && (!ln.cu.empty() || !ln.chroma.empty() || ln.finished == ln.rows || S.error); });
-            if (ln.finished == ln.rows) break;
-            cu.swap(ln.cu), chroma.swap(ln.chroma);
-            ln.cu.clear(), ln.chroma.clear();
+            if (!poll_until(S.spin_us, ready)) {
+                std::unique_lock<std::mutex> lk(S.m);
+                ln.cv_main.wait(lk, ready);
+            }
+            if (ln.finished.load() == ln.rows) break;
             // the rows this call serves: a row that another lane's progress wakes during the call asks for the next one
-            for (Row &r : S.rows)
-                if (r.y % nl == lane && r.pending) r.in_flight = true;
-            int rc = 0;
-            if (!S.error && (!cu.empty() || !chroma.empty())) {
-                lk.unlock();
-                rc = ev.evaluate(lane, cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
-                lk.lock();
-                out.evaluator_calls++, out.cu_requests += cu.size(), out.chroma_requests += chroma.size();
-            }
-            if (rc && !S.error) S.error = rc;
+            cu.clear(), chroma.clear(), served.clear();
             for (Row &r : S.rows) {
-                Lane &rl = S.lanes[r.y % nl];
-                if (r.y % nl == lane && r.in_flight) {
-                    ln.running++;
-                    r.in_flight = false;
-                    r.pending.store(false, std::memory_order_release);
-                }
-                if (S.error && r.need >= 0) {       // an error ends the picture: rows waiting for a neighbour leave as well
-                    r.need = -1, rl.running++;
-                    rl.cv_main.notify_one();
+                if (r.y % nl != lane || r.in_flight || !r.pending.load(std::memory_order_acquire)) continue;
+                r.in_flight = true;
+                ln.posted.fetch_sub(1, std::memory_order_acq_rel);
+                served.push_back(&r);
+                for (int i = 0; i < r.n_req_cu; i++) cu.push_back(r.req_cu[i]);
+                if (r.req_chroma)
+                    for (ChromaEval &c : r.chroma_req) chroma.push_back(&c);
+            }
+            if (served.empty() && !S.error) continue;      // a row is between counting itself out and raising its flag
+            int rc = 0;
+            if (!S.error && (!cu.empty() || !chroma.empty())) rc = ev.evaluate(lane, cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
+            if (rc && !S.error) S.error = rc;
+            for (Row *r : served) {
+                ln.running.fetch_add(1, std::memory_order_acq_rel);
+                r->in_flight = false;
+                r->pending.store(false, std::memory_order_release);
+            }
+            {
+                std::lock_guard<std::mutex> lk(S.m);      // also orders the stores above before the wake-up of a sleeping row
+                out.evaluator_calls++, out.cu_requests += cu.size(), out.chroma_requests += chroma.size();
+                if (S.error) {       // an error ends the picture: rows waiting for a neighbour leave as well
+                    for (Row &r : S.rows)
+                        if (r.need >= 0) r.need = -1, S.lanes[r.y % nl].running.fetch_add(1);
+                    for (Lane &o : S.lanes) o.cv_main.notify_one();
                 }
             }
-            if (S.error)
-                for (Lane &o : S.lanes) o.cv_main.notify_one();
-            cu.clear(), chroma.clear();
             S.cv_rows.notify_all();
         }
     };
