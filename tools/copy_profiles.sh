@@ -8,6 +8,9 @@ P=gpurun_out/profile_$tag; S=gpurun_out/secondary_$tag
 cp $P/kernel_stats.csv $dst/bench_kernel_stats.csv
 grep -o '^{.*}' $P/bench_stats_run.log | tail -1 > $dst/bench_under_rocprof.json
 cat $P/pmc_fetch.txt $P/pmc_write.txt $P/pmc_sq1.txt $P/pmc_sq2.txt $P/pmc_grbm.txt > $dst/pmc_summary.txt
+[ -f $P/pmc_satd.txt ] && cat $P/pmc_satd.txt >> $dst/pmc_summary.txt
+E=gpurun_out/evidence_$(basename $dst)
+if [ -d $E ]; then cp $E/sad_launch_series.txt $E/sad_timeline.txt $E/microbench.txt $dst/; fi
 cp $P/pmc_fetch/fetch_counter_collection.csv $dst/pmc_fetch_counter_collection.csv
 cp $P/pmc_write/write_counter_collection.csv $dst/pmc_write_counter_collection.csv
 if [ -d $S ]; then
@@ -20,7 +23,7 @@ import json, re, sys
 p = sys.argv[1]
 def mean(path, name):
     txt = open(path).read()
-    m = re.search(r"sad_surface_kernel<64>\s*\n\s*" + name + r"\s+mean\s+([0-9.]+)", txt)
+    m = re.search(r"sad_surface_kernel<64[^>]*>\s*\n\s*" + name + r"\s+mean\s+([0-9.]+)", txt)
     return float(m.group(1))
 w, f = mean(p + "/pmc_write.txt", "WRITE_SIZE"), mean(p + "/pmc_fetch.txt", "FETCH_SIZE")
 path = "x265_amd/measured_traffic.json"
