@@ -5,7 +5,7 @@
 // xSad_AMP[idx](cur, 64, ref + dy*stride + dx, stride) (src/encode.cpp:2885-2931,
 // src/pixel.cpp:578-696, 833-844). SAD is an exact integer sum, so any summation order is bit-exact.
 //
-// Mapping (one workgroup = one CTU x one band of dy rows, R/8 wavefronts):
+// Mapping (one workgroup = one CTU x one band of dy rows x one slice of the dx range; four wavefronts of 16 dx each from R = 32 on):
 //   lane = q*16 + gl*4 + b     z = q*4 + b = 16x16 block of the CTU in z-order (q = quadrant, b = block in it)
 //                              gl = one of 4 dx-groups owned by the wavefront; a dx-group is 4
 //                                   consecutive dx, produced at once by v_qsad_pk_u16_u8
