@@ -115,6 +115,25 @@ def test_row_lanes_and_polling_do_not_change_the_result(lib, lanes, spin, tag):
     check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin), tag)
 
 
+def test_hand_over_survives_many_pictures_and_settings(lib):
+    """The rows hand their requests to the coordinators without a lock; the same picture again and again, with lane counts
+    and polling times drawn at random (3 us: waiters usually run out of polling time and go to sleep in mid hand-over)."""
+    import random
+    g = np.load(GOLDEN)
+    pic, before, rec_md5 = fixture_picture(g, "416x240_q22_p1")
+    rnd = random.Random(5)
+    for _ in range(12):
+        lanes, spin = rnd.choice([1, 1, 2, 3, 4]), rnd.choice([0, 3, 30, 300])
+        r = T.Runner(lib, "orc_analysis_", pic["w"], pic["h"], lanes, spin)
+        try:
+            for _rep in range(3):
+                r.set_state(before, pic)
+                out = r.run(pic)
+                assert hashlib.md5(out["rec_y"].tobytes()).hexdigest() == rec_md5[0], (lanes, spin)
+        finally:
+            r.close()
+
+
 @needs_ref("x265_ctu_trace", how="make -C oracle ctu_trace")
 @pytest.mark.parametrize("w,h,frames,qp,seed", [(416, 240, 6, 37, 1234), (416, 240, 4, 27, 1234)])
 def test_fresh_trace_with_carried_statistics(lib, tmp_path, w, h, frames, qp, seed):
