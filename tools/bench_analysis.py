@@ -96,6 +96,15 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=
                     if cnt:
                         print(f"{n}x{n} {name}: {cnt} workgroups, us each: merge selection {m / cnt / 100:.2f}, search {sr / cnt / 100:.2f}, "
                               f"chain {ch / cnt / 100:.2f}", file=sys.stderr)
+        if hasattr(L, "xmi_debug_chain_ticks"):
+            ck = (C.c_uint64 * 24)()
+            L.xmi_debug_chain_ticks(ck)
+            for si, n in enumerate((4, 8, 16, 32)):
+                cnt = ck[si * 6 + 5]
+                if cnt:
+                    print(f"chain {n}x{n}: {cnt} units, us each: set-up {ck[si * 6] / cnt / 100:.2f}, forward {ck[si * 6 + 1] / cnt / 100:.2f}, "
+                          f"quantiser {ck[si * 6 + 2] / cnt / 100:.2f}, inverse {ck[si * 6 + 3] / cnt / 100:.2f}, output {ck[si * 6 + 4] / cnt / 100:.2f}",
+                          file=sys.stderr)
     finally:
         r.close()
     steady = times[1:] if len(times) > 1 else times

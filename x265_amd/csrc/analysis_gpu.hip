@@ -88,8 +88,8 @@ __constant__ int k_chroma_taps[8][4] = { { 0, 64, 0, 0 },   { -2, 58, 10, -2 }, 
 
 // LDS of one workgroup: transform operands (up to 32x32), the unit's source and prediction bytes, the search window
 struct __align__(16) RoundLds {
-    int16_t mat[2][32 * 34];      // core matrix and its transpose, rows N + 2 apart
-    int16_t a[32 * 34], b[32 * 34];
+    int16_t mat[2][32 * 40];      // core matrix and its transpose, rows Cfg<N>::LD apart
+    int16_t a[32 * 40], b[32 * 40];
     uint8_t pix[32 * 32], pred[32 * 32];
     uint8_t win[(64 + 16) * (64 + 24)];
     uint32_t red[4];
@@ -105,6 +105,13 @@ __device__ __forceinline__ const uint8_t *plane_block(const RoundParams &p, int 
     return p.planes + plane + (size_t)(kPad + y0 + (mvy >> 2)) * p.stride + kPad + x0 + (mvx >> 2);
 }
 
+#ifdef XMI_EXP_ROUND_TIMING
+__device__ unsigned long long g_chain_ticks[4][6];      // per unit size 4/8/16/32: set-up, forward, quantiser, inverse, output, count
+#define XMI_CSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define XMI_CSTAMP(var)
+#endif
+
 // xSubDctQuantRec (src/encode.cpp:3005-3021) of one N x N unit by the whole workgroup, P-slice rounding, DCT:
 // source and prediction come with their own strides (any address space); levels, reconstruction and, when asked for, the
 // prediction go out with the stride of the CU's result blocks. Returns sum |level| and the SSD of the reconstruction
@@ -113,59 +120,92 @@ template <int N>
 __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
                            uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd)
 {
-    constexpr int LD = N + 2, LG = Cfg<N>::LOG2, TPT = Cfg<N>::TPT;
+    constexpr int LD = Cfg<N>::LD, LG = Cfg<N>::LOG2, TPT = Cfg<N>::TPT;
     const int tid = threadIdx.x;
     const bool live = tid < TPT;
+    XMI_CSTAMP(c0);
     int16_t *M = L.mat[0], *Mt = L.mat[1];
-    for (int e = tid; e < N * N; e += 256) {
+    // four neighbouring samples per thread and step: the source is dword aligned (picture positions and strides are multiples
+    // of 4), the prediction starts at any byte (a block of a quarter-pel plane, or LDS)
+    for (int e = tid * 4; e < N * N; e += 1024) {
         const int k = e / N, j = e % N;
-        const int16_t c = (int16_t)dct_coef(N, k, j);
-        M[k * LD + j] = c;
-        Mt[j * LD + k] = c;
-        const int s = pix[(size_t)k * pix_stride + j], q = pred[(size_t)k * pred_stride + j];
-        L.pix[e] = (uint8_t)s;
-        L.pred[e] = (uint8_t)q;
-        L.a[k * LD + j] = (int16_t)(s - q);
+        const uint32_t s4 = *reinterpret_cast<const uint32_t *>(pix + (size_t)k * pix_stride + j);
+        const uint8_t *pp = pred + (size_t)k * pred_stride + j;
+        const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(pp) & 3);
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(pp - sh);      // (pointer arithmetic keeps the address space known)
+        const uint32_t q4 = __builtin_amdgcn_alignbyte(pw[1], pw[0], sh);
+        *reinterpret_cast<uint32_t *>(&L.pix[e]) = s4;
+        *reinterpret_cast<uint32_t *>(&L.pred[e]) = q4;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int16_t c = (int16_t)dct_coef(N, k, j + t);
+            M[k * LD + j + t] = c;
+            Mt[(j + t) * LD + k] = c;
+            L.a[k * LD + j + t] = (int16_t)((int)((s4 >> (8 * t)) & 255) - (int)((q4 >> (8 * t)) & 255));
+        }
     }
-    if (tid < 2) L.acc[tid] = 0;
     __syncthreads();
+    XMI_CSTAMP(c1);
     if (live) stage<N, false>(M, L.a, L.b, LG - 1, tid);
     __syncthreads();
     if (live) stage<N, false>(M, L.b, L.a, LG + 6, tid);
     __syncthreads();
+    XMI_CSTAMP(c2);
     const int qbits = 14 + qp / 6 + (15 - 8 - LG), q = k_quant_scales[qp % 6], qrnd = 85 << (qbits - 9);
     const int dshift = 20 - 14 - (15 - 8 - LG), dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
     uint32_t local = 0;
-    for (int e = tid; e < N * N; e += 256) {
+    for (int e = tid * 4; e < N * N; e += 1024) {
         const int k = e / N, i = e % N;
-        const int c = L.a[k * LD + i];
-        const int mag = (abs(c) * q + qrnd) >> qbits;
-        local += (uint32_t)mag;
-        const int lv = clip16(c < 0 ? -mag : mag);
-        level[(size_t)k * out_stride + i] = (int16_t)lv;
-        L.b[i * LD + k] = (int16_t)clip16((lv * dscale + (1 << (dshift - 1))) >> dshift);
+        int lv[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int c = L.a[k * LD + i + t];
+            const int mag = (abs(c) * q + qrnd) >> qbits;
+            local += (uint32_t)mag;
+            lv[t] = clip16(c < 0 ? -mag : mag);
+            L.b[(i + t) * LD + k] = (int16_t)clip16((lv[t] * dscale + (1 << (dshift - 1))) >> dshift);
+        }
+        *reinterpret_cast<uint2 *>(level + (size_t)k * out_stride + i) =
+            make_uint2((uint32_t)(lv[0] & 0xffff) | ((uint32_t)lv[1] << 16), (uint32_t)(lv[2] & 0xffff) | ((uint32_t)lv[3] << 16));
     }
-    if (local) atomicAdd(&L.acc[0], local);
     __syncthreads();
+    XMI_CSTAMP(c3);
     if (live) stage<N, true>(Mt, L.b, L.a, 7, tid);
     __syncthreads();
     if (live) stage<N, true>(Mt, L.a, L.b, 12, tid);
     __syncthreads();
+    XMI_CSTAMP(c4);
     uint32_t d2 = 0;
-    for (int e = tid; e < N * N; e += 256) {
+    for (int e = tid * 4; e < N * N; e += 1024) {
         const int i = e / N, j = e % N;
-        const int pr = L.pred[e];
-        const int v = min(255, max(0, (int)L.b[j * LD + i] + pr));
-        rec[(size_t)i * out_stride + j] = (uint8_t)v;
-        if (pred_out) pred_out[(size_t)i * out_stride + j] = (uint8_t)pr;
-        const int d = (int)L.pix[e] - v;
-        d2 += (uint32_t)(d * d);
+        const uint32_t pr4 = *reinterpret_cast<const uint32_t *>(&L.pred[e]), s4 = *reinterpret_cast<const uint32_t *>(&L.pix[e]);
+        uint32_t r4 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int v = min(255, max(0, (int)L.b[(j + t) * LD + i] + (int)((pr4 >> (8 * t)) & 255)));
+            r4 |= (uint32_t)v << (8 * t);
+            const int d = (int)((s4 >> (8 * t)) & 255) - v;
+            d2 += (uint32_t)(d * d);
+        }
+        *reinterpret_cast<uint32_t *>(rec + (size_t)i * out_stride + j) = r4;
+        if (pred_out) *reinterpret_cast<uint32_t *>(pred_out + (size_t)i * out_stride + j) = pr4;
     }
-    if (d2) atomicAdd(&L.acc[1], d2);
+    // the two sums of the unit: one value per wavefront into LDS (256 atomics on one word take longer than the transform)
+    local = wave_sum(local);
+    d2 = wave_sum(d2);
+    if ((tid & 63) == 0) L.red5[tid >> 6][0] = local, L.red5[tid >> 6][1] = d2;
     __syncthreads();
-    sum = L.acc[0];
-    ssd = L.acc[1];
+    sum = L.red5[0][0] + L.red5[1][0] + L.red5[2][0] + L.red5[3][0];
+    ssd = L.red5[0][1] + L.red5[1][1] + L.red5[2][1] + L.red5[3][1];
     __syncthreads();
+#ifdef XMI_EXP_ROUND_TIMING
+    if (tid == 0) {
+        const unsigned long long c5 = __builtin_amdgcn_s_memrealtime();
+        constexpr int si = N == 4 ? 0 : N == 8 ? 1 : N == 16 ? 2 : 3;
+        atomicAdd(&g_chain_ticks[si][0], c1 - c0), atomicAdd(&g_chain_ticks[si][1], c2 - c1), atomicAdd(&g_chain_ticks[si][2], c3 - c2);
+        atomicAdd(&g_chain_ticks[si][3], c4 - c3), atomicAdd(&g_chain_ticks[si][4], c5 - c4), atomicAdd(&g_chain_ticks[si][5], 1ull);
+    }
+#endif
 }
 
 #ifdef XMI_EXP_ROUND_TIMING
@@ -191,13 +231,16 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     for (int k = 0; k < 5; k++) cand[k] = (k < j.n_merge && j.merge_ok[k]) ? plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]) : nullptr;
     for (int i = tid * 4; i < N * N; i += 1024) {
         const int y = i / N, x = i - y * N;
-        const uchar4 a = *reinterpret_cast<const uchar4 *>(src + (size_t)y * p.width + x);
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(src + (size_t)y * p.width + x);
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             if (!cand[k]) continue;
-            const uint8_t *b = cand[k] + (size_t)y * p.stride + x;
-            const int d0 = (int)a.x - b[0], d1 = (int)a.y - b[1], d2 = (int)a.z - b[2], d3 = (int)a.w - b[3];
-            acc[k] += (uint32_t)(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);
+            // four samples of the candidate from the two aligned dwords that hold them; SSD = a.a + b.b - 2 a.b on bytes
+            const uint8_t *bp = cand[k] + (size_t)y * p.stride + x;
+            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(bp) & 3);
+            const uint32_t *bw = reinterpret_cast<const uint32_t *>(bp - sh);
+            const uint32_t b = __builtin_amdgcn_alignbyte(bw[1], bw[0], sh);
+            acc[k] += __builtin_amdgcn_udot4(a, a, 0u, false) + __builtin_amdgcn_udot4(b, b, 0u, false) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
         }
     }
 #pragma unroll
@@ -695,6 +738,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 
 #ifdef XMI_EXP_ROUND_TIMING
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+int xmi_debug_chain_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ticks), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1; }
 #endif
 
 int xmi_analysis_timing(xmi_analysis *a, uint64_t out[7])

@@ -478,6 +478,9 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         for (int k = 0; k < nm; k++) {
             r.merge_mv[k] = cnd[2 + k];
             r.merge_ok[k] = cnd[2 + k].x >= qmin_x && cnd[2 + k].x <= qmax_x && cnd[2 + k].y >= qmin_y && cnd[2 + k].y <= qmax_y;
+            // a vector that an earlier usable candidate already has cannot win (the first smallest is taken): not evaluated
+            for (int e = 0; e < k && r.merge_ok[k]; e++)
+                if (r.merge_ok[e] && cnd[2 + e].x == cnd[2 + k].x && cnd[2 + e].y == cnd[2 + k].y) r.merge_ok[k] = 0;
         }
         r.amvp[0] = cnd[0], r.amvp[1] = cnd[1];
         r.mv_min_ipel = min_ipel, r.mv_max_ipel = max_ipel;

@@ -27,7 +27,8 @@ __device__ __forceinline__ int clip16(int v) { return min(32767, max(-32768, v))
 
 template <int N>
 struct Cfg {
-    static constexpr int LD = N + 2;                                   // int16 elements per LDS row (odd dword pitch)
+    static constexpr int LD = N + 8;                                   // int16 elements per LDS row: rows start on 16 bytes, and the 16
+                                                                       // rows a b128 load group touches fall into different banks
     static constexpr int TPT = N * N < 256 ? N * N : 256;              // threads per TU
     static constexpr int TUS = 256 / TPT;                              // TUs per 256-thread workgroup
     static constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
@@ -42,11 +43,23 @@ __device__ __forceinline__ void stage(const int16_t *mat, const int16_t *in, int
 #pragma unroll
     for (int e = t; e < N * N; e += TPT) {
         const int a = e / N, b = e % N;
-        const s16x2 *mr = reinterpret_cast<const s16x2 *>(mat + a * LD);
-        const s16x2 *ir = reinterpret_cast<const s16x2 *>(in + b * LD);
         int acc = 0;
+        if constexpr (N >= 8) {      // eight elements of both rows per 16-byte LDS load
+            const uint4 *mr = reinterpret_cast<const uint4 *>(mat + a * LD);
+            const uint4 *ir = reinterpret_cast<const uint4 *>(in + b * LD);
 #pragma unroll
-        for (int c = 0; c < N / 2; c++) acc = __builtin_amdgcn_sdot2(mr[c], ir[c], acc, false);
+            for (int c = 0; c < N / 8; c++) {
+                const uint4 m = mr[c], v = ir[c];
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.x), __builtin_bit_cast(s16x2, v.x), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.y), __builtin_bit_cast(s16x2, v.y), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.z), __builtin_bit_cast(s16x2, v.z), acc, false);
+                acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.w), __builtin_bit_cast(s16x2, v.w), acc, false);
+            }
+        } else {
+            const uint2 m = *reinterpret_cast<const uint2 *>(mat + a * LD), v = *reinterpret_cast<const uint2 *>(in + b * LD);
+            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.x), __builtin_bit_cast(s16x2, v.x), acc, false);
+            acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, m.y), __builtin_bit_cast(s16x2, v.y), acc, false);
+        }
         const int v = (acc + rnd) >> shift;
         out[a * LD + b] = (int16_t)(CLIP ? clip16(v) : v);
     }
