@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../x265_amd/csrc/host/analysis_core.h"
+#include "../x265_amd/csrc/host/encoder_core.h"
 #include "x265_oracle.h"
 
 using namespace xmi::analysis;
@@ -26,6 +27,20 @@ public:
     std::vector<uint8_t> lane_bytes[8];
     std::vector<int16_t> lane_words[8];
 
+    int w = 0, h = 0;
+
+    int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int) override
+    {
+        const int pc = pad / 2;
+        p.w = w, p.h = h;
+        p.src_y = src[0], p.src_u = src[1], p.src_v = src[2];
+        p.ref_stride_y = w + 2 * pad, p.ref_stride_c = w / 2 + 2 * pc;
+        p.ref_y = ref[0] ? ref[0] + (size_t)pad * p.ref_stride_y + pad : nullptr;
+        p.ref_u = ref[1] ? ref[1] + (size_t)pc * p.ref_stride_c + pc : nullptr;
+        p.ref_v = ref[2] ? ref[2] + (size_t)pc * p.ref_stride_c + pc : nullptr;
+        return 0;
+    }
+
     int evaluate(int lane, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
     {
         std::lock_guard<std::mutex> lk(mu);     // the oracle's transform chain keeps a static work buffer
@@ -43,7 +58,93 @@ public:
         return 0;
     }
 
+    int evaluate_intra(int lane, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch) override
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<uint8_t> &bytes = lane_bytes[lane & 7];
+        std::vector<int16_t> &words = lane_words[lane & 7];
+        size_t n = 0;
+        for (int i = 0; i < npu; i++) n += (size_t)pu[i]->size * pu[i]->size;
+        for (int i = 0; i < nch; i++) n += 2 * (size_t)ch[i]->size * ch[i]->size;
+        bytes.assign(n, 0);
+        words.assign(n, 0);
+        uint8_t *b = bytes.data();
+        int16_t *w = words.data();
+        for (int i = 0; i < npu; i++) one_intra(*pu[i], b, w);
+        for (int i = 0; i < nch; i++) one_intra_chroma(*ch[i], b, w);
+        return 0;
+    }
+
 private:
+    // xg_aucIntraFilterType (src/table.cpp:32): which modes predict from the smoothed samples
+    static bool smoothed(int size, int mode)
+    {
+        if (size == 8) return mode == 0 || mode == 2 || mode == 18 || mode == 34;
+        if (size == 16) return !(mode == 1 || (mode >= 9 && mode <= 11) || (mode >= 25 && mode <= 27));
+        if (size == 32) return !(mode == 1 || mode == 10 || mode == 26);
+        return false;
+    }
+
+    void one_intra(IntraEval &q, uint8_t *&b, int16_t *&w)
+    {
+        const int n = q.size;
+        uint8_t cur[32 * 64], pred[32 * 64], rec[32 * 80], raw[132], flt[132];
+        int16_t lev[32 * 64];
+        for (int r = 0; r < n; r++) std::memcpy(cur + r * 64, p.src_y + (size_t)(q.y0 + r) * p.w + q.x0, (size_t)n);
+        orc_intra_result res;
+        orc_intra_search(cur, 64, q.ref, n, q.valids, q.strong, q.mpm, q.sqrt_lambda, &res);
+        q.best_mode = res.best_mode;
+        if (q.valids) {
+            std::memcpy(raw, q.ref, (size_t)(4 * n + 1));
+            orc_padding_ref(raw, n, q.valids);
+            orc_filter_ref(flt, raw, n, q.strong);
+        } else {
+            std::memset(raw, 0x80, sizeof raw), std::memset(flt, 0x80, sizeof flt);
+        }
+        orc_intra_pred(pred, smoothed(n, res.best_mode) ? flt : raw, 64, res.best_mode, n, n != 32);
+        std::memset(lev, 0, sizeof lev);
+        q.sum = orc_tu_chain(cur, pred, rec, lev, n, 64, 80, (unsigned)q.qp, (unsigned)res.best_mode, ORC_SLICE_I);
+        q.ssd = orc_ssd(n, cur, 64, rec, 80);
+        for (int r = 0; r < n; r++) {
+            std::memcpy(b + r * n, rec + r * 80, (size_t)n);
+            std::memcpy(w + r * n, lev + r * 64, (size_t)n * 2);
+        }
+        q.rec = b, q.level = w;
+        b += n * n, w += n * n;
+    }
+
+    void one_intra_chroma(IntraChromaEval &c, uint8_t *&b, int16_t *&w)
+    {
+        const int n = c.size, wc = p.w / 2;
+        uint8_t cur[2][16 * 32], pred[16 * 32], rec[16 * 40], ref[2][68];
+        int16_t lev[16 * 32];
+        for (int pl = 0; pl < 2; pl++) {
+            const uint8_t *src = pl ? p.src_v : p.src_u;
+            for (int r = 0; r < n; r++) std::memcpy(cur[pl] + r * 32, src + (size_t)(c.y0 + r) * wc + c.x0, (size_t)n);
+            if (c.valids) {
+                std::memcpy(ref[pl], pl ? c.ref_v : c.ref_u, (size_t)(4 * n + 1));
+                orc_padding_ref(ref[pl], n, c.valids);
+            } else {
+                std::memset(ref[pl], 0x80, sizeof ref[pl]);
+            }
+        }
+        orc_chroma_result res;
+        orc_intra_chroma_search(cur[0], cur[1], 32, ref[0], ref[1], n, c.luma_mode, &res);
+        c.best_idx = res.best_idx;
+        for (int pl = 0; pl < 2; pl++) {
+            orc_intra_pred(pred, ref[pl], 32, res.best_mode, n, 0);
+            std::memset(lev, 0, sizeof lev);
+            const uint32_t sum = orc_tu_chain(cur[pl], pred, rec, lev, n, 32, 40, (unsigned)c.qpc, ORC_MODE_INVALID, ORC_SLICE_I);
+            for (int r = 0; r < n; r++) {
+                std::memcpy(b + r * n, rec + r * 40, (size_t)n);
+                std::memcpy(w + r * n, lev + r * 32, (size_t)n * 2);
+            }
+            (pl ? c.sum_v : c.sum_u) = sum;
+            (pl ? c.rec_v : c.rec_u) = b, (pl ? c.level_v : c.level_u) = w;
+            b += n * n, w += n * n;
+        }
+    }
+
     // transform chain(s) of a size x size block held with 64-sample rows; results packed with `size`-sample rows
     static uint32_t chains(const uint8_t *pix, const uint8_t *pred, int size, int qp, uint32_t sum[4], uint8_t *rec_out, int16_t *lev_out, int stride)
     {
@@ -130,6 +231,50 @@ private:
     }
 };
 
+// the picture-level passes of the encoder on the checker's primitives
+class CpuFrameOps : public xmi::encoder::FrameOps {
+public:
+    int deblock(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv, uint8_t *y, uint8_t *u,
+                uint8_t *v) override
+    {
+        const size_t n = (size_t)(width / 8) * (height / 4);
+        std::vector<uint8_t> vbs(n), hbs(n), qp_tab((size_t)(width / 4) * (height / 4), (uint8_t)qp);
+        orc_deblock_strengths(width, height, intra_slice, unit_log2, cbf, mv, vbs.data(), hbs.data());
+        const orc_deblock_params dp = { width, height, width, width / 2, 0, 0, 0, 0 };
+        orc_deblock_frame(y, u, v, &dp, vbs.data(), hbs.data(), qp_tab.data());
+        return 0;
+    }
+    int sao_stats(int width, int height, const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
+    {
+        const int cols = width / 64, rows = height / 64;
+        for (int cy = 0; cy < rows; cy++)
+            for (int cx = 0; cx < cols; cx++)
+                for (int c = 0; c < 3; c++) {
+                    int64_t count[5][33], off[5][33];
+                    const int pw = c ? width / 2 : width, ph = c ? height / 2 : height;
+                    orc_sao_stats_ctu(rec[c], pw, org[c], pw, pw, ph, cx, cy, c ? 32 : 64, c != 0, count, off);
+                    xmi::encoder::SaoStats &s = stats[(size_t)(cy * cols + cx) * 3 + c];
+                    for (int t = 0; t < 5; t++)
+                        for (int k = 0; k < 33; k++) s.count[t][k] = (int32_t)count[t][k], s.offset_org[t][k] = (int32_t)off[t][k];
+                }
+        return 0;
+    }
+    int sao_apply(uint8_t *plane, int width, int height, int ctu_size, const xmi::encoder::SaoCtuParam *params) override
+    {
+        std::vector<uint8_t> src(plane, plane + (size_t)width * height);
+        static_assert(sizeof(orc_sao_ctu_param) == sizeof(xmi::encoder::SaoCtuParam), "same layout");
+        orc_sao_apply_plane(src.data(), width, plane, width, width, height, ctu_size, reinterpret_cast<const orc_sao_ctu_param *>(params));
+        return 0;
+    }
+};
+
+struct EncHandle {
+    xmi::encoder::Encoder enc;
+    CpuEvaluator ev;
+    CpuFrameOps ops;
+    EncHandle(int w, int h, int qp, int strong) : enc(w, h, qp, strong) { ev.w = w, ev.h = h; }
+};
+
 struct Handle {
     Analyser an;
     CpuEvaluator ev;
@@ -194,7 +339,62 @@ int orc_analysis_p_picture(void *hv, const uint8_t *src_y, const uint8_t *src_u,
     return 0;
 }
 
+// ---- the whole encoder on the checker's primitives ----
+void *orc_encoder_create(int width, int height, int qp, int strong_intra_smoothing) { return new EncHandle(width, height, qp, strong_intra_smoothing); }
+void orc_encoder_destroy(void *h) { delete static_cast<EncHandle *>(h); }
+int orc_encoder_configure(void *h, int lanes, int spin_us)
+{
+    static_cast<EncHandle *>(h)->enc.analyser().lanes = lanes;
+    static_cast<EncHandle *>(h)->enc.analyser().spin_us = spin_us;
+    return 0;
+}
+// one picture: packed source planes at coded size, slice_type 1 = P / 2 = I; returns the access unit's size
+int orc_encoder_encode(void *hv, const uint8_t *y, const uint8_t *u, const uint8_t *v, int slice_type, uint8_t *out, size_t cap)
+{
+    EncHandle &H = *static_cast<EncHandle *>(hv);
+    return H.enc.encode(y, u, v, slice_type, H.ev, H.ops, out, cap);
+}
+// the last picture's decisions: arrays as orc_analysis_p_picture hands them out, plus the mode map and the rate counters
+void orc_encoder_analysis(void *hv, uint16_t *info0, uint8_t *info1, uint8_t *mode, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint8_t *rec_y,
+                          uint8_t *rec_u, uint8_t *rec_v, uint8_t *ctx_out, uint64_t *frac)
+{
+    EncHandle &H = *static_cast<EncHandle *>(hv);
+    const PictureResult &r = H.enc.analysis_result();
+    std::memcpy(info0, r.info0.data(), r.info0.size() * 2), std::memcpy(info1, r.info1.data(), r.info1.size()), std::memcpy(mode, r.mode.data(), r.mode.size());
+    std::memcpy(coef_y, r.coef_y.data(), r.coef_y.size() * 2), std::memcpy(coef_u, r.coef_u.data(), r.coef_u.size() * 2);
+    std::memcpy(coef_v, r.coef_v.data(), r.coef_v.size() * 2);
+    std::memcpy(rec_y, r.rec_y.data(), r.rec_y.size()), std::memcpy(rec_u, r.rec_u.data(), r.rec_u.size()), std::memcpy(rec_v, r.rec_v.data(), r.rec_v.size());
+    std::memcpy(ctx_out, r.ctx_out.data(), r.ctx_out.size());
+    std::memcpy(frac, H.enc.analyser().frac_bits.data(), H.enc.analyser().frac_bits.size() * 8);
+}
+
+// the last picture's SAO parameters: out[component][ctu][8] = typeIdx, subTypeIdx, offset[4], mergeLeftFlag, mergeUpFlag
+void orc_encoder_sao(void *hv, int32_t *out)
+{
+    const xmi::encoder::Encoder &e = static_cast<EncHandle *>(hv)->enc;
+    for (int c = 0; c < 3; c++)
+        for (const xmi::syntax::SaoUnit &u : e.sao_units(c)) {
+            const int32_t rec[8] = { u.type_idx, u.sub_type, u.offset[0], u.offset[1], u.offset[2], u.offset[3], u.merge_left, u.merge_up };
+            std::memcpy(out, rec, sizeof rec);
+            out += 8;
+        }
+}
+
+void orc_encoder_sao_stats(void *hv, int32_t *out)
+{
+    const xmi::encoder::Encoder &e = static_cast<EncHandle *>(hv)->enc;
+    std::memcpy(out, e.sao_statistics().data(), e.sao_statistics().size() * sizeof(xmi::encoder::SaoStats));
+}
+
+void orc_encoder_reconstruction(void *hv, uint8_t *y, uint8_t *u, uint8_t *v)
+{
+    const xmi::encoder::Encoder &e = static_cast<EncHandle *>(hv)->enc;
+    std::memcpy(y, e.rec_y().data(), e.rec_y().size()), std::memcpy(u, e.rec_u().data(), e.rec_u().size()), std::memcpy(v, e.rec_v().data(), e.rec_v().size());
+}
+
 const uint16_t *orc_analysis_scan(int log2_size) { return diag_scan(log2_size); }
+const uint16_t *orc_syntax_scan(int scan_idx, int log2_size) { return xmi::syntax::coef_scan(scan_idx, log2_size); }
+const uint8_t *orc_syntax_group_scan(int scan_idx, int log2_size) { return xmi::syntax::group_scan(scan_idx, log2_size); }
 const uint8_t *orc_analysis_next_state(void) { return next_state_table(); }
 void orc_analysis_init_contexts(int slice_type, int qp, uint8_t *ctx) { init_contexts(slice_type, qp, ctx); }
 

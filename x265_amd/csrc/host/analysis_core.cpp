@@ -6,6 +6,7 @@
 // wakes the rows. The number of evaluator calls per picture is therefore the length of the critical path through the
 // wavefront, not the number of CUs.
 #include "analysis_core.h"
+#include "syntax.h"
 
 #include <cmath>
 #include <atomic>
@@ -21,13 +22,8 @@ namespace xmi {
 namespace analysis {
 namespace {
 
-// ---- context layout (inc/x265.h:286-311) ----
-enum {
-    kCtxSplit = 0, kCtxSkip = 3, kCtxMergeFlag = 6, kCtxMergeIdx = 7, kCtxPartSize = 8, kCtxPredMode = 13, kCtxMvd = 22,
-    kCtxQtCbf = 29, kCtxQtRootCbf = 39, kCtxSigCg = 40, kCtxSig = 44, kCtxLastX = 86, kCtxLastY = 116, kCtxOne = 146,
-    kCtxAbs = 170, kCtxMvpIdx = 176,
-    kNumSigCg = 2, kNumSigLuma = 27, kNumLast = 15, kNumOneLuma = 16, kNumAbsLuma = 4
-};
+using namespace xmi::syntax;
+
 constexpr int kInvalid = 255, kValid = 0;                 // MODE_INVALID / MODE_VALID (inc/x265.h:163)
 constexpr int kFlagInter = 0x80, kOffCbfC = 8;            // ausModeYInfo0 bits (inc/x265.h:216-217)
 constexpr int kOffSize = 6, kOffCbfY = 5, kOff64 = 4, kMaskSkip = 1, kValidT = 3, kValidL = 1;   // aucModeYInfo1 bits
@@ -77,7 +73,8 @@ const uint8_t kLpsNext[64] = { 0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9
 
 struct Tables {
     uint8_t next[128][2];
-    uint16_t scan[4][1024];     // log2 size 2..5
+    uint16_t scan[3][4][1024];     // [diagonal / horizontal / vertical][log2 size 2..5]
+    uint8_t group[3][4][64];       // the same orders over the 4x4 groups of the block
     Tables()
     {
         for (int s = 0; s < 128; s++) {
@@ -87,22 +84,30 @@ struct Tables {
             next[s][mps ^ 1] = p == 0 ? (uint8_t)(mps ^ 1) : (uint8_t)(2 * kLpsNext[p] + mps);
         }
         next[126][0] = next[126][1] = 126, next[127][0] = next[127][1] = 127;   // the terminating state does not move
-        // up-right diagonal order of a 4x4 block (and of the 4x4 groups of a larger block): along every anti-diagonal from
-        // bottom-left to top-right
-        uint8_t d4[16], d8[64], d2[4];
-        auto diag = [](int n, uint8_t *o) {
+        // order of an n x n square: up-right diagonal (along every anti-diagonal from bottom-left to top-right), row by row,
+        // column by column
+        auto order = [](int kind, int n, uint8_t *o) {
             int k = 0;
-            for (int d = 0; d < 2 * n - 1; d++)
-                for (int y = d < n ? d : n - 1; y >= 0 && d - y < n; y--) o[k++] = (uint8_t)(y * n + (d - y));
+            if (kind == kScanDiag) {
+                for (int d = 0; d < 2 * n - 1; d++)
+                    for (int y = d < n ? d : n - 1; y >= 0 && d - y < n; y--) o[k++] = (uint8_t)(y * n + (d - y));
+            } else {
+                for (int i = 0; i < n * n; i++) o[k++] = (uint8_t)(kind == kScanHor ? i : (i % n) * n + i / n);
+            }
         };
-        diag(2, d2), diag(4, d4), diag(8, d8);
-        for (int l = 2; l <= 5; l++) {
-            const int n = 1 << l, g = n / 4;
-            const uint8_t *go = g == 1 ? nullptr : g == 2 ? d2 : g == 4 ? d4 : d8;
-            int k = 0;
-            for (int gi = 0; gi < g * g; gi++) {
-                const int gp = go ? go[gi] : 0, gy = gp / g, gx = gp % g;
-                for (int i = 0; i < 16; i++) scan[l - 2][k++] = (uint16_t)((gy * 4 + d4[i] / 4) * n + gx * 4 + d4[i] % 4);
+        for (int kind = 0; kind < 3; kind++) {
+            uint8_t in4[16];
+            order(kind, 4, in4);
+            for (int l = 2; l <= 5; l++) {
+                const int n = 1 << l, g = n / 4;
+                uint8_t *go = group[kind][l - 2];
+                if (g == 1) go[0] = 0;
+                else order(kind, g, go);
+                int k = 0;
+                for (int gi = 0; gi < g * g; gi++) {
+                    const int gy = go[gi] / g, gx = go[gi] % g;
+                    for (int i = 0; i < 16; i++) scan[kind][l - 2][k++] = (uint16_t)((gy * 4 + in4[i] / 4) * n + gx * 4 + in4[i] % 4);
+                }
             }
         }
     }
@@ -131,151 +136,10 @@ struct Rate {
         frac += (uint64_t)kEntropyBits[s ^ b];
         w->m[c] = transitions ? tables().next[s][b] : 0;
     }
-    void ep(unsigned n) { frac += 32768ull * n; }
+    void ep(unsigned, int n) { frac += 32768ull * (unsigned)n; }
     void begin() { frac &= 32767; }
     uint32_t bits() const { return (uint32_t)(frac >> 15); }
 };
-
-inline int ilog2(int v)
-{
-    int l = 0;
-    while ((1 << l) < v) l++;
-    return l;
-}
-
-// ---- residual syntax of one transform block, rate only (xEncodeCoeffNxN, src/encode.cpp:2385-2553, diagonal scan) ----
-const uint8_t kGroupIdx[32] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9 };
-
-void rate_last_xy(Rate &r, int x, int y, int log2, bool luma)
-{
-    const int size = 1 << log2;
-    const int cx = kCtxLastX + (luma ? 0 : kNumLast), cy = kCtxLastY + (luma ? 0 : kNumLast);
-    const int gx = kGroupIdx[x], gy = kGroupIdx[y], gmax = kGroupIdx[size - 1];
-    const int off = luma ? (log2 - 2) * 3 + ((log2 - 1) >> 2) : 0, sh = luma ? (log2 + 1) >> 2 : log2 - 2;
-    for (int c = 0; c < gx; c++) r.bin(1, cx + off + (c >> sh));
-    if (gx < gmax) r.bin(0, cx + off + (gx >> sh));
-    for (int c = 0; c < gy; c++) r.bin(1, cy + off + (c >> sh));
-    if (gy < gmax) r.bin(0, cy + off + (gy >> sh));
-    if (gx > 3) r.ep((gx - 2) >> 1);
-    if (gy > 3) r.ep((gy - 2) >> 1);
-}
-
-int sig_ctx(int pattern, int x, int y, int log2, bool luma)
-{
-    static const uint8_t map4[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
-    if (x + y == 0) return 0;
-    if (log2 == 2) return map4[4 * y + x];
-    const int off = log2 == 3 ? 9 : (luma ? 21 : 12);       // diagonal scan
-    const int xs = x & 3, ys = y & 3;
-    int cnt;
-    if (pattern == 0) cnt = xs + ys <= 2 ? (xs + ys == 0 ? 2 : 1) : 0;
-    else if (pattern == 1) cnt = ys <= 1 ? (ys == 0 ? 2 : 1) : 0;
-    else if (pattern == 2) cnt = xs <= 1 ? (xs == 0 ? 2 : 1) : 0;
-    else cnt = 2;
-    return ((luma && ((x >> 2) + (y >> 2)) > 0) ? 3 : 0) + off + cnt;
-}
-
-void rate_remaining(Rate &r, unsigned v, unsigned rice)
-{
-    if (v < (3u << rice)) {
-        r.ep((v >> rice) + 1);
-        if (rice) r.ep(rice);
-    } else {
-        unsigned len = rice, code = v - (3u << rice);
-        while (code >= (1u << len)) {
-            code -= 1u << len;
-            len++;
-        }
-        r.ep(3 + len + 1 - rice);
-        if (len) r.ep(len);
-    }
-}
-
-void rate_coefficients(Rate &r, const int16_t *coef, int stride, int size, bool luma)
-{
-    const int log2 = ilog2(size), side = size >> 2;
-    const uint16_t *scan = tables().scan[log2 - 2];
-    uint8_t cg_flag[64] = {};
-    unsigned remaining = 0;
-    for (int y = 0; y < size; y++)
-        for (int x = 0; x < size; x++) remaining += coef[y * stride + x] != 0;
-    int last = -1, lx = 0, ly = 0;
-    do {
-        const int p = scan[++last];
-        ly = p >> log2, lx = p - (ly << log2);
-        if (coef[ly * stride + lx]) {
-            cg_flag[side * (ly >> 2) + (lx >> 2)] = 1;
-            remaining--;
-        }
-    } while (remaining > 0);
-    rate_last_xy(r, lx, ly, log2, luma);
-
-    const int base_cg = kCtxSigCg + (luma ? 0 : kNumSigCg), base_sig = kCtxSig + (luma ? 0 : kNumSigLuma);
-    const int last_set = last >> 4;
-    unsigned c1 = 1;
-    int pos = last;
-    for (int set = last_set; set >= 0; set--) {
-        const int first = set << 4;
-        int16_t mag[16];
-        int n = 0;
-        unsigned rice = 0;
-        if (pos == last) {
-            mag[0] = (int16_t)std::abs((int)coef[ly * stride + lx]);
-            n = 1;
-            pos--;
-        }
-        // the group this subset covers: the position of its first coefficient names it
-        const int p0 = scan[first], gy = (p0 >> log2) >> 2, gx = (p0 & (size - 1)) >> 2, g = gy * side + gx;
-        const bool right = gx < side - 1 && cg_flag[g + 1], below = gy < side - 1 && cg_flag[g + side];
-        if (set == last_set || set == 0) cg_flag[g] = 1;
-        else r.bin(cg_flag[g] != 0, base_cg + (right || below));
-        if (cg_flag[g]) {
-            const int pattern = size == 4 ? -1 : (int)right + 2 * (int)below;
-            for (; pos >= first; pos--) {
-                const int p = scan[pos], y = p >> log2, x = p - (y << log2);
-                const int v = coef[y * stride + x];
-                if (pos != first || set == 0 || n) r.bin(v != 0, base_sig + sig_ctx(pattern, x, y, log2, luma));
-                if (v) mag[n++] = (int16_t)std::abs(v);
-            }
-        } else {
-            pos = first - 1;
-        }
-        if (n > 0) {
-            unsigned ctx_set = (set > 0 && luma) ? 2 : 0;
-            if (c1 == 0) ctx_set++;
-            c1 = 1;
-            int base = kCtxOne + 4 * ctx_set + (luma ? 0 : kNumOneLuma);
-            const int n1 = n < 8 ? n : 8;
-            int first_g1 = 16;
-            for (int i = 0; i < n1; i++) {
-                const unsigned g1 = mag[i] > 1;
-                r.bin(g1, base + c1);
-                if (g1) {
-                    c1 = 0;
-                    if (first_g1 > i) first_g1 = i;
-                } else if (c1 != 0) {
-                    c1 = c1 + 1 < 3 ? c1 + 1 : 3;
-                }
-            }
-            if (c1 == 0) {
-                base = kCtxAbs + ctx_set + (luma ? 0 : kNumAbsLuma);
-                if (first_g1 != 16) r.bin(mag[first_g1] > 2, base);
-            }
-            r.ep(n);   // signs
-            int first2 = 1;
-            if (c1 == 0 || n > 8) {
-                for (int i = 0; i < n; i++) {
-                    const int base_level = i < 8 ? 2 + first2 : 1;
-                    if (mag[i] >= base_level) {
-                        rate_remaining(r, mag[i] - base_level, rice);
-                        if (mag[i] > 3 * (1 << rice)) rice = rice + 1 < 4 ? rice + 1 : 4;
-                    }
-                    if (mag[i] >= 2) first2 = 0;
-                }
-            }
-        }
-    }
-}
 
 // Bits of the luma part of one CU as xPreEncRec counts them (src/encode.cpp:3038-3077): prediction mode, part size, the
 // coded-block flag of each transform unit and its coefficients, and the root flag of a 64x64 CU.
@@ -293,13 +157,13 @@ uint32_t rate_cu_luma(Rate &r, const int16_t *level, int size, const uint32_t su
                 *cbf |= (s ? 1 : 0) << (j * 2 + i);
                 total += s;
                 r.bin(s != 0, kCtxQtCbf);
-                if (s) rate_coefficients(r, level + j * 32 * 64 + i * 32, 64, 32, true);
+                if (s) code_coefficients(r, level + j * 32 * 64 + i * 32, 64, 32, true, kScanDiag);
             }
         r.bin(total != 0, kCtxQtRootCbf);
     } else {
         *cbf = sum[0] ? 1 : 0;
         r.bin(sum[0] != 0, kCtxQtCbf);
-        if (sum[0]) rate_coefficients(r, level, size, size, true);
+        if (sum[0]) code_coefficients(r, level, size, size, true, kScanDiag);
     }
     return r.bits();
 }
@@ -308,24 +172,7 @@ uint32_t rate_cu_luma(Rate &r, const int16_t *level, int size, const uint32_t su
 // src/encode.cpp:4482-4523, 2357-2382)
 void rate_mvd(Rate &r, int dx, int dy, int mvp_idx)
 {
-    const unsigned ax = (unsigned)std::abs(dx), ay = (unsigned)std::abs(dy);
-    r.bin(ax != 0, kCtxMvd);
-    r.bin(ay != 0, kCtxMvd);
-    if (ax) r.bin(ax > 1, kCtxMvd + 1);
-    if (ay) r.bin(ay > 1, kCtxMvd + 1);
-    auto golomb1 = [&](unsigned v) {   // first-order Exp-Golomb, one bypass command
-        unsigned k = 1, bins = 0;
-        while (v >= (1u << k)) v -= 1u << k, k++, bins++;
-        r.ep(bins + 1 + k);
-    };
-    if (ax) {
-        if (ax > 1) golomb1(ax - 2);
-        r.ep(1);
-    }
-    if (ay) {
-        if (ay > 1) golomb1(ay - 2);
-        r.ep(1);
-    }
+    code_mvd(r, dx, dy);
     r.bin(mvp_idx ? 1 : 0, kCtxMvpIdx);
 }
 
@@ -363,6 +210,17 @@ struct Row {
     uint64_t busy_ns = 0, requests = 0;
     std::chrono::steady_clock::time_point t_resume = std::chrono::steady_clock::now();
     std::vector<ChromaEval> chroma_req;
+    // I pictures: the unfiltered reconstruction next to the CTU - the row above from x0 - 1 to x0 + 127 and the column to the
+    // left (the reference's aucTopPix line buffers and the left column of its CTU cache) -, the requests per PU size
+    // 4 / 8 / 16 / 32 (a PU's request carries those of its chain of first children, as for inter CUs) and the chroma request
+    uint8_t top_y[1 + 128], left_y[64], top_u[1 + 64], left_u[32], top_v[1 + 64], left_v[32];
+    IntraEval in_spec[4];
+    bool in_ok[4] = { false, false, false, false };
+    IntraChromaEval ichroma;
+    IntraEval *req_in[4] = {};
+    int n_req_in = 0;
+    bool req_ichroma = false;
+    int strong = 0;
     // The request hand-over takes no lock: the row fills its own slots, raises `pending` and counts itself out of its
     // lane's `running`; the lane's coordinator reads the slots of the rows it finds pending, and lowers `pending` when the
     // answers are in place. Only a waiter whose polling time has run out takes the mutex, to sleep.
@@ -381,10 +239,28 @@ struct Row {
     int fill_candidates(Mv out[7], int r4, int c4, int r8, int c8, int size);
     uint32_t decide(int px, int py, int size, int depth);
     void chroma_pass();
+    int sample_y(int yy, int xx) const
+    {
+        if (yy < 0) return top_y[xx + 1];
+        if (xx < 0) return yy < 64 ? left_y[yy] : 0x80;
+        return xx < 64 && yy < 64 ? rec_y[yy * 64 + xx] : 0x80;
+    }
+    int sample_c(const uint8_t *top, const uint8_t *left, const uint8_t *rec, int yy, int xx) const
+    {
+        if (yy < 0) return top[xx + 1];
+        if (xx < 0) return yy < 32 ? left[yy] : 0x80;
+        return xx < 32 && yy < 32 ? rec[yy * 32 + xx] : 0x80;
+    }
+    void fill_intra(IntraEval &q, int px, int py, int size);
+    double decide_intra(int px, int py, int size, int depth);
+    void intra_chroma_pass();
+
     void collect_cus(int px, int py, int size, std::vector<int> &list);
     void run();
     void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
+    void evaluate_intra(IntraEval *const *list, int n);
+    void evaluate_intra_chroma();
     void post_and_wait();
 };
 
@@ -413,6 +289,8 @@ struct Shared {
     Analyser *an = nullptr;
     PictureResult *out = nullptr;
     int w = 0, h = 0, cols = 0, nrows = 0, qp = 0;
+    bool intra = false;             // I picture
+    int strong = 0;                 // its bStrongIntraSmoothing
 };
 
 struct Abort {};
@@ -520,7 +398,7 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         rate.begin();
         rate.bin(1, kCtxMergeFlag);
         rate.bin(k != 0, kCtxMergeIdx);
-        if (k) rate.ep(k);
+        if (k) rate.ep(0, k);
         const uint32_t merge_bits = rate.bits();
         double cost = q.ssd_merge + lambda * (coeff_bits + merge_bits);
         const double cost_skip = q.ssd_skip + lambda * merge_bits;
@@ -791,14 +669,175 @@ void Row::evaluate_chroma()
     req_chroma = false;
 }
 
-// the row loop of xEncodeCUs (src/encode.cpp:5233-5590), P slices
+void Row::evaluate_intra(IntraEval *const *list, int n)
+{
+    for (int i = 0; i < n; i++) req_in[i] = list[i];
+    n_req_in = n, n_req_cu = 0;
+    req_chroma = req_ichroma = false;
+    post_and_wait();
+    n_req_in = 0;
+}
+
+void Row::evaluate_intra_chroma()
+{
+    n_req_in = n_req_cu = 0;
+    req_chroma = false, req_ichroma = true;
+    post_and_wait();
+    req_ichroma = false;
+}
+
+// request of the PU at (px, py) of the CTU: availability, most probable modes, neighbouring samples (src/encode.cpp:3964-4015)
+void Row::fill_intra(IntraEval &q, int px, int py, int size)
+{
+    const int r4 = py / 4, c4 = px / 4, b4 = size / 4;
+    q.x0 = ctu_x * 64 + px, q.y0 = y * 64 + py, q.size = size;
+    const bool lb = M(r4 + b4, c4 - 1) != kInvalid, l = M(r4, c4 - 1) != kInvalid, lt = M(r4 - 1, c4 - 1) != kInvalid;
+    const bool t = M(r4 - 1, c4) != kInvalid, tr = M(r4 - 1, c4 + b4) != kInvalid;
+    q.valids = (uint8_t)((lb ? 1 : 0) | (l ? 2 : 0) | (lt ? 4 : 0) | (t ? 8 : 0) | (tr ? 16 : 0));
+    q.strong = (uint8_t)strong;
+    const int left = l ? M(r4, c4 - 1) : 1, top = (t && py) ? M(r4 - 1, c4) : 1;      // DC where there is no neighbour, and above the CTU
+    if (left == top) {
+        if (left > 1) q.mpm[0] = (uint8_t)left, q.mpm[1] = (uint8_t)(((left + 29) % 32) + 2), q.mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+        else q.mpm[0] = 0, q.mpm[1] = 1, q.mpm[2] = 26;
+    } else {
+        q.mpm[0] = (uint8_t)left, q.mpm[1] = (uint8_t)top;
+        q.mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+    }
+    for (int i = 0; i < 2 * size; i++) q.ref[i] = (uint8_t)sample_y(py + 2 * size - 1 - i, px - 1);
+    for (int i = 0; i <= 2 * size; i++) q.ref[2 * size + i] = (uint8_t)sample_y(py - 1, px - 1 + i);
+    q.sqrt_lambda = std::sqrt(lambda);
+    q.qp = qp;
+}
+
+// xEncDecideCU_Intra (src/encode.cpp:3906-4215)
+double Row::decide_intra(int px, int py, int size, int depth)
+{
+    const int log2 = ilog2(size), li = log2 - 2, b4 = size / 4, r4 = py / 4, c4 = px / 4;
+    Ctx &work = cab[0];
+    work = cab[depth];
+    double best = kDoubleMax;
+    int best_mode = 0, pred_idx = 0, valids = 0;
+    if (size < 64) {
+        IntraEval &q = in_spec[li];
+        if (!(in_ok[li] && q.x0 == ctu_x * 64 + px && q.y0 == y * 64 + py && q.size == size)) {
+            IntraEval *list[4];
+            int n = 0;
+            fill_intra(q, px, py, size);
+            list[n++] = &q;
+            for (int sz = size / 2, l = li - 1; sh->speculate && sz >= 4; sz /= 2, l--) {
+                fill_intra(in_spec[l], px, py, sz);
+                in_ok[l] = true;
+                list[n++] = &in_spec[l];
+            }
+            evaluate_intra(list, n);
+        }
+        in_ok[li] = false;
+        best_mode = q.best_mode, valids = q.valids;
+        // the coded index of the mode: its rank among the most probable modes, else its rank among the other 32 (:4048-4081)
+        int m[3] = { q.mpm[0], q.mpm[1], q.mpm[2] };
+        if (best_mode == m[0]) pred_idx = 0;
+        else if (best_mode == m[1]) pred_idx = 1;
+        else if (best_mode == m[2]) pred_idx = 2;
+        else {
+            if (m[0] > m[1]) std::swap(m[0], m[1]);
+            if (m[0] > m[2]) std::swap(m[0], m[2]);
+            if (m[1] > m[2]) std::swap(m[1], m[2]);
+            pred_idx = best_mode;
+            pred_idx -= pred_idx > m[2];
+            pred_idx -= pred_idx > m[1];
+            pred_idx -= pred_idx > m[0];
+            pred_idx += 3;
+        }
+        int cbf = 0;
+        const uint32_t sum[4] = { q.sum, 0, 0, 0 };
+        const uint32_t coeff_bits = rate_cu_luma(rate, q.level, size, sum, &cbf);
+        rate.begin();
+        if (size <= 8) rate.bin(size == 8, kCtxPartSize);
+        const unsigned pi[4] = { (unsigned)pred_idx, 0, 0, 0 };
+        code_intra_dir_luma(rate, 1, pi);
+        const uint32_t mode_bits = rate.bits();
+        best = (int)q.ssd + lambda * (double)(coeff_bits + mode_bits);
+        cab[depth] = work;
+        std::memcpy(best_rec[li], q.rec, (size_t)size * size);
+        std::memcpy(best_coef[li], q.level, (size_t)size * size * 2);
+        best_cbf[li] = cbf;
+    }
+    bool replace = size == 4;
+    double sub = kDoubleMax;
+    if (size > 4 && best >= 0) {
+        const int half = size / 2;
+        double c[4];
+        for (int part = 0; part < 4; part++) c[part] = decide_intra(px + (part & 1) * half, py + (part >> 1) * half, half, depth + 1);
+        sub = c[0] + c[1] + c[2] + c[3] + 4;
+        if (sub >= best) {
+            replace = true;
+            for (int d = depth + 1; d < 5; d++) cab[d] = cab[depth];
+        } else {
+            cab[depth] = cab[depth + 1];
+        }
+    }
+    if (replace) {
+        block_in(rec_y + py * 64 + px, 64, best_rec[li], size, size, size);
+        block_in(coef_y + py * 64 + px, 128, best_coef[li], size * 2, size, size * 2);
+        I0(r4, c4) = (uint16_t)pred_idx;
+        const uint8_t f = (uint8_t)((valids & 0x3f) | (best_cbf[li] ? 1 << kOffCbfY : 0) | ((log2 - 2) << kOffSize));
+        for (int i = 0; i < b4; i++)
+            for (int j = 0; j < b4; j++) {
+                M(r4 + i, c4 + j) = (uint8_t)best_mode;
+                I1(r4 + i, c4 + j) = f;
+            }
+    }
+    return best < sub ? best : sub;
+}
+
+// xEncodeChromaCU (src/encode.cpp:4234-4418): the PUs of the decided CTU in coding order
+void Row::intra_chroma_pass()
+{
+    auto interleave = [](int v) { return (v & 1) | ((v >> 1) & 2) | ((v >> 2) & 4) | ((v >> 3) & 8); };
+    for (int idx = 0; idx != 256;) {
+        const int dx = interleave(idx), dy = interleave(idx >> 1);
+        int size_y = 1 << (2 + (I1(dy, dx) >> kOffSize));
+        const int size = size_y == 4 ? 4 : size_y >> 1;
+        int valids = I1(dy, dx) & 0x1f;
+        if (size_y == 4) {      // the chroma block of four 4x4 luma PUs: below-left from the PU below, top-right from the PU to the right
+            valids &= ~0x11;
+            valids |= I1(dy + 1, dx) & 0x01;
+            valids |= I1(dy, dx + 1) & 0x10;
+        }
+        IntraChromaEval &c = ichroma;
+        const int cx = dx * 2, cy = dy * 2;
+        c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy, c.size = size;
+        c.valids = (uint8_t)valids, c.luma_mode = M(dy, dx);
+        c.qpc = chroma_qp(qp);
+        for (int i = 0; i < 2 * size; i++) {
+            c.ref_u[i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy + 2 * size - 1 - i, cx - 1);
+            c.ref_v[i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy + 2 * size - 1 - i, cx - 1);
+        }
+        for (int i = 0; i <= 2 * size; i++) {
+            c.ref_u[2 * size + i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy - 1, cx - 1 + i);
+            c.ref_v[2 * size + i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy - 1, cx - 1 + i);
+        }
+        evaluate_intra_chroma();
+        block_in(rec_u + cy * 32 + cx, 32, c.rec_u, size, size, size);
+        block_in(rec_v + cy * 32 + cx, 32, c.rec_v, size, size, size);
+        block_in(coef_u + cy * 32 + cx, 64, c.level_u, size * 2, size, size * 2);
+        block_in(coef_v + cy * 32 + cx, 64, c.level_v, size * 2, size, size * 2);
+        const int cbf_c = (c.sum_v ? 2 : 0) | (c.sum_u ? 1 : 0);
+        I0(dy, dx) |= (uint16_t)((c.best_idx << 13) | (cbf_c << kOffCbfC));
+        if (size_y == 4) size_y = 8;
+        idx += size_y * size_y / 16;
+    }
+}
+
+// the row loop of xEncodeCUs (src/encode.cpp:5233-5590)
 void Row::run()
 {
     Shared &S = *sh;
     PictureResult &out = *S.out;
     const int cols = S.cols, w4 = S.w / 4, w8 = S.w / 8;
     qp = S.qp;
-    lambda = 0.578 * std::pow(2.0, (qp - 12) / 3.0);
+    lambda = (S.intra ? 0.57 : 0.578) * std::pow(2.0, (qp - 12) / 3.0);      // src/encode.cpp:5348, 5406
+    strong = S.strong;
     rate.frac = S.an->frac_bits[y];
     rate.transitions = y == 0;
     rate.w = &cab[0];
@@ -808,6 +847,7 @@ void Row::run()
         for (int x = 0; x < cols; x++) {
             ctu_x = x;
             spec_ok[0] = spec_ok[1] = spec_ok[2] = spec_ok[3] = false;
+            in_ok[0] = in_ok[1] = in_ok[2] = in_ok[3] = false;
             if (y > 0) {   // top-right neighbour done (or the whole row above)
                 const int need = x + 2 < cols ? x + 2 : cols;
                 std::unique_lock<std::mutex> lk(S.m);
@@ -838,7 +878,7 @@ void Row::run()
             }
             if (x > 0) {
                 for (int r = 0; r < 16; r++) {
-                    M(r, -1) = kValid;
+                    M(r, -1) = out.mode[(size_t)(y * 16 + r) * w4 + x * 16 - 1];      // MODE_VALID in P pictures
                     I1(r, -1) = out.info1[(size_t)(y * 16 + r) * w4 + x * 16 - 1];
                 }
                 for (int r = 0; r < 8; r++) V(r, -1) = out.mv[(size_t)(y * 8 + r) * w8 + x * 8 - 1];
@@ -850,14 +890,42 @@ void Row::run()
             min_ipel.x = (int16_t)clip64(-64 * x - 64), max_ipel.x = (int16_t)clip64(64 * (cols - x));
             min_ipel.y = (int16_t)clip64(-64 * y - 64), max_ipel.y = (int16_t)clip64(64 * (S.nrows - y));
 
-            out.rd_cost[(size_t)y * cols + x] = decide(0, 0, 64, 0);
-            chroma_pass();
+            if (S.intra) {
+                // the unfiltered reconstruction above and to the left of the CTU, as far as the picture has it
+                const int wc = S.w / 2;
+                std::memset(top_y, 0x80, sizeof top_y), std::memset(top_u, 0x80, sizeof top_u), std::memset(top_v, 0x80, sizeof top_v);
+                std::memset(left_y, 0x80, sizeof left_y), std::memset(left_u, 0x80, sizeof left_u), std::memset(left_v, 0x80, sizeof left_v);
+                if (y > 0) {
+                    for (int i = 0; i <= 128; i++) {
+                        const int gx = x * 64 - 1 + i;
+                        if (gx >= 0 && gx < S.w) top_y[i] = out.rec_y[(size_t)(y * 64 - 1) * S.w + gx];
+                    }
+                    for (int i = 0; i <= 64; i++) {
+                        const int gx = x * 32 - 1 + i;
+                        if (gx >= 0 && gx < wc) top_u[i] = out.rec_u[(size_t)(y * 32 - 1) * wc + gx], top_v[i] = out.rec_v[(size_t)(y * 32 - 1) * wc + gx];
+                    }
+                }
+                if (x > 0) {
+                    for (int r = 0; r < 64; r++) left_y[r] = out.rec_y[(size_t)(y * 64 + r) * S.w + x * 64 - 1];
+                    for (int r = 0; r < 32; r++) {
+                        left_u[r] = out.rec_u[(size_t)(y * 32 + r) * wc + x * 32 - 1];
+                        left_v[r] = out.rec_v[(size_t)(y * 32 + r) * wc + x * 32 - 1];
+                    }
+                }
+                std::memset(mvd, 0, sizeof mvd), std::memset(mvp_idx, 0, sizeof mvp_idx);
+                out.rd_cost[(size_t)y * cols + x] = (uint32_t)decide_intra(0, 0, 64, 0);
+                intra_chroma_pass();
+            } else {
+                out.rd_cost[(size_t)y * cols + x] = decide(0, 0, 64, 0);
+                chroma_pass();
+            }
 
             last = cab[0];
             std::memcpy(&out.ctx_out[((size_t)y * cols + x) * 256], cab[0].m, 256);
             for (int r = 0; r < 16; r++) {
                 std::memcpy(&out.info0[(size_t)(y * 16 + r) * w4 + x * 16], &I0(r, 0), 32);
                 std::memcpy(&out.info1[(size_t)(y * 16 + r) * w4 + x * 16], &I1(r, 0), 16);
+                std::memcpy(&out.mode[(size_t)(y * 16 + r) * w4 + x * 16], &M(r, 0), 16);
             }
             for (int r = 0; r < 8; r++) {
                 std::memcpy(&out.mv[(size_t)(y * 8 + r) * w8 + x * 8], &V(r, 0), 8 * sizeof(Mv));
@@ -905,8 +973,9 @@ int chroma_qp(int qp)
 }
 
 const uint8_t *next_state_table() { return &tables().next[0][0]; }
+const int32_t *entropy_bits_table() { return kEntropyBits; }
 
-const uint16_t *diag_scan(int log2_size) { return log2_size >= 2 && log2_size <= 5 ? tables().scan[log2_size - 2] : nullptr; }
+const uint16_t *diag_scan(int log2_size) { return log2_size >= 2 && log2_size <= 5 ? tables().scan[0][log2_size - 2] : nullptr; }
 
 void init_contexts(int slice_type, int qp, uint8_t ctx[256])
 {
@@ -930,11 +999,14 @@ Analyser::Analyser(int width, int height) : w_(width), h_(height), rows_(height 
     frac_bits.assign(rows_, 0);
 }
 
-int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
+int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out) { return picture(qp, false, 0, ev, out); }
+int Analyser::i_picture(int qp, int strong_intra_smoothing, Evaluator &ev, PictureResult &out) { return picture(qp, true, strong_intra_smoothing, ev, out); }
+
+int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResult &out)
 {
     if (w_ <= 0 || h_ <= 0 || w_ % 64 || h_ % 64 || qp < 0 || qp > 51) return -1;
     const size_t n4 = (size_t)(w_ / 4) * (h_ / 4), n8 = (size_t)(w_ / 8) * (h_ / 8), ny = (size_t)w_ * h_, nctu = (size_t)rows_ * cols_;
-    out.info0.assign(n4, 0), out.info1.assign(n4, 0);
+    out.info0.assign(n4, 0), out.info1.assign(n4, 0), out.mode.assign(n4, 0);
     out.mv.assign(n8, Mv{ 0, 0 }), out.mvd.assign(n8, Mv{ 0, 0 }), out.mvp_idx.assign(n8, 0);
     out.coef_y.assign(ny, 0), out.coef_u.assign(ny / 4, 0), out.coef_v.assign(ny / 4, 0);
     out.rec_y.assign(ny, 0), out.rec_u.assign(ny / 4, 0), out.rec_v.assign(ny / 4, 0);
@@ -947,7 +1019,8 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     S.w = w_, S.h = h_, S.cols = cols_, S.nrows = rows_, S.qp = qp;
     S.done.assign(rows_, 0);
     S.saved.resize(rows_);
-    init_contexts(1, qp, S.start.m);
+    S.intra = intra, S.strong = strong;
+    init_contexts(intra ? 2 : 1, qp, S.start.m);
     S.rows = std::deque<Row>(rows_);
     S.spin_us = spin_us;
     S.speculate = speculate;
@@ -966,6 +1039,8 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
         Lane &ln = S.lanes[lane];
         std::vector<CuEval *> cu;
         std::vector<ChromaEval *> chroma;
+        std::vector<IntraEval *> pu;
+        std::vector<IntraChromaEval *> ichroma;
         std::vector<Row *> served;
         // nothing of the lane is busy on the host, and there is something to do about it
         auto ready = [&] {
@@ -979,7 +1054,7 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
             }
             if (ln.finished.load() == ln.rows) break;
             // the rows this call serves: a row that another lane's progress wakes during the call asks for the next one
-            cu.clear(), chroma.clear(), served.clear();
+            cu.clear(), chroma.clear(), pu.clear(), ichroma.clear(), served.clear();
             for (Row &r : S.rows) {
                 if (r.y % nl != lane || r.in_flight || !r.pending.load(std::memory_order_acquire)) continue;
                 r.in_flight = true;
@@ -988,10 +1063,14 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
                 for (int i = 0; i < r.n_req_cu; i++) cu.push_back(r.req_cu[i]);
                 if (r.req_chroma)
                     for (ChromaEval &c : r.chroma_req) chroma.push_back(&c);
+                for (int i = 0; i < r.n_req_in; i++) pu.push_back(r.req_in[i]);
+                if (r.req_ichroma) ichroma.push_back(&r.ichroma);
             }
             if (served.empty() && !S.error) continue;      // a row is between counting itself out and raising its flag
             int rc = 0;
             if (!S.error && (!cu.empty() || !chroma.empty())) rc = ev.evaluate(lane, cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
+            if (!S.error && !rc && (!pu.empty() || !ichroma.empty()))
+                rc = ev.evaluate_intra(lane, pu.data(), (int)pu.size(), ichroma.data(), (int)ichroma.size());
             if (rc && !S.error) S.error = rc;
             for (Row *r : served) {
                 ln.running.fetch_add(1, std::memory_order_acq_rel);
@@ -1000,7 +1079,7 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
             }
             {
                 std::lock_guard<std::mutex> lk(S.m);      // also orders the stores above before the wake-up of a sleeping row
-                out.evaluator_calls++, out.cu_requests += cu.size(), out.chroma_requests += chroma.size();
+                out.evaluator_calls++, out.cu_requests += cu.size() + pu.size(), out.chroma_requests += chroma.size() + ichroma.size();
                 if (S.error) {       // an error ends the picture: rows waiting for a neighbour leave as well
                     for (Row &r : S.rows)
                         if (r.need >= 0) r.need = -1, S.lanes[r.y % nl].running.fetch_add(1);
@@ -1018,5 +1097,13 @@ int Analyser::p_picture(int qp, Evaluator &ev, PictureResult &out)
     return S.error.load();
 }
 
+const uint16_t *scan_table(int scan_idx, int log2_size) { return tables().scan[scan_idx][log2_size - 2]; }
+const uint8_t *group_table(int scan_idx, int log2_size) { return tables().group[scan_idx][log2_size - 2]; }
+
 }  // namespace analysis
+
+namespace syntax {
+const uint16_t *coef_scan(int scan_idx, int log2_size) { return analysis::scan_table(scan_idx, log2_size); }
+const uint8_t *group_scan(int scan_idx, int log2_size) { return analysis::group_table(scan_idx, log2_size); }
+}  // namespace syntax
 }  // namespace xmi

@@ -58,9 +58,58 @@ struct ChromaEval {
     uint32_t sum_u[4], sum_v[4];
 };
 
+// One square intra PU of an I picture, everything xEncDecideCU_Intra asks of the pixel primitives for it
+// (src/encode.cpp:4005-4115): padding and smoothing of the neighbouring samples (xPaddingRef :3843, xFilterRef :3873), the
+// 35-mode SATD search (cost = SATD + {1,2,3} sqrt(lambda) by most-probable-mode rank, first smallest), the prediction of
+// the winner, its transform chain (DST for 4x4, I-slice rounding) and the SSD of the reconstruction. The neighbouring
+// samples are what the reference gathers (:4010-4015: left column from the bottom up, top-left, top row and top-right,
+// 4 size + 1 bytes) with the availability bits of :3965-3974; samples of unavailable segments are arbitrary.
+struct IntraEval {
+    int x0, y0, size;                 // luma position in the picture, 4..32
+    uint8_t valids;                   // bit 0 below-left, 1 left, 2 top-left, 3 top, 4 top-right
+    uint8_t strong;                   // bStrongIntraSmoothing
+    uint8_t mpm[3];
+    uint8_t ref[132];
+    double sqrt_lambda;
+    int qp;
+    // results; the blocks are size x size, rows `size` apart, valid until the next call of the lane
+    int best_mode;
+    uint32_t ssd, sum;
+    const uint8_t *rec;
+    const int16_t *level;
+};
+
+// Chroma of one intra PU (xEncodeChromaCU, src/encode.cpp:4306-4411): padding of the U and V neighbours, the five-candidate
+// SATD search (planar, vertical, horizontal, DC, the luma mode; a duplicate of the luma mode becomes mode 34), prediction of
+// the winner, both transform chains at the chroma QP.
+struct IntraChromaEval {
+    int x0, y0, size;                 // position and size in the chroma planes, 4..16
+    uint8_t valids, luma_mode;
+    uint8_t ref_u[68], ref_v[68];
+    int qpc;
+    int best_idx;                     // nBestModeC, index into the candidate list
+    uint32_t sum_u, sum_v;
+    const uint8_t *rec_u, *rec_v;
+    const int16_t *level_u, *level_v;
+};
+
 class Evaluator {
 public:
     virtual ~Evaluator() {}
+    // Binds the evaluator to the pictures of the next call of Analyser::p_picture / i_picture, for owners that do not bind it
+    // by other means: packed source planes (width x height, width/2 x height/2) and, for a P picture, the first byte of
+    // each padded plane of the previous reconstruction (`pad` luma samples of border, pad/2 chroma; null for an I picture).
+    virtual int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int qp)
+    {
+        (void)src, (void)ref, (void)pad, (void)qp;
+        return -1;
+    }
+    // the requests of an I picture; same calling rules as evaluate()
+    virtual int evaluate_intra(int lane, IntraEval *const *pu, int npu, IntraChromaEval *const *chroma, int nchroma)
+    {
+        (void)lane, (void)pu, (void)npu, (void)chroma, (void)nchroma;
+        return -1;
+    }
     // Fills the result fields of every request; returns 0, or an error code that ends the picture. Calls with different
     // `lane` values (0 .. Analyser::lanes - 1) come from different threads and may overlap; calls of one lane never do,
     // and the blocks a call hands out stay valid until the next call of the same lane.
@@ -74,6 +123,7 @@ public:
 struct PictureResult {
     std::vector<uint16_t> info0;
     std::vector<uint8_t> info1;
+    std::vector<uint8_t> mode;        // aucModeY per 4x4 block: the intra luma mode in I pictures, 0 (MODE_VALID) in P pictures
     std::vector<Mv> mv, mvd;
     std::vector<uint8_t> mvp_idx;
     std::vector<int16_t> coef_y, coef_u, coef_v;
@@ -114,14 +164,20 @@ public:
     // left neighbour and the CTU above and to the right are done). The evaluator is bound to the picture pair (source,
     // padded previous reconstruction) by its owner before the call. Returns 0 or the evaluator's error.
     int p_picture(int qp, Evaluator &ev, PictureResult &out);
+    // One I picture (xEncodeCUs with xEncDecideCU_Intra, src/encode.cpp:3906-4215, and xEncodeChromaCU, :4234-4418): same
+    // wavefront, same outputs; info0 / info1 in the I-slice layout (prediction index, chroma mode and cbf; availability bits,
+    // luma cbf, size), mv / mvd / mvp_idx zero, rd_cost the depth-0 cost truncated to 32 bits.
+    int i_picture(int qp, int strong_intra_smoothing, Evaluator &ev, PictureResult &out);
 
 private:
+    int picture(int qp, bool intra, int strong, Evaluator &ev, PictureResult &out);
     int w_, h_, rows_, cols_;
 };
 
 // the tables the rate estimate walks; exposed for the tests that pin them against the reference's
 const uint16_t *diag_scan(int log2_size);               // coefficient scan of a 4..32 block, positions y * size + x
 const uint8_t *next_state_table();                       // [state][bin] -> state, 128 x 2
+const int32_t *entropy_bits_table();                     // [state ^ bin] -> cost of the bin in 1/32768 bit (g_entropyBits, src/encode.cpp:131)
 void init_contexts(int slice_type, int qp, uint8_t ctx[256]);   // xCabacInit (src/bitstream.cpp:588), slice 1 = P, 2 = I
 int chroma_qp(int qp);                                   // xg_aucChromaScale (src/table.cpp:160)
 
