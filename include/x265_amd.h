@@ -417,6 +417,35 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
                            int16_t *mvd, uint8_t *mvp_idx, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint8_t *rec_y, uint8_t *rec_u,
                            uint8_t *rec_v, uint32_t *rd_cost, uint8_t *ctx_in, uint8_t *ctx_out, uint64_t *counters);
 
+/* ---- the encoder ------------------------------------------------------------------------------------------
+ * xEncodeFrame (src/encode.cpp:5752-6118) behind the reference's own outer interface, xIEncFrame(X265_t *, xFrame *, out, size)
+ * -> bytes (src/interface.cpp:62): one picture in, its access unit out - VPS / SPS / PPS in front of an I picture, the slice
+ * (one CABAC substream per CTU row with entry points, as the reference writes them), the picture-hash SEI of the final
+ * reconstruction. A picture runs the analysis loop above (for I pictures xEncDecideCU_Intra :3906 and xEncodeChromaCU :4234:
+ * per PU the 35-mode search, prediction, transform chain and distortion as one GPU request), deblocking (boundary strengths
+ * from the decision maps, xDeblockFrame), the SAO statistics, decision (rdoSaoUnitAll :1348, host) and offsets, and the
+ * entropy coder (xEncWriteCU :4547, xCompressCU :5594; host). Constant QP, one reference picture, no rate control - the
+ * configuration of every published figure of the reference. The stream equals the reference's byte for byte when the
+ * caller feeds the pictures its command line would (src/x265.cpp:227-252: picture 0 and every (-ip)th picture as I slices;
+ * sizes that are no multiple of 64 padded by xFrameAligning, src/preProcess.cpp:33).
+ *
+ * xmi_encoder_create   : width, height = coded size (multiples of 64), qp 0..51, strong_intra_smoothing = the -sis switch.
+ * xmi_encoder_configure: lanes / spin_us of the analysis loop (xmi_analysis_configure).
+ * xmi_encoder_encode   : src_* packed source planes at coded size; slice_type XMI_SLICE_I or XMI_SLICE_P (a P picture needs a
+ *                        picture before it); out must hold 3 * width * height + 4096 bytes. Returns the size of the access
+ *                        unit or XMI_ERR_*.
+ * xmi_encoder_reconstruction: the last picture's reconstruction after the in-loop filters, packed planes.
+ * xmi_encoder_timing   : of the last picture, out = { ns analysis, ns deblocking, ns SAO, ns writing, GPU round trips,
+ *                        CU / PU requests } (no counterpart in the reference). */
+typedef struct xmi_encoder xmi_encoder;
+xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_smoothing);
+void xmi_encoder_destroy(xmi_encoder *e);
+int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us);
+int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
+                           size_t capacity);
+int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);
+int xmi_encoder_timing(xmi_encoder *e, uint64_t out[6]);
+
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.
  *   XMI_METRIC_SAD       xSadN[log2(n)-2]                        src/pixel.cpp:546-717

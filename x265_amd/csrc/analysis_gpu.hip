@@ -23,6 +23,8 @@
 #include <vector>
 
 #include "host/analysis_core.h"
+#include "host/encoder_core.h"
+#include "intra_device.h"
 #include "me_search_device.h"
 #include "tu_valu_device.h"
 
@@ -112,11 +114,15 @@ __device__ unsigned long long g_chain_ticks[4][6];      // per unit size 4/8/16/
 #define XMI_CSTAMP(var)
 #endif
 
-// xSubDctQuantRec (src/encode.cpp:3005-3021) of one N x N unit by the whole workgroup, P-slice rounding, DCT:
+// xSubDctQuantRec (src/encode.cpp:3005-3021) of one N x N unit by the whole workgroup; P-slice rounding and DCT unless the
+// template arguments say I slice / DST:
 // source and prediction come with their own strides (any address space); levels, reconstruction and, when asked for, the
 // prediction go out with the stride of the CU's result blocks. Returns sum |level| and the SSD of the reconstruction
 // against the source in every thread.
-template <int N>
+// DST-VII matrix of 4x4 intra luma blocks (xSubDST4, src/pixel.cpp:1567)
+__constant__ int8_t k_dst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+
+template <int N, bool INTRA = false, bool DST = false>
 __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
                            uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd)
 {
@@ -138,7 +144,7 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
         *reinterpret_cast<uint32_t *>(&L.pred[e]) = q4;
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            const int16_t c = (int16_t)dct_coef(N, k, j + t);
+            const int16_t c = (int16_t)(DST ? (int)k_dst4[k & 3][(j + t) & 3] : dct_coef(N, k, j + t));
             M[k * LD + j + t] = c;
             Mt[(j + t) * LD + k] = c;
             L.a[k * LD + j + t] = (int16_t)((int)((s4 >> (8 * t)) & 255) - (int)((q4 >> (8 * t)) & 255));
@@ -151,7 +157,7 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
     if (live) stage<N, false>(M, L.b, L.a, LG + 6, tid);
     __syncthreads();
     XMI_CSTAMP(c2);
-    const int qbits = 14 + qp / 6 + (15 - 8 - LG), q = k_quant_scales[qp % 6], qrnd = 85 << (qbits - 9);
+    const int qbits = 14 + qp / 6 + (15 - 8 - LG), q = k_quant_scales[qp % 6], qrnd = (INTRA ? 171 : 85) << (qbits - 9);      // xQuant (src/pixel.cpp:1060)
     const int dshift = 20 - 14 - (15 - 8 - LG), dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
     uint32_t local = 0;
     for (int e = tid * 4; e < N * N; e += 1024) {
@@ -358,6 +364,21 @@ __device__ void chroma_job(const RoundParams &p, RoundLds &L, const ChromaJob &j
     if (tid == 0) *reinterpret_cast<uint32_t *>(p.out + j.out_sum) = sum;
 }
 
+// completion of a round: every wavefront waits until its own results have left for host memory, then the workgroup counts
+// itself; the last one of the round tells the host
+__device__ __forceinline__ void round_done(unsigned *counter, unsigned target, unsigned *flag, unsigned seq)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(counter, 1u) + 1u;
+        if (done == target) {
+            __threadfence_system();
+            __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p)
 {
     __shared__ RoundLds L;
@@ -382,17 +403,158 @@ __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p
         default: break;
         }
     }
-    // completion: every wavefront waits until its own results have left for host memory, then the workgroup counts itself;
-    // the last one of the round tells the host
-    __threadfence_system();
+    round_done(p.counter, p.target, p.flag, p.seq);
+}
+
+// ---- I pictures: one workgroup per PU request ----
+struct IntraJob {
+    int32_t x0, y0, size;
+    uint8_t valids, strong, mpm[3], reserved[3];
+    int32_t qp;
+    double sqrt_lambda;
+    uint8_t ref[136];
+    uint32_t out_head, out_rec, out_level;
+};
+struct IntraHead {
+    int32_t best_mode;
+    uint32_t sum, ssd;
+};
+struct IntraChromaJob {
+    int32_t x0, y0, size;             // in chroma samples
+    uint8_t valids, luma_mode, reserved[2];
+    int32_t qpc;
+    uint8_t ref[2][136];
+    uint32_t out_head, out_rec[2], out_level[2];
+};
+struct IntraChromaHead {
+    int32_t best_idx;
+    uint32_t sum[2];
+};
+struct IntraRoundParams {
+    const IntraJob *jobs;
+    const IntraChromaJob *cjobs;
+    int npu, nchroma;
+    const uint8_t *src[3];
+    int width;
+    uint8_t *out;
+    unsigned *counter;
+    unsigned target;
+    unsigned *flag;
+    unsigned seq;
+};
+struct __align__(16) IntraLds {
+    RoundLds r;                       // transform operands; r.win holds the source copies of the search and the prediction
+    uint8_t ref[4][272];              // per wavefront: padded samples, then the smoothed set at +136
+    double best_cost[4];
+    int best_mode[4];
+    int best;
+    uint32_t satd[10];
+    xmi_chroma_result cres;
+};
+
+// one luma PU (src/encode.cpp:4005-4115): 35-mode search on the four wavefronts, prediction of the winner, transform chain
+template <int N>
+__device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob &j)
+{
+    constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    xmi_intra_request rq;
+    rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N, rq.valids = j.valids, rq.strong_smoothing = j.strong;
+    rq.mpm[0] = j.mpm[0], rq.mpm[1] = j.mpm[1], rq.mpm[2] = j.mpm[2];
+    rq.sqrt_lambda = j.sqrt_lambda;
+    const IntraParams ip = { p.src[0], j.ref, nullptr, nullptr, p.width, 1 };
+    search<N, 4>(ip, rq, 0, L.ref[wave], L.r.win + wave * 1024, lane, wave, L.best_cost, L.best_mode, &L.best);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(p.counter, 1u) + 1u;
-        if (done == p.target) {
-            __threadfence_system();
-            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int mode = L.best;
+    const uint8_t *ref = ((k_filter_bits[LG - 2] >> mode) & 1) ? L.ref[0] + 136 : L.ref[0];
+    int dc;
+    {
+        int s = 0;
+        for (int i = lane; i < 2 * N; i += 64) s += i < N ? L.ref[0][2 * N - 1 - i] : L.ref[0][2 * N + 1 + (i - N)];
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) s += __shfl_xor(s, k);
+        dc = (s + N) >> (LG + 1);
+    }
+    uint8_t *pr = L.r.win + 4096;
+    for (int e = tid; e < N * N; e += 256) pr[e] = (uint8_t)pred_sample<N>(ref, mode, e / N, e % N, dc, N != 32);
+    __syncthreads();
+    uint32_t sum, ssd;
+    chain_unit<N, true, N == 4>(L.r, p.src[0] + (size_t)j.y0 * p.width + j.x0, p.width, pr, N, j.qp, reinterpret_cast<int16_t *>(p.out + j.out_level),
+                                p.out + j.out_rec, nullptr, N, sum, ssd);
+    if (tid == 0) {
+        IntraHead *h = reinterpret_cast<IntraHead *>(p.out + j.out_head);
+        h->best_mode = mode, h->sum = sum, h->ssd = ssd;
+    }
+}
+
+// chroma of one PU (src/encode.cpp:4306-4411): candidate search on one wavefront, then prediction and chain of U and V
+template <int N>
+__device__ void intra_chroma_pu(const IntraRoundParams &p, IntraLds &L, const IntraChromaJob &j)
+{
+    constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wc = p.width / 2;
+    uint8_t (*s_ref)[136] = reinterpret_cast<uint8_t (*)[136]>(&L.ref[0][0]);
+    uint8_t (*s_src)[256] = reinterpret_cast<uint8_t (*)[256]>(L.r.win);
+    if (wave == 0) {
+        for (int i = lane; i < 2 * (4 * N + 1); i += 64) {
+            const int pl = i >= 4 * N + 1, k = i - pl * (4 * N + 1);
+            s_ref[pl][k] = j.valids ? j.ref[pl][k] : (uint8_t)0x80;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (j.valids) {
+            pad_ref<N>(s_ref[0], j.valids, lane);
+            pad_ref<N>(s_ref[1], j.valids, lane);
+        }
+        for (int e = lane; e < 2 * N * N / 4; e += 64) {
+            const int pl = e >= N * N / 4, k = e - pl * (N * N / 4), y = k / (N / 4), x4 = k % (N / 4);
+            reinterpret_cast<uint32_t *>(s_src[pl])[k] = *reinterpret_cast<const uint32_t *>(p.src[1 + pl] + (size_t)(j.y0 + y) * wc + j.x0 + 4 * x4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        chroma_candidates<N>(j.luma_mode, s_ref, s_src, L.satd, lane, L.cres);
+    }
+    __syncthreads();
+    const int mode = L.cres.best_mode;
+    IntraChromaHead *h = reinterpret_cast<IntraChromaHead *>(p.out + j.out_head);
+    uint8_t *pr = L.r.win + 4096;
+    for (int pl = 0; pl < 2; pl++) {
+        int s = 0;
+        for (int i = lane; i < 2 * N; i += 64) s += i < N ? s_ref[pl][2 * N - 1 - i] : s_ref[pl][2 * N + 1 + (i - N)];
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) s += __shfl_xor(s, k);
+        const int dc = (s + N) >> (LG + 1);
+        for (int e = tid; e < N * N; e += 256) pr[e] = (uint8_t)pred_sample<N>(s_ref[pl], mode, e / N, e % N, dc, false);
+        __syncthreads();
+        uint32_t sum, ssd;
+        chain_unit<N, true, false>(L.r, p.src[1 + pl] + (size_t)j.y0 * wc + j.x0, wc, pr, N, j.qpc, reinterpret_cast<int16_t *>(p.out + j.out_level[pl]),
+                                   p.out + j.out_rec[pl], nullptr, N, sum, ssd);
+        if (tid == 0) h->sum[pl] = sum;
+    }
+    if (tid == 0) h->best_idx = L.cres.best_idx;
+}
+
+__global__ void __launch_bounds__(256) intra_round_kernel(const IntraRoundParams p)
+{
+    __shared__ IntraLds L;
+    const int b = blockIdx.x;
+    if (b < p.npu) {
+        const IntraJob &j = p.jobs[b];
+        switch (j.size) {
+        case 4: intra_pu<4>(p, L, j); break;
+        case 8: intra_pu<8>(p, L, j); break;
+        case 16: intra_pu<16>(p, L, j); break;
+        case 32: intra_pu<32>(p, L, j); break;
+        default: break;
+        }
+    } else if (b - p.npu < p.nchroma) {
+        const IntraChromaJob &j = p.cjobs[b - p.npu];
+        switch (j.size) {
+        case 4: intra_chroma_pu<4>(p, L, j); break;
+        case 8: intra_chroma_pu<8>(p, L, j); break;
+        case 16: intra_chroma_pu<16>(p, L, j); break;
+        default: break;
         }
     }
+    round_done(p.counter, p.target, p.flag, p.seq);
 }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -478,9 +640,9 @@ public:
         const int lane_rows = (h / 64 + lanes - 1) / lanes;
         max_cu = 4 * lane_rows;               // per CTU row and round a CU and its chain of first children (64, 32, 16, 8)
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
-        off_groups = align_up(sizeof(LumaJob) * max_cu);
+        off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);
         off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
-        jobs_bytes = off_cjobs + align_up(sizeof(ChromaJob) * max_chroma);
+        jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, sizeof(IntraChromaJob) * (size_t)lane_rows));
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
         out_bytes = (size_t)lane_rows * 2 * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
@@ -505,20 +667,45 @@ public:
         return XMI_OK;
     }
 
-    // source planes (w x h, w/2 x h/2) and padded reference planes from host memory; builds the quarter-pel planes
-    int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int qp, int qpc)
+    // source planes (w x h, w/2 x h/2) and, for a P picture, padded reference planes from host memory, of which the
+    // quarter-pel planes are built
+    int bind(const uint8_t *const src[3], const uint8_t *const ref[3], int qp, int qpc)
     {
         XMI_HIP(hipMemcpyAsync(d_src[0], src[0], (size_t)w * h, hipMemcpyHostToDevice, st));
         XMI_HIP(hipMemcpyAsync(d_src[1], src[1], (size_t)w * h / 4, hipMemcpyHostToDevice, st));
         XMI_HIP(hipMemcpyAsync(d_src[2], src[2], (size_t)w * h / 4, hipMemcpyHostToDevice, st));
-        XMI_HIP(hipMemcpyAsync(d_ref[0], ref[0], (size_t)stride * rows, hipMemcpyHostToDevice, st));
-        XMI_HIP(hipMemcpyAsync(d_ref[1], ref[1], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
-        XMI_HIP(hipMemcpyAsync(d_ref[2], ref[2], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
-        int rc = xmi_interp_planes_dev(d_ref[0], stride, rows, stride, d_planes, st);
-        if (rc != XMI_OK) return rc;
+        if (ref[0]) {
+            XMI_HIP(hipMemcpyAsync(d_ref[0], ref[0], (size_t)stride * rows, hipMemcpyHostToDevice, st));
+            XMI_HIP(hipMemcpyAsync(d_ref[1], ref[1], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
+            XMI_HIP(hipMemcpyAsync(d_ref[2], ref[2], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
+            int rc = xmi_interp_planes_dev(d_ref[0], stride, rows, stride, d_planes, st);
+            if (rc != XMI_OK) return rc;
+        }
         cur_qp = qp, cur_qpc = qpc;
         XMI_HIP(hipStreamSynchronize(st));
         return XMI_OK;
+    }
+
+    int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int qp) override
+    {
+        XMI_ARG(pad == kPad, "analysis: the reference must be padded by %d luma samples (got %d)", kPad, pad);
+        return bind(src, ref, qp, chroma_qp(qp));
+    }
+
+    int evaluate_intra(int ln, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch) override
+    {
+        if (ln < 0 || ln >= lanes) return XMI_ERR_ARG;
+        thread_local int bound = -1;
+        if (bound != device) {
+            if (hipSetDevice(device) != hipSuccess) {
+                snprintf(lane[ln].err, sizeof lane[ln].err, "hipSetDevice(%d) failed on a lane thread", device);
+                return XMI_ERR_HIP;
+            }
+            bound = device;
+        }
+        const int rc = run_intra(lane[ln], pu, npu, ch, nch);
+        if (rc != XMI_OK) snprintf(lane[ln].err, sizeof lane[ln].err, "%s", xmi_last_error());
+        return rc;
     }
 
     int evaluate(int ln, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch) override
@@ -546,6 +733,109 @@ public:
     }
 
 private:
+    // launch and wait: the host spins on the completion word and looks at the stream now and then, so that a failed launch
+    // cannot hang it
+    int wait_round(LaneRes &R, unsigned seq)
+    {
+        volatile unsigned *flag = R.h_flag;
+        for (unsigned spins = 0; *flag != seq; spins++) {
+            if ((spins & 0xfffff) == 0xfffff) {
+                const hipError_t q = hipStreamQuery(R.st);
+                if (q == hipSuccess) {
+                    if (*flag == seq) break;
+                    xmi::set_error("analysis: the round kernel finished without reporting completion");
+                    return XMI_ERR_HIP;
+                }
+                if (q != hipErrorNotReady) {
+                    xmi::set_error("analysis: round kernel failed: %s", hipGetErrorString(q));
+                    return XMI_ERR_HIP;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return XMI_OK;
+    }
+
+    int run_intra(LaneRes &R, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch)
+    {
+        XMI_ARG(npu <= max_cu && nch * 128 <= max_chroma, "analysis: %d + %d intra requests exceed the round capacity", npu, nch);
+        const auto t0 = std::chrono::steady_clock::now();
+        IntraJob *jobs = reinterpret_cast<IntraJob *>(R.h_jobs);
+        IntraChromaJob *cjobs = reinterpret_cast<IntraChromaJob *>(R.h_jobs + off_cjobs);
+        size_t out = 0;
+        for (int i = 0; i < npu; i++) {
+            const IntraEval &q = *pu[i];
+            IntraJob &j = jobs[i];
+            XMI_ARG(q.size == 4 || q.size == 8 || q.size == 16 || q.size == 32, "analysis: intra PU size %d", q.size);
+            XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 4 == 0 && q.y0 % 4 == 0 && q.x0 + q.size <= w && q.y0 + q.size <= h, "analysis: intra PU (%d,%d) size %d outside the picture",
+                    q.x0, q.y0, q.size);
+            XMI_ARG(q.qp >= 0 && q.qp <= 51 && q.mpm[0] < 35 && q.mpm[1] < 35 && q.mpm[2] < 35, "analysis: intra PU parameters out of range");
+            j.x0 = q.x0, j.y0 = q.y0, j.size = q.size;
+            j.valids = q.valids & 0x1f, j.strong = q.strong;
+            j.mpm[0] = q.mpm[0], j.mpm[1] = q.mpm[1], j.mpm[2] = q.mpm[2];
+            j.qp = q.qp, j.sqrt_lambda = q.sqrt_lambda;
+            std::memcpy(j.ref, q.ref, (size_t)(4 * q.size + 1));
+            const size_t px = (size_t)q.size * q.size;
+            j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraHead));
+            j.out_rec = (uint32_t)out, out = align_up(out + px);
+            j.out_level = (uint32_t)out, out = align_up(out + 2 * px);
+        }
+        for (int i = 0; i < nch; i++) {
+            const IntraChromaEval &c = *ch[i];
+            IntraChromaJob &j = cjobs[i];
+            XMI_ARG(c.size == 4 || c.size == 8 || c.size == 16, "analysis: intra chroma size %d", c.size);
+            XMI_ARG(c.x0 >= 0 && c.y0 >= 0 && c.x0 % 4 == 0 && c.x0 + c.size <= w / 2 && c.y0 + c.size <= h / 2 && c.luma_mode < 35 && c.qpc >= 0 && c.qpc <= 51,
+                    "analysis: intra chroma block (%d,%d) size %d outside the picture, or bad parameters", c.x0, c.y0, c.size);
+            j.x0 = c.x0, j.y0 = c.y0, j.size = c.size;
+            j.valids = c.valids & 0x1f, j.luma_mode = c.luma_mode;
+            j.qpc = c.qpc;
+            std::memcpy(j.ref[0], c.ref_u, (size_t)(4 * c.size + 1)), std::memcpy(j.ref[1], c.ref_v, (size_t)(4 * c.size + 1));
+            const size_t px = (size_t)c.size * c.size;
+            j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraChromaHead));
+            for (int k = 0; k < 2; k++) j.out_rec[k] = (uint32_t)out, out = align_up(out + px);
+            for (int k = 0; k < 2; k++) j.out_level[k] = (uint32_t)out, out = align_up(out + 2 * px);
+        }
+        XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
+        IntraRoundParams p;
+        p.jobs = reinterpret_cast<const IntraJob *>(R.g_jobs);
+        p.cjobs = reinterpret_cast<const IntraChromaJob *>(R.g_jobs + off_cjobs);
+        p.npu = npu, p.nchroma = nch;
+        for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
+        p.width = w;
+        p.out = R.g_out;
+        const unsigned ngroups = (unsigned)(npu + nch);
+        R.issued += ngroups;
+        R.seq++;
+        p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = R.seq;
+        std::atomic_thread_fence(std::memory_order_release);
+        const auto t1 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(intra_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
+        XMI_HIP(hipGetLastError());
+        const auto t2 = std::chrono::steady_clock::now();
+        const int rc = wait_round(R, R.seq);
+        if (rc != XMI_OK) return rc;
+        const auto t3 = std::chrono::steady_clock::now();
+        for (int i = 0; i < npu; i++) {
+            IntraEval &q = *pu[i];
+            const IntraJob &j = jobs[i];
+            const IntraHead &hd = *reinterpret_cast<const IntraHead *>(R.h_out + j.out_head);
+            q.best_mode = hd.best_mode, q.sum = hd.sum, q.ssd = hd.ssd;
+            q.rec = R.h_out + j.out_rec, q.level = reinterpret_cast<const int16_t *>(R.h_out + j.out_level);
+        }
+        for (int i = 0; i < nch; i++) {
+            IntraChromaEval &c = *ch[i];
+            const IntraChromaJob &j = cjobs[i];
+            const IntraChromaHead &hd = *reinterpret_cast<const IntraChromaHead *>(R.h_out + j.out_head);
+            c.best_idx = hd.best_idx, c.sum_u = hd.sum[0], c.sum_v = hd.sum[1];
+            c.rec_u = R.h_out + j.out_rec[0], c.rec_v = R.h_out + j.out_rec[1];
+            c.level_u = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[0]), c.level_v = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[1]);
+        }
+        const auto t4 = std::chrono::steady_clock::now();
+        auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+        R.t_prepare += ns(t0, t1), R.t_launch += ns(t1, t2), R.t_wait += ns(t2, t3), R.t_collect += ns(t3, t4), R.rounds++;
+        return XMI_OK;
+    }
+
     int run(LaneRes &R, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
     {
         XMI_ARG(ncu <= max_cu, "analysis: %d CU requests exceed the round capacity %d", ncu, max_cu);
@@ -639,23 +929,8 @@ private:
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
         XMI_HIP(hipGetLastError());
         const auto t2 = std::chrono::steady_clock::now();
-        // spin on the completion word; look at the stream now and then so that a failed launch cannot hang the host
-        volatile unsigned *flag = R.h_flag;
-        for (unsigned spins = 0; *flag != seq; spins++) {
-            if ((spins & 0xfffff) == 0xfffff) {
-                const hipError_t q = hipStreamQuery(R.st);
-                if (q == hipSuccess) {
-                    if (*flag == seq) break;
-                    xmi::set_error("analysis: the round kernel finished without reporting completion");
-                    return XMI_ERR_HIP;
-                }
-                if (q != hipErrorNotReady) {
-                    xmi::set_error("analysis: round kernel failed: %s", hipGetErrorString(q));
-                    return XMI_ERR_HIP;
-                }
-            }
-        }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        const int wrc = wait_round(R, seq);
+        if (wrc != XMI_OK) return wrc;
         const auto t3 = std::chrono::steady_clock::now();
 
         for (int i = 0; i < ncu; i++) {
@@ -779,7 +1054,7 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
     XMI_ARG(pad == kPad, "xmi_analysis_p_picture: the reference must be padded by %d luma samples (got %d)", kPad, pad);
     XMI_ARG(qp >= 0 && qp <= 51, "xmi_analysis_p_picture: qp %d", qp);
     const uint8_t *src[3] = { src_y, src_u, src_v }, *ref[3] = { ref_y, ref_u, ref_v };
-    rc = a->ev.bind_pictures(src, ref, qp, chroma_qp(qp));
+    rc = a->ev.bind(src, ref, qp, chroma_qp(qp));
     if (rc != XMI_OK) return rc;
     rc = a->an.p_picture(qp, a->ev, a->res);
     if (rc != 0) {
@@ -795,6 +1070,118 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
     put(coef_y, r.coef_y), put(coef_u, r.coef_u), put(coef_v, r.coef_v), put(rec_y, r.rec_y), put(rec_u, r.rec_u), put(rec_v, r.rec_v);
     put(rd_cost, r.rd_cost), put(ctx_in, r.ctx_in), put(ctx_out, r.ctx_out);
     if (counters) counters[0] = r.evaluator_calls, counters[1] = r.cu_requests, counters[2] = r.chroma_requests;
+    return XMI_OK;
+}
+
+}  // extern "C"
+
+// ---- the whole encoder ----------------------------------------------------------------------------------------------------
+namespace {
+
+// the picture-level passes of host/encoder_core.h on the library's kernels (host-pointer entry points)
+class GpuFrameOps : public xmi::encoder::FrameOps {
+public:
+    std::vector<uint8_t> vbs, hbs, qp_tab;
+
+    int deblock(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv, uint8_t *y, uint8_t *u,
+                uint8_t *v) override
+    {
+        const size_t n = (size_t)(width / 8) * (height / 4);
+        vbs.resize(n), hbs.resize(n);
+        qp_tab.assign((size_t)(width / 4) * (height / 4), (uint8_t)qp);
+        int rc = xmi_deblock_strengths(width, height, intra_slice, unit_log2, cbf, mv, vbs.data(), hbs.data());
+        if (rc != XMI_OK) return rc;
+        const xmi_deblock_params dp = { width, height, width, width / 2, 0, 0, 0, 0 };
+        return xmi_deblock_frame(y, u, v, &dp, vbs.data(), hbs.data(), qp_tab.data());
+    }
+    int sao_stats(int width, int height, const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
+    {
+        static_assert(sizeof(xmi::encoder::SaoStats) == sizeof(xmi_sao_stats), "same layout");
+        const xmi_sao_geom g = { width, height, width, width / 2, width, width / 2 };
+        return xmi_sao_stats_frame(&g, rec[0], rec[1], rec[2], org[0], org[1], org[2], reinterpret_cast<xmi_sao_stats *>(stats));
+    }
+    int sao_apply(uint8_t *plane, int width, int height, int ctu_size, const xmi::encoder::SaoCtuParam *params) override
+    {
+        static_assert(sizeof(xmi::encoder::SaoCtuParam) == sizeof(xmi_sao_ctu_param), "same layout");
+        return xmi_sao_apply_plane(plane, width, width, height, ctu_size, reinterpret_cast<const xmi_sao_ctu_param *>(params));
+    }
+};
+
+}  // namespace
+
+struct xmi_encoder {
+    xmi::encoder::Encoder enc;
+    GpuEvaluator ev;
+    GpuFrameOps ops;
+    xmi_encoder(int w, int h, int qp, int strong) : enc(w, h, qp, strong) {}
+};
+
+extern "C" {
+
+xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_smoothing)
+{
+    if (xmi::require_device() != XMI_OK) return nullptr;
+    if (width <= 0 || height <= 0 || width % 64 || height % 64 || width > 8192 || height > 4352 || qp < 0 || qp > 51) {
+        xmi::set_error("xmi_encoder_create: %dx%d qp %d: the coded size must be a multiple of 64, at most 8192x4352, qp 0..51", width, height, qp);
+        return nullptr;
+    }
+    xmi_encoder *e = new (std::nothrow) xmi_encoder(width, height, qp, strong_intra_smoothing ? 1 : 0);
+    if (!e) {
+        xmi::set_error("xmi_encoder_create: out of host memory");
+        return nullptr;
+    }
+    if (e->ev.init(width, height, e->enc.analyser().lanes) != XMI_OK) {
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+void xmi_encoder_destroy(xmi_encoder *e) { delete e; }
+
+int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(e, "xmi_encoder_configure: null handle");
+    XMI_ARG(spin_us >= 0 && spin_us <= 1000000, "xmi_encoder_configure: spin_us %d", spin_us);
+    if (lanes != e->ev.lanes) {
+        rc = e->ev.set_lanes(lanes);
+        if (rc == XMI_OK) e->enc.analyser().lanes = lanes;
+    }
+    if (rc == XMI_OK) e->enc.analyser().spin_us = spin_us;
+    return rc;
+}
+
+int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out, size_t capacity)
+{
+    int rc = xmi::require_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(e && src_y && src_u && src_v && out, "xmi_encoder_encode: null argument");
+    XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_encode: slice type %d", slice_type);
+    const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ops, out, capacity);
+    if (n > 0) return n;
+    if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold 3 * width * height + 4096 bytes");
+    else if (n == -101) xmi::set_error("xmi_encoder_encode: a P picture needs a picture before it");
+    else if (e->ev.first_error()[0]) xmi::set_error("xmi_encoder_encode: %s", e->ev.first_error());
+    return n == -100 || n == -101 ? XMI_ERR_ARG : (n == XMI_ERR_ARG || n == XMI_ERR_NO_DEVICE ? n : XMI_ERR_HIP);
+}
+
+int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v)
+{
+    XMI_ARG(e && y && u && v, "xmi_encoder_reconstruction: null argument");
+    std::memcpy(y, e->enc.rec_y().data(), e->enc.rec_y().size());
+    std::memcpy(u, e->enc.rec_u().data(), e->enc.rec_u().size());
+    std::memcpy(v, e->enc.rec_v().data(), e->enc.rec_v().size());
+    return XMI_OK;
+}
+
+int xmi_encoder_timing(xmi_encoder *e, uint64_t out[6])
+{
+    XMI_ARG(e && out, "xmi_encoder_timing: null argument");
+    for (int k = 0; k < 4; k++) out[k] = e->enc.stage_ns[k];
+    out[4] = e->enc.analysis_result().evaluator_calls;
+    out[5] = e->enc.analysis_result().cu_requests + e->enc.analysis_result().chroma_requests;
     return XMI_OK;
 }
 

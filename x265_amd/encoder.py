@@ -1,0 +1,95 @@
+"""Python handle of the encoder in libx265_amd.so (xmi_encoder_*, include/x265_amd.h) and the picture preparation of the
+reference's command line, for the tests and the benchmark. Nothing is computed here."""
+import ctypes as C
+
+import numpy as np
+
+from .capi import SLICE_I, SLICE_P, XmiError, load
+
+
+def align_frame(y, u, v, width, height):
+    """What the reference's command line hands its encoder when the picture size is no multiple of 64 (xFrameAligning,
+    src/preProcess.cpp:33): columns are padded with the row's last sample; every added row is a copy of `width` bytes of
+    the input buffer from the start of the plane's last row on - the row itself and, past its end, whatever follows it
+    in the Y, U, V buffer (zeros after V). -> contiguous planes of width x height, width/2 x height/2."""
+    flat = np.concatenate([y.ravel(), u.ravel(), v.ravel(), np.zeros(width, np.uint8)])
+    out, start = [], 0
+    for p, s in ((y, 1), (u, 2), (v, 2)):
+        ph, pw, aw, ah = p.shape[0], p.shape[1], width // s, height // s
+        a = np.zeros((ah, aw), np.uint8)
+        a[:ph, :pw] = p
+        a[:ph, pw:] = p[:, -1:]
+        if ah > ph:
+            last = start + (ph - 1) * pw
+            a[ph:, :] = flat[last:last + aw]
+        out.append(np.ascontiguousarray(a))
+        start += ph * pw
+    return out
+
+
+class Encoder:
+    """one encoder instance; pictures are (y, u, v) uint8 arrays of the display size given to the constructor"""
+
+    def __init__(self, width, height, qp, strong_intra_smoothing=False, lanes=None, spin_us=0):
+        self.lib = load()
+        self.width, self.height = width, height
+        self.W, self.H = (width + 63) // 64 * 64, (height + 63) // 64 * 64
+        self.lib.xmi_encoder_create.restype = C.c_void_p
+        self.lib.xmi_encoder_create.argtypes = [C.c_int] * 4
+        self.lib.xmi_encoder_destroy.argtypes = [C.c_void_p]
+        self.lib.xmi_encoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.lib.xmi_encoder_encode.restype = C.c_int64
+        self.lib.xmi_encoder_encode.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t]
+        self.lib.xmi_encoder_reconstruction.argtypes = [C.c_void_p] * 4
+        self.lib.xmi_encoder_timing.argtypes = [C.c_void_p] * 2
+        self.lib.xmi_last_error.restype = C.c_char_p
+        self.handle = self.lib.xmi_encoder_create(self.W, self.H, qp, int(bool(strong_intra_smoothing)))
+        if not self.handle:
+            raise XmiError(self.lib.xmi_last_error().decode())
+        if lanes is not None or spin_us:
+            rc = self.lib.xmi_encoder_configure(self.handle, lanes or 1, spin_us)
+            if rc != 0:
+                raise XmiError(self.lib.xmi_last_error().decode())
+        self.out = np.zeros(self.W * self.H * 3 + 4096, np.uint8)
+
+    def close(self):
+        if self.handle:
+            self.lib.xmi_encoder_destroy(self.handle)
+            self.handle = None
+
+    def encode(self, y, u, v, intra):
+        """-> the access unit's bytes"""
+        if (self.W, self.H) != (self.width, self.height):
+            y, u, v = align_frame(y, u, v, self.W, self.H)
+        else:
+            y, u, v = (np.ascontiguousarray(p) for p in (y, u, v))
+        n = self.lib.xmi_encoder_encode(self.handle, y.ctypes.data, u.ctypes.data, v.ctypes.data, SLICE_I if intra else SLICE_P, self.out.ctypes.data, self.out.size)
+        if n <= 0:
+            raise XmiError(f"xmi_encoder_encode returned {n}: {self.lib.xmi_last_error().decode()}")
+        return bytes(self.out[:n])
+
+    def reconstruction(self):
+        y = np.zeros((self.H, self.W), np.uint8)
+        u, v = np.zeros((self.H // 2, self.W // 2), np.uint8), np.zeros((self.H // 2, self.W // 2), np.uint8)
+        self.lib.xmi_encoder_reconstruction(self.handle, y.ctypes.data, u.ctypes.data, v.ctypes.data)
+        return y, u, v
+
+    def timing(self):
+        t = (C.c_uint64 * 6)()
+        self.lib.xmi_encoder_timing(self.handle, t)
+        return {"analysis_ms": t[0] / 1e6, "deblock_ms": t[1] / 1e6, "sao_ms": t[2] / 1e6, "write_ms": t[3] / 1e6, "round_trips": int(t[4]), "requests": int(t[5])}
+
+
+def encode_clip(frames, width, height, qp, intra_period=100, **kw):
+    """frames: iterable of (y, u, v); slice types as the reference's command line picks them without scene-change detection
+    (src/x265.cpp:240: picture i is an I slice when i % intra_period == 0 and the picture before it was none) -> stream bytes"""
+    enc = Encoder(width, height, qp, **kw)
+    try:
+        out, prev_intra = [], False
+        for i, (y, u, v) in enumerate(frames):
+            intra = i % intra_period == 0 and not prev_intra
+            out.append(enc.encode(y, u, v, intra))
+            prev_intra = intra
+        return b"".join(out)
+    finally:
+        enc.close()
