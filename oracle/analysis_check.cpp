@@ -234,36 +234,38 @@ private:
 // the picture-level passes of the encoder on the checker's primitives
 class CpuFrameOps : public xmi::encoder::FrameOps {
 public:
-    int deblock(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv, uint8_t *y, uint8_t *u,
-                uint8_t *v) override
+    std::vector<uint8_t> plane[3];      // the deblocked picture
+
+    int deblock_and_stats(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                          const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
     {
-        const size_t n = (size_t)(width / 8) * (height / 4);
+        const size_t n = (size_t)(width / 8) * (height / 4), ny = (size_t)width * height;
         std::vector<uint8_t> vbs(n), hbs(n), qp_tab((size_t)(width / 4) * (height / 4), (uint8_t)qp);
         orc_deblock_strengths(width, height, intra_slice, unit_log2, cbf, mv, vbs.data(), hbs.data());
+        for (int c = 0; c < 3; c++) plane[c].assign(rec[c], rec[c] + (c ? ny / 4 : ny));
         const orc_deblock_params dp = { width, height, width, width / 2, 0, 0, 0, 0 };
-        orc_deblock_frame(y, u, v, &dp, vbs.data(), hbs.data(), qp_tab.data());
-        return 0;
-    }
-    int sao_stats(int width, int height, const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
-    {
+        orc_deblock_frame(plane[0].data(), plane[1].data(), plane[2].data(), &dp, vbs.data(), hbs.data(), qp_tab.data());
         const int cols = width / 64, rows = height / 64;
         for (int cy = 0; cy < rows; cy++)
             for (int cx = 0; cx < cols; cx++)
                 for (int c = 0; c < 3; c++) {
                     int64_t count[5][33], off[5][33];
                     const int pw = c ? width / 2 : width, ph = c ? height / 2 : height;
-                    orc_sao_stats_ctu(rec[c], pw, org[c], pw, pw, ph, cx, cy, c ? 32 : 64, c != 0, count, off);
+                    orc_sao_stats_ctu(plane[c].data(), pw, org[c], pw, pw, ph, cx, cy, c ? 32 : 64, c != 0, count, off);
                     xmi::encoder::SaoStats &s = stats[(size_t)(cy * cols + cx) * 3 + c];
                     for (int t = 0; t < 5; t++)
                         for (int k = 0; k < 33; k++) s.count[t][k] = (int32_t)count[t][k], s.offset_org[t][k] = (int32_t)off[t][k];
                 }
         return 0;
     }
-    int sao_apply(uint8_t *plane, int width, int height, int ctu_size, const xmi::encoder::SaoCtuParam *params) override
+    int sao_apply(int width, int height, const xmi::encoder::SaoCtuParam *const params[3], uint8_t *const out[3]) override
     {
-        std::vector<uint8_t> src(plane, plane + (size_t)width * height);
         static_assert(sizeof(orc_sao_ctu_param) == sizeof(xmi::encoder::SaoCtuParam), "same layout");
-        orc_sao_apply_plane(src.data(), width, plane, width, width, height, ctu_size, reinterpret_cast<const orc_sao_ctu_param *>(params));
+        for (int c = 0; c < 3; c++) {
+            const int pw = c ? width / 2 : width, ph = c ? height / 2 : height;
+            if (params[c]) orc_sao_apply_plane(plane[c].data(), pw, out[c], pw, pw, ph, c ? 32 : 64, reinterpret_cast<const orc_sao_ctu_param *>(params[c]));
+            else std::memcpy(out[c], plane[c].data(), plane[c].size());
+        }
         return 0;
     }
 };

@@ -1,0 +1,86 @@
+"""CPU: the host side of the encoder (x265_amd/csrc/host: decision loops, SAO decision, CABAC writer, headers) bound to the
+CPU checker's primitives (oracle/libx265_analysis_check.so) writes the recorded streams byte for byte. The product binds the
+same host source to the GPU (tests/test_encoder_gpu.py); this test holds the serial logic against the fixtures without one."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from gen_yuv import frame  # noqa: E402
+from tests.prereq import needs_ref  # noqa: E402
+
+LIB = os.path.join(ROOT, "oracle", "libx265_analysis_check.so")
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))
+
+
+def checker():
+    if not os.path.exists(LIB):
+        pytest.fail("oracle/libx265_analysis_check.so is not built (make -C oracle analysis_check)")
+    lib = C.CDLL(LIB)
+    lib.orc_encoder_create.restype = C.c_void_p
+    lib.orc_encoder_create.argtypes = [C.c_int] * 4
+    lib.orc_encoder_destroy.argtypes = [C.c_void_p]
+    lib.orc_encoder_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.orc_encoder_encode.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t]
+    return lib
+
+
+def encode(lib, w, h, frames, qp, lanes=1):
+    from x265_amd.encoder import align_frame
+    W, H = (w + 63) // 64 * 64, (h + 63) // 64 * 64
+    enc = lib.orc_encoder_create(W, H, qp, 0)
+    lib.orc_encoder_configure(enc, lanes, 0)
+    rng = np.random.default_rng(1234)
+    out = np.zeros(W * H * 3 + 4096, np.uint8)
+    stream, raw = b"", b""
+    for t in range(frames):
+        y, u, v = frame(w, h, t, rng)
+        raw += y.tobytes() + u.tobytes() + v.tobytes()
+        ya, ua, va = align_frame(y, u, v, W, H)
+        n = lib.orc_encoder_encode(enc, ya.ctypes.data, ua.ctypes.data, va.ctypes.data, 2 if t == 0 else 1, out.ctypes.data, out.size)
+        assert n > 0, n
+        stream += bytes(out[:n])
+    lib.orc_encoder_destroy(enc)
+    return stream, raw
+
+
+@pytest.mark.parametrize("key,lanes", [("416x240_f8_q32", 1), ("416x240_f3_q22", 2), ("416x240_f8_q37", 1)])
+def test_host_encoder_writes_the_recorded_stream(key, lanes):
+    lib = checker()
+    size, f, q = key.split("_")
+    w, h = (int(v) for v in size.split("x"))
+    stream, raw = encode(lib, w, h, int(f[1:]), int(q[1:]), lanes)
+    assert hashlib.md5(raw).hexdigest() == GOLD[key]["input_md5"]
+    assert len(stream) == GOLD[key]["bytes"]
+    assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
+
+
+@needs_ref("libx265ref_pixel.so", how="make -C oracle ref")
+def test_scan_tables_against_the_reference():
+    """the horizontal / vertical / diagonal coefficient scans the writer derives equal the reference's tables
+    (xg_ausScanIdx, xg_sigLastScan8x8, xg_sigLastScanCG32x32, src/table.cpp:268-511), read from its compiled table.cpp"""
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libx265ref_pixel.so"))
+    lib = checker()
+    lib.orc_syntax_scan.restype = C.POINTER(C.c_uint16)
+    lib.orc_syntax_scan.argtypes = [C.c_int, C.c_int]
+    lib.orc_syntax_group_scan.restype = C.POINTER(C.c_uint8)
+    lib.orc_syntax_group_scan.argtypes = [C.c_int, C.c_int]
+    table = ((C.POINTER(C.c_uint16) * 5) * 3).in_dll(ref, "xg_ausScanIdx")
+    for kind in range(3):
+        for log2 in (2, 3) if kind else (2, 3, 4, 5):      # the reference only ever walks the diagonal scan of 16x16 and 32x32 blocks
+            n = 1 << (2 * log2)
+            ours = [lib.orc_syntax_scan(kind, log2)[i] for i in range(n)]
+            theirs = [table[kind][log2 - 1][i] for i in range(n)]
+            assert ours == theirs, (kind, log2)
+    cg8 = ((C.c_uint16 * 4) * 3).in_dll(ref, "xg_sigLastScan8x8")
+    for kind in range(3):
+        assert [lib.orc_syntax_group_scan(kind, 3)[i] for i in range(4)] == list(cg8[kind])
+    cg32 = (C.c_uint16 * 64).in_dll(ref, "xg_sigLastScanCG32x32")
+    assert [lib.orc_syntax_group_scan(0, 5)[i] for i in range(64)] == list(cg32)
+    assert [lib.orc_syntax_group_scan(0, 4)[i] for i in range(16)] == [table[0][1][i] for i in range(16)]

@@ -561,7 +561,7 @@ size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 constexpr int kMaxLanes = 8;
 
-class GpuEvaluator : public Evaluator {
+class GpuEvaluator : public Evaluator, public xmi::encoder::FrameOps {
 public:
     struct ChromaPlace {
         size_t sum, rec[2], level[2];
@@ -586,6 +586,13 @@ public:
     size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0;
     hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
+    // picture-level passes of the encoder (FrameOps): reconstruction before / after the SAO offsets, decision maps, strength
+    // tables, statistics and parameters on the device; one pinned staging buffer for the copies in either direction
+    uint8_t *d_rec[3] = {}, *d_sao[3] = {}, *d_maps = nullptr, *d_bs = nullptr, *d_qp = nullptr, *h_stage = nullptr;
+    int16_t *d_mv = nullptr;
+    xmi_sao_stats *d_stats = nullptr;
+    xmi_sao_ctu_param *d_params = nullptr;
+    size_t stage_bytes = 0;
 
     ~GpuEvaluator() override { release(); }
 
@@ -597,6 +604,18 @@ public:
             d_src[i] = d_ref[i] = nullptr;
         }
         if (d_planes) (void)hipFree(d_planes), d_planes = nullptr;
+        for (int i = 0; i < 3; i++) {
+            if (d_rec[i]) (void)hipFree(d_rec[i]);
+            if (d_sao[i]) (void)hipFree(d_sao[i]);
+            d_rec[i] = d_sao[i] = nullptr;
+        }
+        if (d_maps) (void)hipFree(d_maps), d_maps = nullptr;
+        if (d_bs) (void)hipFree(d_bs), d_bs = nullptr;
+        if (d_qp) (void)hipFree(d_qp), d_qp = nullptr;
+        if (d_mv) (void)hipFree(d_mv), d_mv = nullptr;
+        if (d_stats) (void)hipFree(d_stats), d_stats = nullptr;
+        if (d_params) (void)hipFree(d_params), d_params = nullptr;
+        if (h_stage) (void)hipHostFree(h_stage), h_stage = nullptr;
         release_lanes();
         if (st) (void)hipStreamDestroy(st), st = nullptr;
     }
@@ -629,6 +648,83 @@ public:
         XMI_HIP(hipMemsetAsync(d_planes, 0, 16 * plane, st));
         XMI_HIP(hipStreamSynchronize(st));
         return set_lanes(nlanes);
+    }
+
+    // what the picture-level passes need on top of init()
+    int init_frame_ops()
+    {
+        const size_t ny = (size_t)w * h, n4 = ny / 16, n8 = ny / 64, nctu = (size_t)(w / 64) * (h / 64);
+        for (int c = 0; c < 3; c++) {
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_rec[c]), c ? ny / 4 : ny));
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_sao[c]), c ? ny / 4 : ny));
+        }
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_maps), 2 * n4));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_bs), 2 * n4));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_qp), n4));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_mv), n8 * 4));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_stats), nctu * 3 * sizeof(xmi_sao_stats)));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_params), nctu * 3 * sizeof(xmi_sao_ctu_param)));
+        stage_bytes = std::max(ny * 3 / 2 + 2 * n4 + n8 * 4, nctu * 3 * sizeof(xmi_sao_stats)) + 4096;
+        XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&h_stage), stage_bytes, hipHostMallocDefault));
+        return XMI_OK;
+    }
+
+    int deblock_and_stats(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                          const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
+    {
+        static_assert(sizeof(xmi::encoder::SaoStats) == sizeof(xmi_sao_stats), "same layout");
+        XMI_ARG(width == w && height == h && d_rec[0], "encoder: picture-level passes were set up for %dx%d", w, h);
+        (void)org;      // the source planes are on the device since bind()
+        const size_t ny = (size_t)w * h, n4 = ny / 16, n8 = ny / 64, nctu = (size_t)(w / 64) * (h / 64);
+        // one staging block: Y, U, V, unit sizes, cbf flags, vectors
+        uint8_t *sp = h_stage;
+        std::memcpy(sp, rec[0], ny), std::memcpy(sp + ny, rec[1], ny / 4), std::memcpy(sp + ny * 5 / 4, rec[2], ny / 4);
+        uint8_t *sm = sp + ny * 3 / 2;
+        std::memcpy(sm, unit_log2, n4), std::memcpy(sm + n4, cbf, n4);
+        if (!intra_slice) std::memcpy(sm + 2 * n4, mv, n8 * 4);
+        XMI_HIP(hipMemcpyAsync(d_rec[0], sp, ny, hipMemcpyHostToDevice, st));
+        XMI_HIP(hipMemcpyAsync(d_rec[1], sp + ny, ny / 4, hipMemcpyHostToDevice, st));
+        XMI_HIP(hipMemcpyAsync(d_rec[2], sp + ny * 5 / 4, ny / 4, hipMemcpyHostToDevice, st));
+        XMI_HIP(hipMemcpyAsync(d_maps, sm, 2 * n4, hipMemcpyHostToDevice, st));
+        if (!intra_slice) XMI_HIP(hipMemcpyAsync(d_mv, sm + 2 * n4, n8 * 4, hipMemcpyHostToDevice, st));
+        XMI_HIP(hipMemsetAsync(d_qp, qp, n4, st));
+        int rc = xmi_deblock_strengths_dev(w, h, intra_slice, d_maps, d_maps + n4, intra_slice ? nullptr : d_mv, d_bs, d_bs + n4, st);
+        if (rc != XMI_OK) return rc;
+        const xmi_deblock_params dp = { w, h, w, w / 2, 0, 0, 0, 0 };
+        rc = xmi_deblock_frame_dev(d_rec[0], d_rec[1], d_rec[2], &dp, d_bs, d_bs + n4, d_qp, st);
+        if (rc != XMI_OK) return rc;
+        const xmi_sao_geom g = { w, h, w, w / 2, w, w / 2 };
+        rc = xmi_sao_stats_dev(&g, d_rec[0], d_rec[1], d_rec[2], d_src[0], d_src[1], d_src[2], d_stats, st);
+        if (rc != XMI_OK) return rc;
+        XMI_HIP(hipMemcpyAsync(h_stage, d_stats, nctu * 3 * sizeof(xmi_sao_stats), hipMemcpyDeviceToHost, st));
+        XMI_HIP(hipStreamSynchronize(st));
+        std::memcpy(stats, h_stage, nctu * 3 * sizeof(xmi_sao_stats));
+        return XMI_OK;
+    }
+
+    int sao_apply(int width, int height, const xmi::encoder::SaoCtuParam *const params[3], uint8_t *const out[3]) override
+    {
+        static_assert(sizeof(xmi::encoder::SaoCtuParam) == sizeof(xmi_sao_ctu_param), "same layout");
+        XMI_ARG(width == w && height == h && d_rec[0], "encoder: picture-level passes were set up for %dx%d", w, h);
+        const size_t ny = (size_t)w * h, nctu = (size_t)(w / 64) * (h / 64);
+        xmi_sao_ctu_param *hp = reinterpret_cast<xmi_sao_ctu_param *>(h_stage + ny * 3 / 2);
+        for (int c = 0; c < 3; c++)
+            if (params[c]) std::memcpy(hp + c * nctu, params[c], nctu * sizeof(xmi_sao_ctu_param));
+        XMI_HIP(hipMemcpyAsync(d_params, hp, 3 * nctu * sizeof(xmi_sao_ctu_param), hipMemcpyHostToDevice, st));
+        const size_t off[3] = { 0, ny, ny * 5 / 4 };
+        for (int c = 0; c < 3; c++) {
+            const int pw = c ? w / 2 : w, ph = c ? h / 2 : h;
+            const uint8_t *from = d_rec[c];
+            if (params[c]) {
+                const int rc = xmi_sao_apply_plane_dev(d_rec[c], pw, d_sao[c], pw, pw, ph, c ? 32 : 64, d_params + c * nctu, st);
+                if (rc != XMI_OK) return rc;
+                from = d_sao[c];
+            }
+            XMI_HIP(hipMemcpyAsync(h_stage + off[c], from, (size_t)pw * ph, hipMemcpyDeviceToHost, st));
+        }
+        XMI_HIP(hipStreamSynchronize(st));
+        for (int c = 0; c < 3; c++) std::memcpy(out[c], h_stage + off[c], c ? ny / 4 : ny);
+        return XMI_OK;
     }
 
     // (re)creates what the lanes own; rows are dealt to lanes round robin, so a lane serves at most ceil(rows / lanes) of them
@@ -1076,43 +1172,9 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
 }  // extern "C"
 
 // ---- the whole encoder ----------------------------------------------------------------------------------------------------
-namespace {
-
-// the picture-level passes of host/encoder_core.h on the library's kernels (host-pointer entry points)
-class GpuFrameOps : public xmi::encoder::FrameOps {
-public:
-    std::vector<uint8_t> vbs, hbs, qp_tab;
-
-    int deblock(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv, uint8_t *y, uint8_t *u,
-                uint8_t *v) override
-    {
-        const size_t n = (size_t)(width / 8) * (height / 4);
-        vbs.resize(n), hbs.resize(n);
-        qp_tab.assign((size_t)(width / 4) * (height / 4), (uint8_t)qp);
-        int rc = xmi_deblock_strengths(width, height, intra_slice, unit_log2, cbf, mv, vbs.data(), hbs.data());
-        if (rc != XMI_OK) return rc;
-        const xmi_deblock_params dp = { width, height, width, width / 2, 0, 0, 0, 0 };
-        return xmi_deblock_frame(y, u, v, &dp, vbs.data(), hbs.data(), qp_tab.data());
-    }
-    int sao_stats(int width, int height, const uint8_t *const rec[3], const uint8_t *const org[3], xmi::encoder::SaoStats *stats) override
-    {
-        static_assert(sizeof(xmi::encoder::SaoStats) == sizeof(xmi_sao_stats), "same layout");
-        const xmi_sao_geom g = { width, height, width, width / 2, width, width / 2 };
-        return xmi_sao_stats_frame(&g, rec[0], rec[1], rec[2], org[0], org[1], org[2], reinterpret_cast<xmi_sao_stats *>(stats));
-    }
-    int sao_apply(uint8_t *plane, int width, int height, int ctu_size, const xmi::encoder::SaoCtuParam *params) override
-    {
-        static_assert(sizeof(xmi::encoder::SaoCtuParam) == sizeof(xmi_sao_ctu_param), "same layout");
-        return xmi_sao_apply_plane(plane, width, width, height, ctu_size, reinterpret_cast<const xmi_sao_ctu_param *>(params));
-    }
-};
-
-}  // namespace
-
 struct xmi_encoder {
     xmi::encoder::Encoder enc;
     GpuEvaluator ev;
-    GpuFrameOps ops;
     xmi_encoder(int w, int h, int qp, int strong) : enc(w, h, qp, strong) {}
 };
 
@@ -1130,7 +1192,7 @@ xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_
         xmi::set_error("xmi_encoder_create: out of host memory");
         return nullptr;
     }
-    if (e->ev.init(width, height, e->enc.analyser().lanes) != XMI_OK) {
+    if (e->ev.init(width, height, e->enc.analyser().lanes) != XMI_OK || e->ev.init_frame_ops() != XMI_OK) {
         delete e;
         return nullptr;
     }
@@ -1159,7 +1221,7 @@ int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *
     if (rc != XMI_OK) return rc;
     XMI_ARG(e && src_y && src_u && src_v && out, "xmi_encoder_encode: null argument");
     XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_encode: slice type %d", slice_type);
-    const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ops, out, capacity);
+    const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ev, out, capacity);
     if (n > 0) return n;
     if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold 3 * width * height + 4096 bytes");
     else if (n == -101) xmi::set_error("xmi_encoder_encode: a P picture needs a picture before it");

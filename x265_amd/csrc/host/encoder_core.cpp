@@ -531,7 +531,6 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     rc = intra ? an_.i_picture(qp_, strong_, ev, res_) : an_.p_picture(qp_, ev, res_);
     if (rc) return rc < 0 ? rc : -rc;
     const auto t1 = clock::now();
-    rec_[0] = res_.rec_y, rec_[1] = res_.rec_u, rec_[2] = res_.rec_v;
 
     // ---- in-loop filters ----
     const int w4 = w_ / 4, w8 = w_ / 8;
@@ -540,28 +539,31 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
             const CtuView v = { res_, x, y, cols_, w4, w8, w_ };
             ctu_units(v, unit_log2_.data(), unit_cbf_.data());
         }
-    rc = ops.deblock(w_, h_, intra, qp_, unit_log2_.data(), unit_cbf_.data(), reinterpret_cast<const int16_t *>(res_.mv.data()), rec_[0].data(), rec_[1].data(),
-                     rec_[2].data());
+    sao_on_[0] = sao_on_[1] = true;      // rdoSaoUnitRowInit (src/encode.cpp:305): the rates it tests are never written
+    const uint8_t *recp[3] = { res_.rec_y.data(), res_.rec_u.data(), res_.rec_v.data() }, *orgp[3] = { src_y, src_u, src_v };
+    rc = ops.deblock_and_stats(w_, h_, intra, qp_, unit_log2_.data(), unit_cbf_.data(), reinterpret_cast<const int16_t *>(res_.mv.data()), recp, orgp,
+                               stats_.data());
     if (rc) return rc < 0 ? rc : -rc;
     const auto t2 = clock::now();
-    sao_on_[0] = sao_on_[1] = true;      // rdoSaoUnitRowInit (src/encode.cpp:305): the rates it tests are never written
-    const uint8_t *recp[3] = { rec_[0].data(), rec_[1].data(), rec_[2].data() }, *orgp[3] = { src_y, src_u, src_v };
-    rc = ops.sao_stats(w_, h_, recp, orgp, stats_.data());
-    if (rc) return rc < 0 ? rc : -rc;
     sao_decide(slice_type, stats_.data());
     {
-        std::vector<SaoCtuParam> params((size_t)rows_ * cols_);
+        const size_t nctu = (size_t)rows_ * cols_;
+        sao_params_.resize(3 * nctu);
+        const SaoCtuParam *pp[3] = { nullptr, nullptr, nullptr };
         for (int comp = 0; comp < 3; comp++) {
             if (!(comp == 0 ? sao_on_[0] : sao_on_[1])) continue;
-            for (size_t i = 0; i < params.size(); i++) {
+            SaoCtuParam *params = &sao_params_[comp * nctu];
+            for (size_t i = 0; i < nctu; i++) {
                 const SaoUnit &u = sao_[comp][i];
                 params[i].type_idx = (int8_t)u.type_idx, params[i].band_position = (uint8_t)u.sub_type;
                 for (int k = 0; k < 4; k++) params[i].offset[k] = (int8_t)u.offset[k];
                 params[i].reserved[0] = params[i].reserved[1] = 0;
             }
-            rc = ops.sao_apply(rec_[comp].data(), comp ? wc : w_, comp ? hc : h_, comp ? 32 : 64, params.data());
-            if (rc) return rc < 0 ? rc : -rc;
+            pp[comp] = params;
         }
+        uint8_t *outp[3] = { rec_[0].data(), rec_[1].data(), rec_[2].data() };
+        rc = ops.sao_apply(w_, h_, pp, outp);
+        if (rc) return rc < 0 ? rc : -rc;
     }
     const auto t3 = clock::now();
 

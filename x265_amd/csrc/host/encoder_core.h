@@ -32,14 +32,17 @@ struct SaoCtuParam {
 class FrameOps {
 public:
     virtual ~FrameOps() {}
-    // Boundary strengths from the decision maps (ff_hevc_deblocking_boundary_strengths, src/Deblock.cpp:369: unit size and
-    // luma cbf per 4x4 block, vector per 8x8 block) and xDeblockFrame (src/Deblock.cpp:524) on the reconstruction, in place.
-    virtual int deblock(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv, uint8_t *y,
-                        uint8_t *u, uint8_t *v) = 0;
-    // calcSaoStatsCu (src/encode.cpp:364) for every CTU and component: stats[ctu * 3 + component]
-    virtual int sao_stats(int width, int height, const uint8_t *const rec[3], const uint8_t *const org[3], SaoStats *stats) = 0;
-    // processSaoUnitAll (src/encode.cpp:1762) on one component plane, in place; params per CTU in raster order
-    virtual int sao_apply(uint8_t *plane, int width, int height, int ctu_size, const SaoCtuParam *params) = 0;
+    // In-loop deblocking of the unfiltered reconstruction `rec` - boundary strengths from the decision maps
+    // (ff_hevc_deblocking_boundary_strengths, src/Deblock.cpp:369: unit size and luma cbf per 4x4 block, vector per 8x8
+    // block), then xDeblockFrame (src/Deblock.cpp:524) - and, on the result, calcSaoStatsCu (src/encode.cpp:364) against the
+    // source `org` for every CTU and component: stats[ctu * 3 + component]. The deblocked picture stays with the
+    // implementation until sao_apply().
+    virtual int deblock_and_stats(int width, int height, int intra_slice, int qp, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
+                                  const uint8_t *const rec[3], const uint8_t *const org[3], SaoStats *stats) = 0;
+    // processSaoUnitAll (src/encode.cpp:1762) on the deblocked picture of the last deblock_and_stats(): params[c] holds
+    // component c's parameters per CTU in raster order, or is null when SAO is off for it. The final reconstruction goes
+    // to out[].
+    virtual int sao_apply(int width, int height, const SaoCtuParam *const params[3], uint8_t *const out[3]) = 0;
 };
 
 class Encoder {
@@ -62,7 +65,7 @@ public:
     const std::vector<syntax::SaoUnit> &sao_units(int comp) const { return sao_[comp]; }
     const std::vector<SaoStats> &sao_statistics() const { return stats_; }
     int poc() const { return poc_; }
-    // wall time of the last picture's stages in nanoseconds: analysis, deblocking, SAO (statistics + decision + offsets), writing
+    // wall time of the last picture's stages in nanoseconds: analysis, deblocking + SAO statistics, SAO decision + offsets, writing
     uint64_t stage_ns[4] = { 0, 0, 0, 0 };
 
 private:
@@ -79,6 +82,7 @@ private:
     bool sao_on_[2] = { true, true };
     std::vector<uint8_t> unit_log2_, unit_cbf_;
     std::vector<SaoStats> stats_;
+    std::vector<SaoCtuParam> sao_params_;
     std::vector<uint8_t> sub_;               // slice data under construction
 };
 
