@@ -191,6 +191,21 @@ def analysis_rate(L, qp=32, pictures=4, segments=True):
         return {"error": repr(e)}
 
 
+def encode_rate(L, qp=32, segments=True):
+    """The first half of the headline metric with this library's code only: encode fps of xmi_encoder_encode (analysis loop,
+    in-loop filters, SAO, entropy coding; I and P pictures; the stream is the reference's, tests/test_encoder_gpu.py) on the
+    clip the reference's encoder is timed on under cpu_baseline.encoder. Outside the timed region, rank 0."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import bench_encoder
+        out = bench_encoder.run(1920, 1080, 6, qp)
+        if segments:
+            out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8)
+        return out
+    except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -379,6 +394,7 @@ def main():
             out["satd"] = satd_rates(L, capi, torch, dev, stream)
             if not args.no_analysis:
                 out["analysis"] = analysis_rate(L, segments=not args.no_segments)
+                out["encode"] = encode_rate(L, segments=not args.no_segments)
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

@@ -435,8 +435,9 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
  *                        picture before it); out must hold 3 * width * height + 4096 bytes. Returns the size of the access
  *                        unit or XMI_ERR_*.
  * xmi_encoder_reconstruction: the last picture's reconstruction after the in-loop filters, packed planes.
- * xmi_encoder_timing   : of the last picture, out = { ns analysis, ns deblocking, ns SAO, ns writing, GPU round trips,
- *                        CU / PU requests } (no counterpart in the reference). */
+ * xmi_encoder_timing   : of the last picture, out = { ns analysis, ns deblocking + SAO statistics, ns SAO decision + offsets, ns
+ *                        writing, GPU round trips, CU / PU requests, and of the round trips: ns writing job tables, ns in the
+ *                        launch call, ns waiting for the GPU, ns reading results } (no counterpart in the reference). */
 typedef struct xmi_encoder xmi_encoder;
 xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_smoothing);
 void xmi_encoder_destroy(xmi_encoder *e);
@@ -444,7 +445,7 @@ int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us);
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
                            size_t capacity);
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);
-int xmi_encoder_timing(xmi_encoder *e, uint64_t out[6]);
+int xmi_encoder_timing(xmi_encoder *e, uint64_t out[10]);
 
 /* ---- batched block metrics -------------------------------------------------------------------
  * count pairs of n x n blocks, packed back to back (block i at offset i*n*n), one uint32 per pair.

@@ -14,28 +14,96 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gen_yuv import frame  # noqa: E402
 
 
+def clip(w, h, n, seed=None):
+    rng = np.random.default_rng(seed if seed is not None else (7 if w == 1920 else 1234))
+    return [frame(w, h, t, rng) for t in range(n)]
+
+
+def run(w=1920, h=1080, n=6, qp=32, lanes=1, spin_us=200, verbose=False):
+    """one picture stream: the clip of the CPU baseline (tools/gen_yuv.py, seed 7 at 1080p), picture 0 intra; wall clock of the
+    encode calls (pictures resident in host memory; the call uploads them)"""
+    import hashlib
+    from x265_amd.encoder import Encoder
+    pics = clip(w, h, n)
+    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us)
+    try:
+        warm = Encoder(w, h, qp)        # first call of a process: code objects, buffers - on an instance of its own, so that the
+        warm.encode(*pics[0], True)     # timed instance starts from a new encoder's state, as the reference's run does
+        warm.close()
+        stream, per = b"", []
+        t_all = time.perf_counter()
+        for i, (y, u, v) in enumerate(pics):
+            t0 = time.perf_counter()
+            au = enc.encode(y, u, v, i == 0)
+            dt = time.perf_counter() - t0
+            stream += au
+            per.append({"picture": i, "type": "I" if i == 0 else "P", "bytes": len(au), "ms": round(dt * 1e3, 2),
+                        **{k: round(v, 2) if isinstance(v, float) else ({a: round(b, 1) for a, b in v.items()} if isinstance(v, dict) else v) for k, v in enc.timing().items()}})
+            if verbose:
+                print(json.dumps(per[-1]), flush=True)
+        wall = time.perf_counter() - t_all
+    finally:
+        enc.close()
+    p_ms = [p["ms"] for p in per[1:]]
+    return {"what": f"{w}x{h} synthetic IPPP, {n} pictures, QP {qp}: this library's encoder (xmi_encoder_encode), one picture stream",
+            "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": hashlib.md5(stream).hexdigest(),
+            "i_picture_ms": per[0]["ms"], "i_picture_round_trips": per[0]["round_trips"], "i_picture_us_per_round_trip": per[0]["us_per_round_trip"], "p_picture_ms": round(float(np.mean(p_ms)), 2) if p_ms else None,
+            "p_pictures_per_s": round(1e3 / float(np.mean(p_ms)), 2) if p_ms else None,
+            "p_stage_ms": {k: round(float(np.mean([p[k] for p in per[1:]])), 2) for k in ("analysis_ms", "deblock_ms", "sao_ms", "write_ms")} if p_ms else None,
+            "round_trips_per_p_picture": int(np.mean([p["round_trips"] for p in per[1:]])) if p_ms else None,
+            "p_picture_us_per_round_trip": per[-1]["us_per_round_trip"] if p_ms else None}
+
+
+def run_segments(w=1920, h=1080, n=4, qp=32, segments=8):
+    """`segments` independent GOP segments (each its own encoder, I picture first) encoded at the same time on one GPU, one
+    host thread per segment (the C call releases the interpreter lock): whole-job pictures per second over all pictures,
+    and over the P pictures alone (after a barrier behind the I pictures)"""
+    import threading
+    from x265_amd.encoder import Encoder
+    clips = [clip(w, h, n, seed=7 + s) for s in range(segments)]
+    encs = [Encoder(w, h, qp, spin_us=0) for _ in range(segments)]
+    errs, marks = [], {}
+    gate = threading.Barrier(segments + 1)
+
+    def work(s):
+        try:
+            encs[s].encode(*clips[s][0], True)
+            gate.wait()
+            gate.wait()
+            for y, u, v in clips[s][1:]:
+                encs[s].encode(y, u, v, False)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+            gate.abort()
+
+    th = [threading.Thread(target=work, args=(s,)) for s in range(segments)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    try:
+        gate.wait()
+        marks["i_done"] = time.perf_counter()
+        gate.wait()
+    except threading.BrokenBarrierError:
+        pass
+    for t in th:
+        t.join()
+    t1 = time.perf_counter()
+    for e in encs:
+        e.close()
+    if errs:
+        return {"error": errs[0]}
+    return {"segments": segments, "pictures_per_segment": n, "encode_fps": round(segments * n / (t1 - t0), 2),
+            "p_pictures_per_s": round(segments * (n - 1) / (t1 - marks["i_done"]), 2), "i_pictures_s": round(marks["i_done"] - t0, 3)}
+
+
 def main():
     a = sys.argv[1:]
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
     lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (1, 200)
-    from x265_amd.encoder import Encoder
-    rng = np.random.default_rng(7 if w == 1920 else 1234)
-    pics = [frame(w, h, t, rng) for t in range(n)]
-    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin)
-    total, per = 0, []
-    t_all = time.perf_counter()
-    for i, (y, u, v) in enumerate(pics):
-        t0 = time.perf_counter()
-        au = enc.encode(y, u, v, i == 0)
-        dt = time.perf_counter() - t0
-        total += len(au)
-        per.append({"picture": i, "type": "I" if i == 0 else "P", "bytes": len(au), "ms": round(dt * 1e3, 2), **{k: round(v, 2) if isinstance(v, float) else v for k, v in enc.timing().items()}})
-        print(json.dumps(per[-1]), flush=True)
-    wall = time.perf_counter() - t_all
-    p_ms = [p["ms"] for p in per[1:]]
-    print(json.dumps({"pictures": n, "bytes": total, "fps": round(n / wall, 2), "i_picture_ms": per[0]["ms"], "p_picture_ms_mean": round(float(np.mean(p_ms)), 2) if p_ms else None,
-                      "p_fps": round(1e3 / float(np.mean(p_ms)), 2) if p_ms else None}))
-    enc.close()
+    print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True)))
+    if "--segments" in a:
+        print(json.dumps(run_segments(w, h, 4, qp, 8)))
 
 
 if __name__ == "__main__":

@@ -1175,6 +1175,7 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
 struct xmi_encoder {
     xmi::encoder::Encoder enc;
     GpuEvaluator ev;
+    uint64_t lane_mark[kMaxLanes][4] = {};      // the lanes' time sums when the last picture began
     xmi_encoder(int w, int h, int qp, int strong) : enc(w, h, qp, strong) {}
 };
 
@@ -1221,6 +1222,10 @@ int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *
     if (rc != XMI_OK) return rc;
     XMI_ARG(e && src_y && src_u && src_v && out, "xmi_encoder_encode: null argument");
     XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_encode: slice type %d", slice_type);
+    for (int i = 0; i < e->ev.lanes; i++) {
+        const GpuEvaluator::LaneRes &l = e->ev.lane[i];
+        e->lane_mark[i][0] = l.t_prepare, e->lane_mark[i][1] = l.t_launch, e->lane_mark[i][2] = l.t_wait, e->lane_mark[i][3] = l.t_collect;
+    }
     const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ev, out, capacity);
     if (n > 0) return n;
     if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold 3 * width * height + 4096 bytes");
@@ -1238,12 +1243,18 @@ int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *
     return XMI_OK;
 }
 
-int xmi_encoder_timing(xmi_encoder *e, uint64_t out[6])
+int xmi_encoder_timing(xmi_encoder *e, uint64_t out[10])
 {
     XMI_ARG(e && out, "xmi_encoder_timing: null argument");
     for (int k = 0; k < 4; k++) out[k] = e->enc.stage_ns[k];
     out[4] = e->enc.analysis_result().evaluator_calls;
     out[5] = e->enc.analysis_result().cu_requests + e->enc.analysis_result().chroma_requests;
+    for (int k = 6; k < 10; k++) out[k] = 0;
+    for (int i = 0; i < e->ev.lanes; i++) {
+        const GpuEvaluator::LaneRes &l = e->ev.lane[i];
+        out[6] += l.t_prepare - e->lane_mark[i][0], out[7] += l.t_launch - e->lane_mark[i][1];
+        out[8] += l.t_wait - e->lane_mark[i][2], out[9] += l.t_collect - e->lane_mark[i][3];
+    }
     return XMI_OK;
 }
 

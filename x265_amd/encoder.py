@@ -75,9 +75,12 @@ class Encoder:
         return y, u, v
 
     def timing(self):
-        t = (C.c_uint64 * 6)()
+        t = (C.c_uint64 * 10)()
         self.lib.xmi_encoder_timing(self.handle, t)
-        return {"analysis_ms": t[0] / 1e6, "deblock_ms": t[1] / 1e6, "sao_ms": t[2] / 1e6, "write_ms": t[3] / 1e6, "round_trips": int(t[4]), "requests": int(t[5])}
+        n = max(1, int(t[4]))
+        return {"analysis_ms": t[0] / 1e6, "deblock_ms": t[1] / 1e6, "sao_ms": t[2] / 1e6, "write_ms": t[3] / 1e6, "round_trips": int(t[4]), "requests": int(t[5]),
+                "us_per_round_trip": {"total": t[0] / 1e3 / n, "job_tables": t[6] / 1e3 / n, "launch_call": t[7] / 1e3 / n, "gpu_wait": t[8] / 1e3 / n,
+                                      "read_back": t[9] / 1e3 / n}}
 
 
 def encode_clip(frames, width, height, qp, intra_period=100, **kw):
