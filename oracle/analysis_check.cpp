@@ -58,20 +58,22 @@ public:
         return 0;
     }
 
-    int evaluate_intra(int lane, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch) override
+    int evaluate_intra(int lane, const IntraBatch &bt) override
     {
         std::lock_guard<std::mutex> lk(mu);
         std::vector<uint8_t> &bytes = lane_bytes[lane & 7];
         std::vector<int16_t> &words = lane_words[lane & 7];
-        size_t n = 0;
-        for (int i = 0; i < npu; i++) n += (size_t)pu[i]->size * pu[i]->size;
-        for (int i = 0; i < nch; i++) n += 2 * (size_t)ch[i]->size * ch[i]->size;
+        size_t n = 64 * (size_t)bt.nquad + 128 * (size_t)bt.ncquad;
+        for (int i = 0; i < bt.npu; i++) n += (size_t)bt.pu[i]->size * bt.pu[i]->size;
+        for (int i = 0; i < bt.nchroma; i++) n += 2 * (size_t)bt.chroma[i]->size * bt.chroma[i]->size;
         bytes.assign(n, 0);
         words.assign(n, 0);
         uint8_t *b = bytes.data();
         int16_t *w = words.data();
-        for (int i = 0; i < npu; i++) one_intra(*pu[i], b, w);
-        for (int i = 0; i < nch; i++) one_intra_chroma(*ch[i], b, w);
+        for (int i = 0; i < bt.npu; i++) one_intra(*bt.pu[i], b, w);
+        for (int i = 0; i < bt.nchroma; i++) one_intra_chroma(*bt.chroma[i], b, w);
+        for (int i = 0; i < bt.nquad; i++) one_quad(*bt.quad[i], b, w);
+        for (int i = 0; i < bt.ncquad; i++) one_chroma_quad(*bt.cquad[i], b, w);
         return 0;
     }
 
@@ -111,6 +113,76 @@ private:
         }
         q.rec = b, q.level = w;
         b += n * n, w += n * n;
+    }
+
+    // the 17 neighbouring samples of the 4x4 PU k of an 8x8 area: from the area's own 33 samples outside it, from the
+    // reconstruction of the PUs before it inside (area: 8x8, rows 8 apart)
+    static void quad_neighbours(uint8_t *ref, const uint8_t *outer, const uint8_t *area, int k)
+    {
+        const int ox = (k & 1) * 4, oy = (k >> 1) * 4;
+        auto at = [&](int yy, int xx) -> uint8_t {      // relative to the area's origin
+            if (yy < 0) return outer[16 + 1 + xx];
+            if (xx < 0) return outer[15 - yy];
+            return xx < 8 && yy < 8 ? area[yy * 8 + xx] : (uint8_t)0x80;
+        };
+        for (int i = 0; i < 8; i++) ref[i] = at(oy + 7 - i, ox - 1);
+        for (int i = 0; i <= 8; i++) ref[8 + i] = at(oy - 1, ox - 1 + i);
+    }
+
+    // four IntraEval of size 4 back to back
+    void one_quad(IntraQuadEval &q, uint8_t *&b, int16_t *&w)
+    {
+        uint8_t *area = b;
+        int16_t *lev = w;
+        b += 64, w += 64;
+        for (int k = 0; k < 4; k++) {
+            IntraEval e;
+            e.x0 = q.x0 + (k & 1) * 4, e.y0 = q.y0 + (k >> 1) * 4, e.size = 4;
+            e.valids = q.valids[k], e.strong = q.strong, e.sqrt_lambda = q.sqrt_lambda, e.qp = q.qp;
+            const int left = (k & 1) ? q.best_mode[k - 1] : q.left_mode[k >> 1], top = (k >> 1) ? q.best_mode[k - 2] : q.top_mode[k & 1];
+            if (left == top) {
+                if (left > 1) e.mpm[0] = (uint8_t)left, e.mpm[1] = (uint8_t)(((left + 29) % 32) + 2), e.mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+                else e.mpm[0] = 0, e.mpm[1] = 1, e.mpm[2] = 26;
+            } else {
+                e.mpm[0] = (uint8_t)left, e.mpm[1] = (uint8_t)top;
+                e.mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+            }
+            quad_neighbours(e.ref, q.ref, area, k);
+            uint8_t tmp_b[16], *tb = tmp_b;
+            int16_t tmp_w[16], *tw = tmp_w;
+            one_intra(e, tb, tw);
+            q.best_mode[k] = e.best_mode, q.ssd[k] = e.ssd, q.sum[k] = e.sum;
+            for (int r = 0; r < 4; r++) {
+                std::memcpy(area + ((k >> 1) * 4 + r) * 8 + (k & 1) * 4, tmp_b + r * 4, 4);
+                std::memcpy(lev + ((k >> 1) * 4 + r) * 8 + (k & 1) * 4, tmp_w + r * 4, 8);
+            }
+        }
+        q.rec = area, q.level = lev;
+    }
+
+    // four IntraChromaEval of size 4 back to back
+    void one_chroma_quad(IntraChromaQuadEval &c, uint8_t *&b, int16_t *&w)
+    {
+        uint8_t *area[2] = { b, b + 64 };
+        int16_t *lev[2] = { w, w + 64 };
+        b += 128, w += 128;
+        for (int k = 0; k < 4; k++) {
+            IntraChromaEval e;
+            e.x0 = c.x0 + (k & 1) * 4, e.y0 = c.y0 + (k >> 1) * 4, e.size = 4;
+            e.valids = c.valids[k], e.luma_mode = c.luma_mode[k], e.qpc = c.qpc;
+            quad_neighbours(e.ref_u, c.ref_u, area[0], k);
+            quad_neighbours(e.ref_v, c.ref_v, area[1], k);
+            uint8_t tmp_b[32], *tb = tmp_b;
+            int16_t tmp_w[32], *tw = tmp_w;
+            one_intra_chroma(e, tb, tw);
+            c.best_idx[k] = e.best_idx, c.sum_u[k] = e.sum_u, c.sum_v[k] = e.sum_v;
+            for (int pl = 0; pl < 2; pl++)
+                for (int r = 0; r < 4; r++) {
+                    std::memcpy(area[pl] + ((k >> 1) * 4 + r) * 8 + (k & 1) * 4, (pl ? e.rec_v : e.rec_u) + r * 4, 4);
+                    std::memcpy(lev[pl] + ((k >> 1) * 4 + r) * 8 + (k & 1) * 4, (pl ? e.level_v : e.level_u) + r * 4, 8);
+                }
+        }
+        c.rec_u = area[0], c.rec_v = area[1], c.level_u = lev[0], c.level_v = lev[1];
     }
 
     void one_intra_chroma(IntraChromaEval &c, uint8_t *&b, int16_t *&w)

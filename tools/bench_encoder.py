@@ -102,6 +102,14 @@ def main():
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
     lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (1, 200)
     print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True)))
+    from x265_amd import capi
+    L = capi.load()
+    if hasattr(L, "xmi_debug_intra_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING): workgroup time per job type
+        import ctypes
+        tk = (ctypes.c_ulonglong * 18)()
+        L.xmi_debug_intra_ticks(tk)
+        names = ("pu4", "pu8", "pu16", "pu32", "chroma4", "chroma8", "chroma16", "luma_group", "chroma_group")
+        print(json.dumps({n: {"us": round(tk[2 * i] / max(1, tk[2 * i + 1]) / 100.0, 2), "count": int(tk[2 * i + 1])} for i, n in enumerate(names)}))
     if "--segments" in a:
         print(json.dumps(run_segments(w, h, 4, qp, 8)))
 

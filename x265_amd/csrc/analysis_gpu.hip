@@ -124,7 +124,7 @@ __constant__ int8_t k_dst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 8
 
 template <int N, bool INTRA = false, bool DST = false>
 __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
-                           uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd)
+                           uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd, uint8_t *rec_copy = nullptr, int copy_stride = 0)
 {
     constexpr int LD = Cfg<N>::LD, LG = Cfg<N>::LOG2, TPT = Cfg<N>::TPT;
     const int tid = threadIdx.x;
@@ -194,6 +194,7 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
             d2 += (uint32_t)(d * d);
         }
         *reinterpret_cast<uint32_t *>(rec + (size_t)i * out_stride + j) = r4;
+        if (rec_copy) *reinterpret_cast<uint32_t *>(rec_copy + i * copy_stride + j) = r4;
         if (pred_out) *reinterpret_cast<uint32_t *>(pred_out + (size_t)i * out_stride + j) = pr4;
     }
     // the two sums of the unit: one value per wavefront into LDS (256 atomics on one word take longer than the transform)
@@ -409,7 +410,7 @@ __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p
 // ---- I pictures: one workgroup per PU request ----
 struct IntraJob {
     int32_t x0, y0, size;
-    uint8_t valids, strong, mpm[3], reserved[3];
+    uint8_t valids, strong, mpm[3], parts, reserved[2];      // parts: workgroups that share the PU's mode search
     int32_t qp;
     double sqrt_lambda;
     uint8_t ref[136];
@@ -430,10 +431,49 @@ struct IntraChromaHead {
     int32_t best_idx;
     uint32_t sum[2];
 };
+// four 4x4 PUs of an 8x8 block back to back (luma), and the same for an 8x8 area of the chroma planes
+struct IntraQuadJob {
+    int32_t x0, y0;
+    uint8_t valids[4], left_mode[2], top_mode[2], strong, reserved[3];
+    int32_t qp;
+    double sqrt_lambda;
+    uint8_t ref[40];
+    uint32_t out_head, out_rec, out_level;
+};
+struct IntraQuadHead {
+    int32_t best_mode[4];
+    uint32_t sum[4], ssd[4];
+};
+struct IntraChromaQuadJob {
+    int32_t x0, y0;
+    uint8_t valids[4], luma_mode[4];
+    int32_t qpc;
+    uint8_t ref[2][40];
+    uint32_t out_head, out_rec[2], out_level[2];
+};
+struct IntraChromaQuadHead {
+    int32_t best_idx[4];
+    uint32_t sum[2][4];
+};
+struct IntraGroup {               // what one workgroup of the PU part does
+    uint16_t job;
+    uint8_t part, reserved;
+};
+struct IntraPartial {             // a workgroup's best candidate, for the workgroup of the PU that finishes last
+    double cost;
+    int32_t mode, reserved;
+};
+constexpr int kIntraParts = 3;    // workgroups per 16x16 / 32x32 PU
+
 struct IntraRoundParams {
     const IntraJob *jobs;
+    const IntraGroup *groups;
+    IntraPartial *partials;       // [job][part], device memory
+    unsigned *arrived;            // [job], device memory, zero between rounds
     const IntraChromaJob *cjobs;
-    int npu, nchroma;
+    const IntraQuadJob *qjobs;
+    const IntraChromaQuadJob *cqjobs;
+    int npu, nchroma, nquad, ncquad;
     const uint8_t *src[3];
     int width;
     uint8_t *out;
@@ -448,13 +488,26 @@ struct __align__(16) IntraLds {
     double best_cost[4];
     int best_mode[4];
     int best;
+    double cost;
+    int last;
     uint32_t satd[10];
     xmi_chroma_result cres;
+    // quads: the 8x8 area(s) being reconstructed, their outer samples, the samples of the PU in hand, the modes so far
+    uint8_t area[2][64], outer[2][40], qref[2][20];
+    int qmode[4];
 };
+
+// sample at (xx, yy) relative to the origin of an 8x8 area: from its 33 outer samples, or from the area itself
+__device__ __forceinline__ uint8_t quad_sample(const uint8_t *outer, const uint8_t *area, int yy, int xx)
+{
+    if (yy < 0) return outer[16 + 1 + xx];
+    if (xx < 0) return outer[15 - yy];
+    return xx < 8 && yy < 8 ? area[yy * 8 + xx] : (uint8_t)0x80;
+}
 
 // one luma PU (src/encode.cpp:4005-4115): 35-mode search on the four wavefronts, prediction of the winner, transform chain
 template <int N>
-__device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob &j)
+__device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob &j, int job, int part)
 {
     constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -463,8 +516,36 @@ __device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob 
     rq.mpm[0] = j.mpm[0], rq.mpm[1] = j.mpm[1], rq.mpm[2] = j.mpm[2];
     rq.sqrt_lambda = j.sqrt_lambda;
     const IntraParams ip = { p.src[0], j.ref, nullptr, nullptr, p.width, 1 };
-    search<N, 4>(ip, rq, 0, L.ref[wave], L.r.win + wave * 1024, lane, wave, L.best_cost, L.best_mode, &L.best);
+    const int parts = j.parts;
+    search<N, 4>(ip, rq, 0, L.ref[wave], L.r.win + wave * 1024, lane, wave, L.best_cost, L.best_mode, &L.best, part, parts, &L.cost);
     __syncthreads();
+    if (parts > 1) {
+        // the workgroups of the PU leave their candidates in device memory; the one that arrives last picks the winner -
+        // smallest cost, smallest mode among equals, i.e. the first minimum in mode order - and goes on alone
+        IntraPartial *mine = p.partials + job * kIntraParts;
+        if (tid == 0) {
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(&mine[part].cost), __builtin_bit_cast(unsigned long long, L.cost), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mine[part].mode, L.best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            const unsigned before = atomicAdd(p.arrived + job, 1u);
+            L.last = before == (unsigned)parts - 1;
+            if (L.last) {
+                __threadfence();
+                double bc = 1.7976931348623157e308;
+                int bm = 64;
+                for (int g = 0; g < parts; g++) {
+                    const double c = __builtin_bit_cast(double, __hip_atomic_load(reinterpret_cast<unsigned long long *>(&mine[g].cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    const int m = __hip_atomic_load(&mine[g].mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c < bc || (c == bc && m < bm)) bc = c, bm = m;
+                }
+                L.best = bm;
+                __hip_atomic_store(p.arrived + job, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next round
+            }
+        }
+        __syncthreads();
+        if (!L.last) return;
+    }
     const int mode = L.best;
     const uint8_t *ref = ((k_filter_bits[LG - 2] >> mode) & 1) ? L.ref[0] + 136 : L.ref[0];
     int dc;
@@ -532,28 +613,230 @@ __device__ void intra_chroma_pu(const IntraRoundParams &p, IntraLds &L, const In
     if (tid == 0) h->best_idx = L.cres.best_idx;
 }
 
+// DCT matrix of 4x4 blocks (xSubDCT4, src/pixel.cpp:1415)
+__constant__ int8_t k_dct4[4][4] = { { 64, 64, 64, 64 }, { 83, 36, -36, -83 }, { 64, -64, -64, 64 }, { 36, -83, 83, -36 } };
+
+// xSubDctQuantRec of one 4x4 unit on ONE wavefront (lanes 0..15 own a sample / coefficient each, no workgroup barrier), I-slice
+// rounding: the stages of chain_unit<4> with the operands in 16-entry LDS arrays. M: the transform matrix [k][j]; src: the
+// source block (LDS); pred: 16 packed samples (LDS). Returns sum |level| and the SSD of the reconstruction in every lane.
+__device__ __forceinline__ void chain4_wave(const int16_t *M, int16_t *A, int16_t *B, const uint8_t *src, int src_stride, const uint8_t *pred, int qp,
+                                            int16_t *level, uint8_t *rec, int out_stride, uint8_t *rec_copy, int copy_stride, uint32_t &sum, uint32_t &ssd, int lane)
+{
+    const bool on = lane < 16;
+    const int a = (lane >> 2) & 3, b = lane & 3;
+    const int s = src[a * src_stride + b], p = pred[a * 4 + b];
+    if (on) A[a * 4 + b] = (int16_t)(s - p);
+    __builtin_amdgcn_wave_barrier();
+    int v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) v += (int)M[a * 4 + c] * (int)A[b * 4 + c];
+    if (on) B[a * 4 + b] = (int16_t)((v + 1) >> 1);
+    __builtin_amdgcn_wave_barrier();
+    v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) v += (int)M[a * 4 + c] * (int)B[b * 4 + c];
+    const int coef = (int16_t)((v + 128) >> 8);      // vertical frequency a, horizontal frequency b
+    const int qbits = 19 + qp / 6, q = k_quant_scales[qp % 6], qrnd = 171 << (qbits - 9), dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
+    const int mag = (abs(coef) * q + qrnd) >> qbits;
+    const int lv = clip16(coef < 0 ? -mag : mag);
+    __builtin_amdgcn_wave_barrier();
+    if (on) {
+        level[a * out_stride + b] = (int16_t)lv;
+        A[b * 4 + a] = (int16_t)clip16((lv * dscale + 1) >> 1);      // dequantised, transposed
+    }
+    __builtin_amdgcn_wave_barrier();
+    v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) v += (int)M[c * 4 + a] * (int)A[b * 4 + c];
+    if (on) B[a * 4 + b] = (int16_t)clip16((v + 64) >> 7);
+    __builtin_amdgcn_wave_barrier();
+    v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) v += (int)M[c * 4 + a] * (int)B[b * 4 + c];
+    if (on) A[a * 4 + b] = (int16_t)clip16((v + 2048) >> 12);           // column a, row b
+    __builtin_amdgcn_wave_barrier();
+    const int r = min(255, max(0, (int)A[b * 4 + a] + p));                // row a, column b
+    if (on) {
+        rec[a * out_stride + b] = (uint8_t)r;
+        rec_copy[a * copy_stride + b] = (uint8_t)r;
+    }
+    uint32_t m = on ? (uint32_t)mag : 0u, d2 = on ? (uint32_t)((s - r) * (s - r)) : 0u;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m += __shfl_xor(m, o), d2 += __shfl_xor(d2, o);
+    sum = __shfl(m, 0), ssd = __shfl(d2, 0);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// IntraQuadEval on one wavefront: PU k sees the reconstruction and the modes of the PUs before it. The 8x8 source block and
+// everything the four PUs exchange stay in LDS; nothing in the loop waits for memory or for another wavefront.
+__device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQuadJob &j)
+{
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x >= 64) return;
+    if (lane < 33) L.outer[0][lane] = j.ref[lane];
+    if (lane < 16) {
+        reinterpret_cast<uint32_t *>(L.r.pix)[lane] = *reinterpret_cast<const uint32_t *>(p.src[0] + (size_t)(j.y0 + (lane >> 1)) * p.width + j.x0 + (lane & 1) * 4);
+        L.r.mat[0][lane] = k_dst4[lane >> 2][lane & 3];
+    }
+    IntraQuadHead *h = reinterpret_cast<IntraQuadHead *>(p.out + j.out_head);
+    int16_t *level = reinterpret_cast<int16_t *>(p.out + j.out_level);
+    uint8_t *rec = p.out + j.out_rec;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 4; k++) {
+        const int ox = (k & 1) * 4, oy = (k >> 1) * 4;
+        if (lane < 8) L.qref[0][lane] = quad_sample(L.outer[0], L.area[0], oy + 7 - lane, ox - 1);
+        else if (lane < 17) L.qref[0][lane] = quad_sample(L.outer[0], L.area[0], oy - 1, ox - 1 + (lane - 8));
+        __builtin_amdgcn_wave_barrier();
+        const int left = (k & 1) ? L.qmode[k - 1] : j.left_mode[k >> 1], top = (k >> 1) ? L.qmode[k - 2] : j.top_mode[k & 1];
+        xmi_intra_request rq;
+        rq.x0 = ox, rq.y0 = oy, rq.size = 4, rq.valids = j.valids[k], rq.strong_smoothing = j.strong;      // position in the LDS copy of the source
+        if (left == top) {      // most probable modes (src/encode.cpp:3980-4003)
+            if (left > 1) rq.mpm[0] = (uint8_t)left, rq.mpm[1] = (uint8_t)(((left + 29) % 32) + 2), rq.mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+            else rq.mpm[0] = 0, rq.mpm[1] = 1, rq.mpm[2] = 26;
+        } else {
+            rq.mpm[0] = (uint8_t)left, rq.mpm[1] = (uint8_t)top;
+            rq.mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+        }
+        rq.sqrt_lambda = j.sqrt_lambda;
+        const IntraParams ip = { L.r.pix, L.qref[0], nullptr, nullptr, 8, 1 };
+        search<4, 1>(ip, rq, 0, L.ref[0], L.r.win, lane, 0, L.best_cost, L.best_mode, &L.best);
+        __builtin_amdgcn_wave_barrier();
+        const int mode = L.best;
+        int dc;
+        {
+            int s = lane < 8 ? (lane < 4 ? L.ref[0][7 - lane] : L.ref[0][9 + (lane - 4)]) : 0;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
+            dc = (__shfl(s, 0) + 4) >> 3;
+        }
+        if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(L.ref[0], mode, lane / 4, lane % 4, dc, true);
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sum, ssd;
+        chain4_wave(L.r.mat[0], L.r.a, L.r.b, L.r.pix + oy * 8 + ox, 8, L.r.pred, j.qp, level + oy * 8 + ox, rec + oy * 8 + ox, 8, L.area[0] + oy * 8 + ox, 8, sum, ssd, lane);
+        if (lane == 0) {
+            h->best_mode[k] = mode, h->sum[k] = sum, h->ssd[k] = ssd;
+            L.qmode[k] = mode;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// IntraChromaQuadEval on one wavefront
+__device__ void intra_chroma_quad(const IntraRoundParams &p, IntraLds &L, const IntraChromaQuadJob &j)
+{
+    const int lane = threadIdx.x & 63, wc = p.width / 2;
+    if (threadIdx.x >= 64) return;
+    for (int i = lane; i < 66; i += 64) L.outer[i / 33][i % 33] = j.ref[i / 33][i % 33];
+    if (lane < 32) {      // the 8x8 source blocks of U and V
+        const int pl = lane >> 4, i = lane & 15;
+        reinterpret_cast<uint32_t *>(L.r.pix)[lane] = *reinterpret_cast<const uint32_t *>(p.src[1 + pl] + (size_t)(j.y0 + (i >> 1)) * wc + j.x0 + (i & 1) * 4);
+    }
+    if (lane < 16) L.r.mat[0][lane] = k_dct4[lane >> 2][lane & 3];
+    IntraChromaQuadHead *h = reinterpret_cast<IntraChromaQuadHead *>(p.out + j.out_head);
+    uint8_t (*s_ref)[136] = reinterpret_cast<uint8_t (*)[136]>(&L.ref[0][0]);
+    uint8_t (*s_src)[256] = reinterpret_cast<uint8_t (*)[256]>(L.r.win);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < 4; k++) {
+        const int ox = (k & 1) * 4, oy = (k >> 1) * 4;
+        const unsigned valids = j.valids[k];
+        if (lane < 34) {
+            const int pl = lane / 17, i = lane % 17;
+            const uint8_t v = i < 8 ? quad_sample(L.outer[pl], L.area[pl], oy + 7 - i, ox - 1) : quad_sample(L.outer[pl], L.area[pl], oy - 1, ox - 1 + (i - 8));
+            s_ref[pl][i] = valids ? v : (uint8_t)0x80;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valids) {
+            pad_ref<4>(s_ref[0], valids, lane);
+            pad_ref<4>(s_ref[1], valids, lane);
+        }
+        if (lane < 8) {
+            const int pl = lane >> 2, yy = lane & 3;
+            reinterpret_cast<uint32_t *>(s_src[pl])[yy] = *reinterpret_cast<const uint32_t *>(L.r.pix + pl * 64 + (oy + yy) * 8 + ox);
+        }
+        __builtin_amdgcn_wave_barrier();
+        chroma_candidates<4>(j.luma_mode[k], s_ref, s_src, L.satd, lane, L.cres);
+        __builtin_amdgcn_wave_barrier();
+        const int mode = L.cres.best_mode;
+        for (int pl = 0; pl < 2; pl++) {
+            int s = lane < 8 ? (lane < 4 ? s_ref[pl][7 - lane] : s_ref[pl][9 + (lane - 4)]) : 0;
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
+            const int dc = (__shfl(s, 0) + 4) >> 3;
+            if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(s_ref[pl], mode, lane / 4, lane % 4, dc, false);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t sum, ssd;
+            chain4_wave(L.r.mat[0], L.r.a, L.r.b, L.r.pix + pl * 64 + oy * 8 + ox, 8, L.r.pred, j.qpc, reinterpret_cast<int16_t *>(p.out + j.out_level[pl]) + oy * 8 + ox,
+                        p.out + j.out_rec[pl] + oy * 8 + ox, 8, L.area[pl] + oy * 8 + ox, 8, sum, ssd, lane);
+            if (lane == 0) h->sum[pl][k] = sum;
+        }
+        if (lane == 0) h->best_idx[k] = L.cres.best_idx;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// A job record lives in host memory, and every read of it crosses the bus: the workgroup fetches its record once, all lanes
+// at a time, into LDS and works from there.
+template <class Job>
+__device__ __forceinline__ const Job &fetch_job(const Job *src, uint32_t *s_job)
+{
+    static_assert(sizeof(Job) % 4 == 0, "job records are copied as dwords");
+    for (int i = threadIdx.x; i < (int)(sizeof(Job) / 4); i += 256) s_job[i] = reinterpret_cast<const uint32_t *>(src)[i];
+    __syncthreads();
+    return *reinterpret_cast<const Job *>(s_job);
+}
+
+#ifdef XMI_EXP_ROUND_TIMING
+// measurement build: per job type (PU 4/8/16/32, chroma 4/8/16, luma group, chroma group) 100 MHz ticks of the workgroup and count
+__device__ unsigned long long g_intra_ticks[9][2];
+#endif
+
 __global__ void __launch_bounds__(256) intra_round_kernel(const IntraRoundParams p)
 {
     __shared__ IntraLds L;
+#ifdef XMI_EXP_ROUND_TIMING
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    int job_type = -1;
+#define XMI_JOB_TYPE(v) job_type = (v)
+#else
+#define XMI_JOB_TYPE(v)
+#endif
+    __shared__ __align__(16) uint32_t s_job[(sizeof(IntraJob) > sizeof(IntraChromaJob) ? sizeof(IntraJob) : sizeof(IntraChromaJob)) / 4 + 4];
+    static_assert(sizeof(IntraQuadJob) <= sizeof(IntraJob) && sizeof(IntraChromaQuadJob) <= sizeof(IntraChromaJob), "s_job holds every job type");
     const int b = blockIdx.x;
     if (b < p.npu) {
-        const IntraJob &j = p.jobs[b];
+        const IntraGroup g = p.groups[b];
+        const IntraJob &j = fetch_job(p.jobs + g.job, s_job);
+        XMI_JOB_TYPE(j.size == 4 ? 0 : j.size == 8 ? 1 : j.size == 16 ? 2 : 3);
         switch (j.size) {
-        case 4: intra_pu<4>(p, L, j); break;
-        case 8: intra_pu<8>(p, L, j); break;
-        case 16: intra_pu<16>(p, L, j); break;
-        case 32: intra_pu<32>(p, L, j); break;
+        case 4: intra_pu<4>(p, L, j, g.job, g.part); break;
+        case 8: intra_pu<8>(p, L, j, g.job, g.part); break;
+        case 16: intra_pu<16>(p, L, j, g.job, g.part); break;
+        case 32: intra_pu<32>(p, L, j, g.job, g.part); break;
         default: break;
         }
     } else if (b - p.npu < p.nchroma) {
-        const IntraChromaJob &j = p.cjobs[b - p.npu];
+        const IntraChromaJob &j = fetch_job(p.cjobs + (b - p.npu), s_job);
+        XMI_JOB_TYPE(j.size == 4 ? 4 : j.size == 8 ? 5 : 6);
         switch (j.size) {
         case 4: intra_chroma_pu<4>(p, L, j); break;
         case 8: intra_chroma_pu<8>(p, L, j); break;
         case 16: intra_chroma_pu<16>(p, L, j); break;
         default: break;
         }
+    } else if (b - p.npu - p.nchroma < p.nquad) {
+        XMI_JOB_TYPE(7);
+        intra_quad(p, L, fetch_job(p.qjobs + (b - p.npu - p.nchroma), s_job));
+    } else if (b - p.npu - p.nchroma - p.nquad < p.ncquad) {
+        XMI_JOB_TYPE(8);
+        intra_chroma_quad(p, L, fetch_job(p.cqjobs + (b - p.npu - p.nchroma - p.nquad), s_job));
     }
+#ifdef XMI_EXP_ROUND_TIMING
+    __syncthreads();
+    if (threadIdx.x == 0 && job_type >= 0) {
+        atomicAdd(&g_intra_ticks[job_type][0], __builtin_amdgcn_s_memrealtime() - t_begin);
+        atomicAdd(&g_intra_ticks[job_type][1], 1ull);
+    }
+#endif
     round_done(p.counter, p.target, p.flag, p.seq);
 }
 
@@ -570,6 +853,7 @@ public:
     struct LaneRes {
         hipStream_t st = nullptr;
         unsigned *d_counter = nullptr;
+        uint8_t *d_intra = nullptr;                        // per PU job of a round: candidates of its workgroups, arrival counter
         uint8_t *h_jobs = nullptr, *h_out = nullptr;       // pinned, mapped; the kernel reads / writes them in place
         unsigned *h_flag = nullptr;
         uint8_t *g_jobs = nullptr, *g_out = nullptr;       // the same buffers as the GPU addresses them
@@ -583,7 +867,7 @@ public:
     int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0;
     uint8_t *d_src[3] = {}, *d_ref[3] = {}, *d_planes = nullptr;
     LaneRes lane[kMaxLanes];
-    size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0;
+    size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, intra_scratch = 0;
     hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
     // picture-level passes of the encoder (FrameOps): reconstruction before / after the SAO offsets, decision maps, strength
@@ -624,6 +908,7 @@ public:
     {
         for (LaneRes &l : lane) {
             if (l.d_counter) (void)hipFree(l.d_counter), l.d_counter = nullptr;
+            if (l.d_intra) (void)hipFree(l.d_intra), l.d_intra = nullptr;
             if (l.h_jobs) (void)hipHostFree(l.h_jobs), l.h_jobs = nullptr;
             if (l.h_out) (void)hipHostFree(l.h_out), l.h_out = nullptr;
             if (l.h_flag) (void)hipHostFree(l.h_flag), l.h_flag = nullptr;
@@ -738,7 +1023,7 @@ public:
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);
         off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
-        jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, sizeof(IntraChromaJob) * (size_t)lane_rows));
+        jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, (sizeof(IntraChromaJob) + sizeof(IntraQuadJob) + sizeof(IntraChromaQuadJob)) * (size_t)lane_rows));
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
         out_bytes = (size_t)lane_rows * 2 * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
@@ -746,6 +1031,9 @@ public:
         for (int i = 0; i < lanes; i++) {
             LaneRes &l = lane[i];
             XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_counter), 256));
+            intra_scratch = align_up(sizeof(IntraPartial) * kIntraParts * max_cu);
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_intra), intra_scratch + align_up(4 * (size_t)max_cu)));
+            XMI_HIP(hipMemsetAsync(l.d_intra, 0, intra_scratch + align_up(4 * (size_t)max_cu), st));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_jobs), jobs_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_out), out_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_flag), 256, flags));
@@ -788,7 +1076,7 @@ public:
         return bind(src, ref, qp, chroma_qp(qp));
     }
 
-    int evaluate_intra(int ln, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch) override
+    int evaluate_intra(int ln, const IntraBatch &bt) override
     {
         if (ln < 0 || ln >= lanes) return XMI_ERR_ARG;
         thread_local int bound = -1;
@@ -799,7 +1087,7 @@ public:
             }
             bound = device;
         }
-        const int rc = run_intra(lane[ln], pu, npu, ch, nch);
+        const int rc = run_intra(lane[ln], bt);
         if (rc != XMI_OK) snprintf(lane[ln].err, sizeof lane[ln].err, "%s", xmi_last_error());
         return rc;
     }
@@ -852,12 +1140,20 @@ private:
         return XMI_OK;
     }
 
-    int run_intra(LaneRes &R, IntraEval *const *pu, int npu, IntraChromaEval *const *ch, int nch)
+    int run_intra(LaneRes &R, const IntraBatch &bt)
     {
-        XMI_ARG(npu <= max_cu && nch * 128 <= max_chroma, "analysis: %d + %d intra requests exceed the round capacity", npu, nch);
+        IntraEval *const *pu = bt.pu;
+        IntraChromaEval *const *ch = bt.chroma;
+        const int npu = bt.npu, nch = bt.nchroma, nq = bt.nquad, ncq = bt.ncquad, lane_rows = max_cu / 4;
+        XMI_ARG(npu <= max_cu && nch <= lane_rows && nq <= lane_rows && ncq <= lane_rows, "analysis: intra requests (%d, %d, %d, %d) exceed the round capacity", npu, nch, nq,
+                ncq);
         const auto t0 = std::chrono::steady_clock::now();
         IntraJob *jobs = reinterpret_cast<IntraJob *>(R.h_jobs);
+        IntraGroup *groups = reinterpret_cast<IntraGroup *>(R.h_jobs + off_groups);
+        int ngroups_pu = 0;
         IntraChromaJob *cjobs = reinterpret_cast<IntraChromaJob *>(R.h_jobs + off_cjobs);
+        IntraQuadJob *qjobs = reinterpret_cast<IntraQuadJob *>(cjobs + lane_rows);
+        IntraChromaQuadJob *cqjobs = reinterpret_cast<IntraChromaQuadJob *>(qjobs + lane_rows);
         size_t out = 0;
         for (int i = 0; i < npu; i++) {
             const IntraEval &q = *pu[i];
@@ -870,6 +1166,8 @@ private:
             j.valids = q.valids & 0x1f, j.strong = q.strong;
             j.mpm[0] = q.mpm[0], j.mpm[1] = q.mpm[1], j.mpm[2] = q.mpm[2];
             j.qp = q.qp, j.sqrt_lambda = q.sqrt_lambda;
+            j.parts = q.size >= 16 ? kIntraParts : 1;      // the 35-mode search of a large PU is spread over several workgroups
+            for (int g = 0; g < j.parts; g++) groups[ngroups_pu++] = { (uint16_t)i, (uint8_t)g, 0 };
             std::memcpy(j.ref, q.ref, (size_t)(4 * q.size + 1));
             const size_t px = (size_t)q.size * q.size;
             j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraHead));
@@ -891,15 +1189,52 @@ private:
             for (int k = 0; k < 2; k++) j.out_rec[k] = (uint32_t)out, out = align_up(out + px);
             for (int k = 0; k < 2; k++) j.out_level[k] = (uint32_t)out, out = align_up(out + 2 * px);
         }
+        for (int i = 0; i < nq; i++) {
+            const IntraQuadEval &q = *bt.quad[i];
+            IntraQuadJob &j = qjobs[i];
+            XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 8 == 0 && q.y0 % 8 == 0 && q.x0 + 8 <= w && q.y0 + 8 <= h && q.qp >= 0 && q.qp <= 51,
+                    "analysis: intra 4x4 group (%d,%d) outside the picture, or bad parameters", q.x0, q.y0);
+            j.x0 = q.x0, j.y0 = q.y0;
+            for (int k = 0; k < 4; k++) j.valids[k] = q.valids[k] & 0x1f;
+            for (int k = 0; k < 2; k++) {
+                XMI_ARG(q.left_mode[k] < 35 && q.top_mode[k] < 35, "analysis: intra 4x4 group: neighbour mode out of range");
+                j.left_mode[k] = q.left_mode[k], j.top_mode[k] = q.top_mode[k];
+            }
+            j.strong = q.strong, j.qp = q.qp, j.sqrt_lambda = q.sqrt_lambda;
+            std::memcpy(j.ref, q.ref, 33);
+            j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraQuadHead));
+            j.out_rec = (uint32_t)out, out = align_up(out + 64);
+            j.out_level = (uint32_t)out, out = align_up(out + 128);
+        }
+        for (int i = 0; i < ncq; i++) {
+            const IntraChromaQuadEval &c = *bt.cquad[i];
+            IntraChromaQuadJob &j = cqjobs[i];
+            XMI_ARG(c.x0 >= 0 && c.y0 >= 0 && c.x0 % 8 == 0 && c.y0 % 8 == 0 && c.x0 + 8 <= w / 2 && c.y0 + 8 <= h / 2 && c.qpc >= 0 && c.qpc <= 51,
+                    "analysis: intra chroma group (%d,%d) outside the picture, or bad parameters", c.x0, c.y0);
+            j.x0 = c.x0, j.y0 = c.y0, j.qpc = c.qpc;
+            for (int k = 0; k < 4; k++) {
+                XMI_ARG(c.luma_mode[k] < 35, "analysis: intra chroma group: luma mode out of range");
+                j.valids[k] = c.valids[k] & 0x1f, j.luma_mode[k] = c.luma_mode[k];
+            }
+            std::memcpy(j.ref[0], c.ref_u, 33), std::memcpy(j.ref[1], c.ref_v, 33);
+            j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraChromaQuadHead));
+            for (int k = 0; k < 2; k++) j.out_rec[k] = (uint32_t)out, out = align_up(out + 64);
+            for (int k = 0; k < 2; k++) j.out_level[k] = (uint32_t)out, out = align_up(out + 128);
+        }
         XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
         IntraRoundParams p;
         p.jobs = reinterpret_cast<const IntraJob *>(R.g_jobs);
+        p.groups = reinterpret_cast<const IntraGroup *>(R.g_jobs + off_groups);
+        p.partials = reinterpret_cast<IntraPartial *>(R.d_intra);
+        p.arrived = reinterpret_cast<unsigned *>(R.d_intra + intra_scratch);
         p.cjobs = reinterpret_cast<const IntraChromaJob *>(R.g_jobs + off_cjobs);
-        p.npu = npu, p.nchroma = nch;
+        p.qjobs = reinterpret_cast<const IntraQuadJob *>(p.cjobs + lane_rows);
+        p.cqjobs = reinterpret_cast<const IntraChromaQuadJob *>(p.qjobs + lane_rows);
+        p.npu = ngroups_pu, p.nchroma = nch, p.nquad = nq, p.ncquad = ncq;
         for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
         p.width = w;
         p.out = R.g_out;
-        const unsigned ngroups = (unsigned)(npu + nch);
+        const unsigned ngroups = (unsigned)(ngroups_pu + nch + nq + ncq);
         R.issued += ngroups;
         R.seq++;
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = R.seq;
@@ -923,6 +1258,21 @@ private:
             const IntraChromaJob &j = cjobs[i];
             const IntraChromaHead &hd = *reinterpret_cast<const IntraChromaHead *>(R.h_out + j.out_head);
             c.best_idx = hd.best_idx, c.sum_u = hd.sum[0], c.sum_v = hd.sum[1];
+            c.rec_u = R.h_out + j.out_rec[0], c.rec_v = R.h_out + j.out_rec[1];
+            c.level_u = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[0]), c.level_v = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[1]);
+        }
+        for (int i = 0; i < nq; i++) {
+            IntraQuadEval &q = *bt.quad[i];
+            const IntraQuadJob &j = qjobs[i];
+            const IntraQuadHead &hd = *reinterpret_cast<const IntraQuadHead *>(R.h_out + j.out_head);
+            for (int k = 0; k < 4; k++) q.best_mode[k] = hd.best_mode[k], q.sum[k] = hd.sum[k], q.ssd[k] = hd.ssd[k];
+            q.rec = R.h_out + j.out_rec, q.level = reinterpret_cast<const int16_t *>(R.h_out + j.out_level);
+        }
+        for (int i = 0; i < ncq; i++) {
+            IntraChromaQuadEval &c = *bt.cquad[i];
+            const IntraChromaQuadJob &j = cqjobs[i];
+            const IntraChromaQuadHead &hd = *reinterpret_cast<const IntraChromaQuadHead *>(R.h_out + j.out_head);
+            for (int k = 0; k < 4; k++) c.best_idx[k] = hd.best_idx[k], c.sum_u[k] = hd.sum[0][k], c.sum_v[k] = hd.sum[1][k];
             c.rec_u = R.h_out + j.out_rec[0], c.rec_v = R.h_out + j.out_rec[1];
             c.level_u = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[0]), c.level_v = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[1]);
         }
@@ -1109,6 +1459,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 
 #ifdef XMI_EXP_ROUND_TIMING
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
+int xmi_debug_intra_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_intra_ticks), sizeof(unsigned long long) * 18) == hipSuccess ? 0 : -1; }
 int xmi_debug_chain_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ticks), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1; }
 #endif
 

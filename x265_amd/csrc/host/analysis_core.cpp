@@ -217,9 +217,14 @@ struct Row {
     IntraEval in_spec[4];
     bool in_ok[4] = { false, false, false, false };
     IntraChromaEval ichroma;
+    IntraQuadEval quad;             // the four 4x4 PUs under the 8x8 PU of the last chain
+    bool quad_ok = false;
+    uint8_t quad_rec[16];           // the PU of them that is being decided, packed
+    int16_t quad_level[16];
+    IntraChromaQuadEval cquad;
     IntraEval *req_in[4] = {};
     int n_req_in = 0;
-    bool req_ichroma = false;
+    bool req_ichroma = false, req_quad = false, req_cquad = false;
     int strong = 0;
     // The request hand-over takes no lock: the row fills its own slots, raises `pending` and counts itself out of its
     // lane's `running`; the lane's coordinator reads the slots of the rows it finds pending, and lowers `pending` when the
@@ -259,8 +264,9 @@ struct Row {
     void run();
     void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
-    void evaluate_intra(IntraEval *const *list, int n);
-    void evaluate_intra_chroma();
+    void evaluate_intra(IntraEval *const *list, int n, bool with_quad);
+    void evaluate_intra_chroma(bool quad);
+    void fill_quad(int px, int py);
     void post_and_wait();
 };
 
@@ -669,22 +675,48 @@ void Row::evaluate_chroma()
     req_chroma = false;
 }
 
-void Row::evaluate_intra(IntraEval *const *list, int n)
+void Row::evaluate_intra(IntraEval *const *list, int n, bool with_quad)
 {
     for (int i = 0; i < n; i++) req_in[i] = list[i];
     n_req_in = n, n_req_cu = 0;
-    req_chroma = req_ichroma = false;
+    req_chroma = req_ichroma = req_cquad = false;
+    req_quad = with_quad;
     post_and_wait();
     n_req_in = 0;
+    req_quad = false;
 }
 
-void Row::evaluate_intra_chroma()
+void Row::evaluate_intra_chroma(bool quad)
 {
     n_req_in = n_req_cu = 0;
-    req_chroma = false, req_ichroma = true;
+    req_chroma = req_quad = false;
+    req_ichroma = !quad, req_cquad = quad;
     post_and_wait();
-    req_ichroma = false;
+    req_ichroma = req_cquad = false;
 }
+
+// request for the four 4x4 PUs of the 8x8 block at (px, py) of the CTU, nothing of which is decided yet
+void Row::fill_quad(int px, int py)
+{
+    const int r4 = py / 4, c4 = px / 4;
+    IntraQuadEval &q = quad;
+    q.x0 = ctu_x * 64 + px, q.y0 = y * 64 + py;
+    for (int i = 0; i < 16; i++) q.ref[i] = (uint8_t)sample_y(py + 15 - i, px - 1);
+    for (int i = 0; i <= 16; i++) q.ref[16 + i] = (uint8_t)sample_y(py - 1, px - 1 + i);
+    auto ok = [&](int r, int c) { return M(r, c) != kInvalid; };
+    // PU k at (c4 + (k & 1), r4 + (k >> 1)): neighbours inside the block are the PUs before it
+    q.valids[0] = (uint8_t)((ok(r4 + 1, c4 - 1) ? 1 : 0) | (ok(r4, c4 - 1) ? 2 : 0) | (ok(r4 - 1, c4 - 1) ? 4 : 0) | (ok(r4 - 1, c4) ? 8 : 0) | (ok(r4 - 1, c4 + 1) ? 16 : 0));
+    q.valids[1] = (uint8_t)(0 | 2 | (ok(r4 - 1, c4) ? 4 : 0) | (ok(r4 - 1, c4 + 1) ? 8 : 0) | (ok(r4 - 1, c4 + 2) ? 16 : 0));
+    q.valids[2] = (uint8_t)((ok(r4 + 2, c4 - 1) ? 1 : 0) | (ok(r4 + 1, c4 - 1) ? 2 : 0) | (ok(r4, c4 - 1) ? 4 : 0) | 8 | 16);
+    q.valids[3] = (uint8_t)((ok(r4 + 2, c4) ? 1 : 0) | 2 | 4 | 8 | (ok(r4, c4 + 2) ? 16 : 0));
+    q.left_mode[0] = ok(r4, c4 - 1) ? M(r4, c4 - 1) : 1, q.left_mode[1] = ok(r4 + 1, c4 - 1) ? M(r4 + 1, c4 - 1) : 1;
+    q.top_mode[0] = (ok(r4 - 1, c4) && py) ? M(r4 - 1, c4) : 1, q.top_mode[1] = (ok(r4 - 1, c4 + 1) && py) ? M(r4 - 1, c4 + 1) : 1;
+    q.strong = (uint8_t)strong;
+    q.sqrt_lambda = std::sqrt(lambda);
+    q.qp = qp;
+}
+
+inline int interleave4(int v) { return (v & 1) | ((v >> 1) & 2) | ((v >> 2) & 4) | ((v >> 3) & 8); }      // getInterleaveBits (src/encode.cpp:4220)
 
 // request of the PU at (px, py) of the CTU: availability, most probable modes, neighbouring samples (src/encode.cpp:3964-4015)
 void Row::fill_intra(IntraEval &q, int px, int py, int size)
@@ -719,17 +751,38 @@ double Row::decide_intra(int px, int py, int size, int depth)
     int best_mode = 0, pred_idx = 0, valids = 0;
     if (size < 64) {
         IntraEval &q = in_spec[li];
-        if (!(in_ok[li] && q.x0 == ctu_x * 64 + px && q.y0 == y * 64 + py && q.size == size)) {
+        const int gx = ctu_x * 64 + px, gy = y * 64 + py;
+        if (size == 4 && quad_ok && (gx & ~7) == quad.x0 && (gy & ~7) == quad.y0) {
+            // one of the four PUs that were evaluated with their 8x8 block: the request as this PU sees it now must be
+            // the one the evaluator derived, then its results are taken over
+            const int k = ((gy >> 2) & 1) * 2 + ((gx >> 2) & 1);
+            fill_intra(q, px, py, 4);
+            if (q.valids != quad.valids[k]) {      // (cannot happen: both follow the coding order)
+                sh->error = -3;
+                throw Abort();
+            }
+            q.best_mode = quad.best_mode[k], q.ssd = quad.ssd[k], q.sum = quad.sum[k];
+            block_in(quad_rec, 4, quad.rec + (k >> 1) * 32 + (k & 1) * 4, 8, 4, 4);
+            block_in(quad_level, 8, quad.level + (k >> 1) * 32 + (k & 1) * 4, 16, 4, 8);
+            q.rec = quad_rec, q.level = quad_level;
+            if (k == 3) quad_ok = false;
+        } else if (!(in_ok[li] && q.x0 == gx && q.y0 == gy && q.size == size)) {
             IntraEval *list[4];
             int n = 0;
+            bool with_quad = false;
             fill_intra(q, px, py, size);
             list[n++] = &q;
             for (int sz = size / 2, l = li - 1; sh->speculate && sz >= 4; sz /= 2, l--) {
+                if (sz == 4) {      // below the 8x8 PU: all four 4x4 PUs
+                    fill_quad(px, py);
+                    with_quad = quad_ok = true;
+                    break;
+                }
                 fill_intra(in_spec[l], px, py, sz);
                 in_ok[l] = true;
                 list[n++] = &in_spec[l];
             }
-            evaluate_intra(list, n);
+            evaluate_intra(list, n, with_quad);
         }
         in_ok[li] = false;
         best_mode = q.best_mode, valids = q.valids;
@@ -790,42 +843,69 @@ double Row::decide_intra(int px, int py, int size, int depth)
     return best < sub ? best : sub;
 }
 
-// xEncodeChromaCU (src/encode.cpp:4234-4418): the PUs of the decided CTU in coding order
+// xEncodeChromaCU (src/encode.cpp:4234-4418): the PUs of the decided CTU in coding order. Luma PUs of 16x16 and more have one
+// chroma PU each; the chroma of the 8x8 luma blocks of a 16x16 block - four 4x4 chroma PUs - goes out as one request.
 void Row::intra_chroma_pass()
 {
-    auto interleave = [](int v) { return (v & 1) | ((v >> 1) & 2) | ((v >> 2) & 4) | ((v >> 3) & 8); };
-    for (int idx = 0; idx != 256;) {
-        const int dx = interleave(idx), dy = interleave(idx >> 1);
-        int size_y = 1 << (2 + (I1(dy, dx) >> kOffSize));
-        const int size = size_y == 4 ? 4 : size_y >> 1;
+    auto unit_valids = [&](int dy, int dx) {
         int valids = I1(dy, dx) & 0x1f;
-        if (size_y == 4) {      // the chroma block of four 4x4 luma PUs: below-left from the PU below, top-right from the PU to the right
+        if ((I1(dy, dx) >> kOffSize) == 0) {      // the chroma block of four 4x4 luma PUs: below-left from the PU below, top-right from the PU to the right
             valids &= ~0x11;
             valids |= I1(dy + 1, dx) & 0x01;
             valids |= I1(dy, dx + 1) & 0x10;
         }
-        IntraChromaEval &c = ichroma;
-        const int cx = dx * 2, cy = dy * 2;
-        c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy, c.size = size;
-        c.valids = (uint8_t)valids, c.luma_mode = M(dy, dx);
-        c.qpc = chroma_qp(qp);
+        return valids;
+    };
+    auto gather = [&](uint8_t *ru, uint8_t *rv, int cx, int cy, int size) {
         for (int i = 0; i < 2 * size; i++) {
-            c.ref_u[i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy + 2 * size - 1 - i, cx - 1);
-            c.ref_v[i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy + 2 * size - 1 - i, cx - 1);
+            ru[i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy + 2 * size - 1 - i, cx - 1);
+            rv[i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy + 2 * size - 1 - i, cx - 1);
         }
         for (int i = 0; i <= 2 * size; i++) {
-            c.ref_u[2 * size + i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy - 1, cx - 1 + i);
-            c.ref_v[2 * size + i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy - 1, cx - 1 + i);
+            ru[2 * size + i] = (uint8_t)sample_c(top_u, left_u, rec_u, cy - 1, cx - 1 + i);
+            rv[2 * size + i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy - 1, cx - 1 + i);
         }
-        evaluate_intra_chroma();
-        block_in(rec_u + cy * 32 + cx, 32, c.rec_u, size, size, size);
-        block_in(rec_v + cy * 32 + cx, 32, c.rec_v, size, size, size);
-        block_in(coef_u + cy * 32 + cx, 64, c.level_u, size * 2, size, size * 2);
-        block_in(coef_v + cy * 32 + cx, 64, c.level_v, size * 2, size, size * 2);
-        const int cbf_c = (c.sum_v ? 2 : 0) | (c.sum_u ? 1 : 0);
-        I0(dy, dx) |= (uint16_t)((c.best_idx << 13) | (cbf_c << kOffCbfC));
-        if (size_y == 4) size_y = 8;
-        idx += size_y * size_y / 16;
+    };
+    for (int idx = 0; idx != 256;) {
+        const int dx = interleave4(idx), dy = interleave4(idx >> 1);
+        const int size_y = 1 << (2 + (I1(dy, dx) >> kOffSize));
+        const int cx = dx * 2, cy = dy * 2;
+        if (size_y >= 16 || !sh->speculate) {
+            const int size = size_y == 4 ? 4 : size_y >> 1;
+            IntraChromaEval &c = ichroma;
+            c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy, c.size = size;
+            c.valids = (uint8_t)unit_valids(dy, dx), c.luma_mode = M(dy, dx);
+            c.qpc = chroma_qp(qp);
+            gather(c.ref_u, c.ref_v, cx, cy, size);
+            evaluate_intra_chroma(false);
+            block_in(rec_u + cy * 32 + cx, 32, c.rec_u, size, size, size);
+            block_in(rec_v + cy * 32 + cx, 32, c.rec_v, size, size, size);
+            block_in(coef_u + cy * 32 + cx, 64, c.level_u, size * 2, size, size * 2);
+            block_in(coef_v + cy * 32 + cx, 64, c.level_v, size * 2, size, size * 2);
+            const int cbf_c = (c.sum_v ? 2 : 0) | (c.sum_u ? 1 : 0);
+            I0(dy, dx) |= (uint16_t)((c.best_idx << 13) | (cbf_c << kOffCbfC));
+            idx += size_y < 8 ? 4 : size_y * size_y / 16;
+            continue;
+        }
+        // a 16x16 luma block of smaller PUs (idx is a multiple of 16): the 8x8 area of its chroma
+        IntraChromaQuadEval &c = cquad;
+        c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy;
+        c.qpc = chroma_qp(qp);
+        for (int k = 0; k < 4; k++) {
+            const int uy = dy + (k >> 1) * 2, ux = dx + (k & 1) * 2;
+            c.valids[k] = (uint8_t)unit_valids(uy, ux), c.luma_mode[k] = M(uy, ux);
+        }
+        gather(c.ref_u, c.ref_v, cx, cy, 8);
+        evaluate_intra_chroma(true);
+        block_in(rec_u + cy * 32 + cx, 32, c.rec_u, 8, 8, 8);
+        block_in(rec_v + cy * 32 + cx, 32, c.rec_v, 8, 8, 8);
+        block_in(coef_u + cy * 32 + cx, 64, c.level_u, 16, 8, 16);
+        block_in(coef_v + cy * 32 + cx, 64, c.level_v, 16, 8, 16);
+        for (int k = 0; k < 4; k++) {
+            const int cbf_c = (c.sum_v[k] ? 2 : 0) | (c.sum_u[k] ? 1 : 0);
+            I0(dy + (k >> 1) * 2, dx + (k & 1) * 2) |= (uint16_t)((c.best_idx[k] << 13) | (cbf_c << kOffCbfC));
+        }
+        idx += 16;
     }
 }
 
@@ -848,6 +928,7 @@ void Row::run()
             ctu_x = x;
             spec_ok[0] = spec_ok[1] = spec_ok[2] = spec_ok[3] = false;
             in_ok[0] = in_ok[1] = in_ok[2] = in_ok[3] = false;
+            quad_ok = false;
             if (y > 0) {   // top-right neighbour done (or the whole row above)
                 const int need = x + 2 < cols ? x + 2 : cols;
                 std::unique_lock<std::mutex> lk(S.m);
@@ -1041,6 +1122,8 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
         std::vector<ChromaEval *> chroma;
         std::vector<IntraEval *> pu;
         std::vector<IntraChromaEval *> ichroma;
+        std::vector<IntraQuadEval *> quads;
+        std::vector<IntraChromaQuadEval *> cquads;
         std::vector<Row *> served;
         // nothing of the lane is busy on the host, and there is something to do about it
         auto ready = [&] {
@@ -1054,7 +1137,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
             }
             if (ln.finished.load() == ln.rows) break;
             // the rows this call serves: a row that another lane's progress wakes during the call asks for the next one
-            cu.clear(), chroma.clear(), pu.clear(), ichroma.clear(), served.clear();
+            cu.clear(), chroma.clear(), pu.clear(), ichroma.clear(), quads.clear(), cquads.clear(), served.clear();
             for (Row &r : S.rows) {
                 if (r.y % nl != lane || r.in_flight || !r.pending.load(std::memory_order_acquire)) continue;
                 r.in_flight = true;
@@ -1065,12 +1148,18 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                     for (ChromaEval &c : r.chroma_req) chroma.push_back(&c);
                 for (int i = 0; i < r.n_req_in; i++) pu.push_back(r.req_in[i]);
                 if (r.req_ichroma) ichroma.push_back(&r.ichroma);
+                if (r.req_quad) quads.push_back(&r.quad);
+                if (r.req_cquad) cquads.push_back(&r.cquad);
             }
             if (served.empty() && !S.error) continue;      // a row is between counting itself out and raising its flag
             int rc = 0;
             if (!S.error && (!cu.empty() || !chroma.empty())) rc = ev.evaluate(lane, cu.data(), (int)cu.size(), chroma.data(), (int)chroma.size());
-            if (!S.error && !rc && (!pu.empty() || !ichroma.empty()))
-                rc = ev.evaluate_intra(lane, pu.data(), (int)pu.size(), ichroma.data(), (int)ichroma.size());
+            if (!S.error && !rc && (!pu.empty() || !ichroma.empty() || !quads.empty() || !cquads.empty())) {
+                IntraBatch b;
+                b.pu = pu.data(), b.npu = (int)pu.size(), b.chroma = ichroma.data(), b.nchroma = (int)ichroma.size();
+                b.quad = quads.data(), b.nquad = (int)quads.size(), b.cquad = cquads.data(), b.ncquad = (int)cquads.size();
+                rc = ev.evaluate_intra(lane, b);
+            }
             if (rc && !S.error) S.error = rc;
             for (Row *r : served) {
                 ln.running.fetch_add(1, std::memory_order_acq_rel);
@@ -1079,7 +1168,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
             }
             {
                 std::lock_guard<std::mutex> lk(S.m);      // also orders the stores above before the wake-up of a sleeping row
-                out.evaluator_calls++, out.cu_requests += cu.size() + pu.size(), out.chroma_requests += chroma.size() + ichroma.size();
+                out.evaluator_calls++, out.cu_requests += cu.size() + pu.size() + quads.size(), out.chroma_requests += chroma.size() + ichroma.size() + cquads.size();
                 if (S.error) {       // an error ends the picture: rows waiting for a neighbour leave as well
                     for (Row &r : S.rows)
                         if (r.need >= 0) r.need = -1, S.lanes[r.y % nl].running.fetch_add(1);

@@ -93,6 +93,51 @@ struct IntraChromaEval {
     const int16_t *level_u, *level_v;
 };
 
+// The four 4x4 PUs of an 8x8 luma block, evaluated one after the other in coding order, each as an IntraEval of size 4. A 4x4
+// PU is always kept (src/encode.cpp:4133: bReplace at the minimum size), so what a PU sees of the PUs before it - their
+// reconstruction as neighbouring samples, their modes as most probable modes - depends on no cost comparison and the four
+// evaluations can run back to back where the samples are. ref: the 33 neighbouring samples of the 8x8 block (as an 8x8 PU's),
+// which hold every sample the four PUs need from outside the block.
+struct IntraQuadEval {
+    int x0, y0;                       // luma position of the 8x8 block
+    uint8_t ref[36];
+    uint8_t valids[4];                // availability bits of each PU (PUs before it in the block count as available)
+    uint8_t left_mode[2], top_mode[2];   // effective neighbour modes from outside the block (DC substituted as :3977-3978
+                                         // does): left of PU 0 / PU 2, above PU 0 / PU 1
+    uint8_t strong;
+    double sqrt_lambda;
+    int qp;
+    // results; rec and level are the 8x8 block, rows 8 apart
+    int best_mode[4];
+    uint32_t ssd[4], sum[4];
+    const uint8_t *rec;
+    const int16_t *level;
+};
+
+// The chroma of four neighbouring 8x8 luma blocks (an 8x8 area of the chroma planes): four IntraChromaEval of size 4 back
+// to back; nothing in xEncodeChromaCU depends on a cost comparison. ref_*: the 33 neighbouring samples of the area.
+struct IntraChromaQuadEval {
+    int x0, y0;                       // position of the area in the chroma planes
+    uint8_t ref_u[36], ref_v[36];
+    uint8_t valids[4], luma_mode[4];
+    int qpc;
+    int best_idx[4];
+    uint32_t sum_u[4], sum_v[4];
+    const uint8_t *rec_u, *rec_v;     // 8x8 areas, rows 8 apart
+    const int16_t *level_u, *level_v;
+};
+
+struct IntraBatch {
+    IntraEval *const *pu = nullptr;
+    int npu = 0;
+    IntraChromaEval *const *chroma = nullptr;
+    int nchroma = 0;
+    IntraQuadEval *const *quad = nullptr;
+    int nquad = 0;
+    IntraChromaQuadEval *const *cquad = nullptr;
+    int ncquad = 0;
+};
+
 class Evaluator {
 public:
     virtual ~Evaluator() {}
@@ -105,9 +150,9 @@ public:
         return -1;
     }
     // the requests of an I picture; same calling rules as evaluate()
-    virtual int evaluate_intra(int lane, IntraEval *const *pu, int npu, IntraChromaEval *const *chroma, int nchroma)
+    virtual int evaluate_intra(int lane, const IntraBatch &batch)
     {
-        (void)lane, (void)pu, (void)npu, (void)chroma, (void)nchroma;
+        (void)lane, (void)batch;
         return -1;
     }
     // Fills the result fields of every request; returns 0, or an error code that ends the picture. Calls with different

@@ -96,7 +96,7 @@ __device__ __forceinline__ void pad_ref(uint8_t *ref0, unsigned valids, int lane
 // s_best (WPR entries of cost, mode) joins them at the end.
 template <int N, int WPR>
 __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int idx, uint8_t *s_ref, uint8_t *s_src, int lane, int sub,
-                       double *s_best_cost, int *s_best_mode, int *lds_best = nullptr)
+                       double *s_best_cost, int *s_best_mode, int *lds_best = nullptr, int part = 0, int parts = 1, double *lds_cost = nullptr)
 {
     constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     constexpr int L = 4 * N + 1;
@@ -148,7 +148,8 @@ __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int id
     double best_cost = 1.7976931348623157e308;
     int best_mode = 64;
     xmi_intra_result *out = p.res ? p.res + idx : nullptr;      // a caller that only wants the winner (lds_best) passes no result array
-    for (int m0 = sub * MP; m0 < 35; m0 += MP * WPR) {
+    // `parts` workgroups may share the modes of one request (part = this one's index): pass i of all goes to wavefront i % (WPR * parts)
+    for (int m0 = (part * WPR + sub) * MP; m0 < 35; m0 += MP * WPR * parts) {
         const int mode = m0 + lane / T;
         int sum = 0;
         if (mode < 35) {
@@ -227,6 +228,7 @@ __device__ void search(const IntraParams &p, const xmi_intra_request &rq, int id
             out->reserved = 0;
         }
         if (lds_best) *lds_best = best_mode;
+        if (lds_cost) *lds_cost = best_cost;
     }
 }
 
