@@ -28,6 +28,10 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak; measured copy ceiling is ~6
 PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/config.h:52); grown to R+16 for R > 64
 
 
+ENCODE_FRAMES = 64      # the encode legs (this library's encoder, and the reference's on the host cores) use the published
+                        # configuration: 1920x1080, 64 pictures, IPPP, QP 32
+
+
 def measured_traffic(w, h, rng):
     """HBM bytes per launch from the committed PMC passes of this workload (x265_amd/measured_traffic.json), else None.
     Counters cannot be collected from inside this process; tools/profile_round.sh refreshes the file."""
@@ -104,7 +108,7 @@ def cpu_primitives(ref_lib, seconds_per_case=0.25):
     return {r["cpu"]: {"Mblk_per_s": r["Mblk_per_s"], "GBps": r["GBps"], "kind": r["kind"]} for r in rows}
 
 
-def cpu_encoder_fps(frames=6, qp=32):
+def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32):
     """The reference's encoder (its own sources compiled into oracle/_ref/x265_refsse; the 7 NASM-only SATD/SSD entries
     come from the restatement) on a short 1080p IPPP clip, wall clock of the whole run: one thread, and the reference's
     own OpenMP row threads (x265_refsse_mt, -t up to its limit of 16) on the host cores this process may use."""
@@ -198,7 +202,7 @@ def encode_rate(L, qp=32, segments=True):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import bench_encoder
-        out = bench_encoder.run(1920, 1080, 6, qp)
+        out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
         if segments:
             out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8)
         return out
@@ -357,6 +361,19 @@ def main():
         dist.all_gather_object(devs, f"cuda:{local}" + ("" if backend == "nccl" else " (shared, gloo rehearsal)"))
     else:
         devs = [f"cuda:{local}"]
+    # encode leg of a multi-GPU run: every rank encodes its own GOP segments with the library's encoder at the same time
+    # (8 concurrent segments per GPU, as in the single-GPU encode block); rank 0 reports the sum. No exchange inside.
+    enc_ranks = None
+    if world > 1 and not args.headline_only and not args.no_analysis:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_encoder
+        dist.barrier()
+        try:
+            mine = bench_encoder.run_segments(1920, 1080, 4, 32, 8)
+        except Exception as e:      # noqa: BLE001
+            mine = {"error": repr(e)}
+        enc_ranks = [None] * world
+        dist.all_gather_object(enc_ranks, mine)
     if world > 1:              # all collectives are done: leave the group together, before rank 0's CPU-side legs
         dist.barrier()
         dist.destroy_process_group()
@@ -395,6 +412,11 @@ def main():
             if not args.no_analysis:
                 out["analysis"] = analysis_rate(L, segments=not args.no_segments)
                 out["encode"] = encode_rate(L, segments=not args.no_segments)
+                if enc_ranks:
+                    good = [r for r in enc_ranks if r and "error" not in r]
+                    out["encode"]["all_ranks_8_segments"] = {"p_pictures_per_s": round(sum(r["p_pictures_per_s"] for r in good), 2),
+                                                             "encode_fps": round(sum(r["encode_fps"] for r in good), 2), "ranks": len(good),
+                                                             "per_rank_p_pictures_per_s": [r.get("p_pictures_per_s") if r else None for r in enc_ranks]}
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)

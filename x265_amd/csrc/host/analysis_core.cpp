@@ -283,7 +283,9 @@ struct Lane {
 
 struct Shared {
     std::mutex m;
-    std::condition_variable cv_rows;
+    std::condition_variable cv_rows;    // rows whose polling time ran out sleep here until their answers are in place
+    std::condition_variable cv_need;    // rows that wait for the row above sleep here
+    std::atomic<int> sleepers{ 0 };     // rows asleep on cv_rows: a round that finds none wakes nobody (no system call)
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
     bool speculate = true;          // a CU's request carries those of its chain of first children
@@ -652,7 +654,9 @@ void Row::post_and_wait()
     }
     if (!poll_until(sh->spin_us, [&] { return !pending.load(std::memory_order_acquire); })) {
         std::unique_lock<std::mutex> lk(sh->m);
+        sh->sleepers.fetch_add(1, std::memory_order_relaxed);
         sh->cv_rows.wait(lk, [&] { return !pending.load(std::memory_order_acquire); });
+        sh->sleepers.fetch_sub(1, std::memory_order_relaxed);
     }
     t_resume = std::chrono::steady_clock::now();
     if (sh->error) throw Abort();
@@ -937,7 +941,7 @@ void Row::run()
                     Lane &ln = S.lanes[y % S.lanes.size()];
                     if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
                     const auto t0 = std::chrono::steady_clock::now();
-                    S.cv_rows.wait(lk, [&] { return this->need < 0; });
+                    S.cv_need.wait(lk, [&] { return this->need < 0; });
                     t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
                     if (S.error) throw Abort();
                 }
@@ -1028,7 +1032,7 @@ void Row::run()
                     if (below.need >= 0 && S.done[y] >= below.need) {
                         below.need = -1;
                         S.lanes[(y + 1) % S.lanes.size()].running++;
-                        S.cv_rows.notify_all();
+                        S.cv_need.notify_all();
                     }
                 }
             }
@@ -1173,9 +1177,10 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                     for (Row &r : S.rows)
                         if (r.need >= 0) r.need = -1, S.lanes[r.y % nl].running.fetch_add(1);
                     for (Lane &o : S.lanes) o.cv_main.notify_one();
+                    S.cv_need.notify_all();
                 }
             }
-            S.cv_rows.notify_all();
+            if (S.sleepers.load(std::memory_order_relaxed) > 0 || S.error) S.cv_rows.notify_all();
         }
     };
     for (int l = 1; l < nl; l++) threads.emplace_back(coordinate, l);
