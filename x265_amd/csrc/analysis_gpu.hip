@@ -232,40 +232,50 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     const uint8_t *src = p.src[0] + (size_t)j.y0 * p.width + j.x0;
     // merge candidates: both workgroups of the job come to the same selection. The candidates do not depend on each other:
     // their loads go out together and one reduction serves all of them.
-    uint32_t acc[5] = { 0, 0, 0, 0, 0 };
     const uint8_t *cand[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) cand[k] = (k < j.n_merge && j.merge_ok[k]) ? plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]) : nullptr;
-    for (int i = tid * 4; i < N * N; i += 1024) {
-        const int y = i / N, x = i - y * N;
-        const uint32_t a = *reinterpret_cast<const uint32_t *>(src + (size_t)y * p.width + x);
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            if (!cand[k]) continue;
-            // four samples of the candidate from the two aligned dwords that hold them; SSD = a.a + b.b - 2 a.b on bytes
-            const uint8_t *bp = cand[k] + (size_t)y * p.stride + x;
-            const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(bp) & 3);
-            const uint32_t *bw = reinterpret_cast<const uint32_t *>(bp - sh);
-            const uint32_t b = __builtin_amdgcn_alignbyte(bw[1], bw[0], sh);
-            acc[k] += __builtin_amdgcn_udot4(a, a, 0u, false) + __builtin_amdgcn_udot4(b, b, 0u, false) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
-        }
-    }
+    int n_ok = 0, n_zero = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        cand[k] = (k < j.n_merge && j.merge_ok[k]) ? plane_block(p, j.x0, j.y0, j.merge_mv[k][0], j.merge_mv[k][1]) : nullptr;
+        if (cand[k]) n_ok++, n_zero += j.merge_mv[k][0] == 0 && j.merge_mv[k][1] == 0;
     }
-    __syncthreads();
-    if ((tid & 63) == 0)
-#pragma unroll
-        for (int k = 0; k < 5; k++) L.red5[tid >> 6][k] = acc[k];
-    __syncthreads();
+    // The search path needs the selection for one bit only: whether the winner is the zero vector (bZeroMV, src/encode.cpp:3341).
+    // Usable candidates are distinct, so without a zero vector among them the bit is 0, and with the zero vector as the only
+    // one it is 1: no distortion has to be measured for that.
+    const bool known = path == 1 && (n_zero == 0 || n_ok == 1);
     uint32_t best_ssd = 0xffffffffu;
     int best = -1;
+    if (!known) {
+        uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+        for (int i = tid * 4; i < N * N; i += 1024) {
+            const int y = i / N, x = i - y * N;
+            const uint32_t a = *reinterpret_cast<const uint32_t *>(src + (size_t)y * p.width + x);
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const uint32_t ssd = L.red5[0][k] + L.red5[1][k] + L.red5[2][k] + L.red5[3][k];
-        if (cand[k] && ssd < best_ssd) best_ssd = ssd, best = k;      // the first smallest (src/encode.cpp:3281)
+            for (int k = 0; k < 5; k++) {
+                if (!cand[k]) continue;
+                // four samples of the candidate from the two aligned dwords that hold them; SSD = a.a + b.b - 2 a.b on bytes
+                const uint8_t *bp = cand[k] + (size_t)y * p.stride + x;
+                const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(bp) & 3);
+                const uint32_t *bw = reinterpret_cast<const uint32_t *>(bp - sh);
+                const uint32_t b = __builtin_amdgcn_alignbyte(bw[1], bw[0], sh);
+                acc[k] += __builtin_amdgcn_udot4(a, a, 0u, false) + __builtin_amdgcn_udot4(b, b, 0u, false) - 2u * __builtin_amdgcn_udot4(a, b, 0u, false);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 5; k++) L.red5[tid >> 6][k] = acc[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t ssd = L.red5[0][k] + L.red5[1][k] + L.red5[2][k] + L.red5[3][k];
+            if (cand[k] && ssd < best_ssd) best_ssd = ssd, best = k;      // the first smallest (src/encode.cpp:3281)
+        }
     }
     LumaHead *head = reinterpret_cast<LumaHead *>(p.out + j.out_head);
     XMI_STAMP(t_merge);
@@ -278,7 +288,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         xmi_me_request rq;
         rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N;
         rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
-        rq.zero_mv_tested = best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0;
+        rq.zero_mv_tested = known ? n_zero != 0 : (best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0);
         rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
         rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
         rq.sqrt_lambda = j.sqrt_lambda;
