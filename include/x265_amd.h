@@ -406,6 +406,12 @@ typedef struct xmi_analysis xmi_analysis;
 xmi_analysis *xmi_analysis_create(int width, int height);
 void xmi_analysis_destroy(xmi_analysis *a);
 int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us);
+/* How far a CU's request to the GPU reaches ahead (no counterpart in the reference; results do not depend on it). 0: one
+ * request per CU. 1: a CU's request takes its first child, that child's first child, ... along (same corner, same
+ * neighbours). 2 (default): it takes every CU that may still be decided in the CTU, under the guess that all of them end up
+ * with the vector of the asking CU's first merge candidate; a CU whose real neighbours are the guessed ones finds its answer
+ * waiting. Fewer round trips where motion is coherent, more pixel work. */
+int xmi_analysis_speculate(xmi_analysis *a, int level);
 /* Measurement aid (no counterpart in the reference): where the round trips of this handle have spent their time so far,
  * summed over its lanes: out = { ns writing job tables, ns in the launch call, ns waiting for the GPU, ns reading results
  * back, round trips, and for the last picture: ns the CTU-row threads spent on decision work between their requests,
@@ -442,6 +448,7 @@ typedef struct xmi_encoder xmi_encoder;
 xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_smoothing);
 void xmi_encoder_destroy(xmi_encoder *e);
 int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us);
+int xmi_encoder_speculate(xmi_encoder *e, int level);      /* xmi_analysis_speculate for the encoder's analysis loop */
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
                            size_t capacity);
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);

@@ -368,6 +368,13 @@ int orc_analysis_configure(void *h, int lanes, int spin_us)
     static_cast<Handle *>(h)->an.spin_us = spin_us;
     return 0;
 }
+// how far a CU's request reaches ahead (Analyser::speculate): 0 none, 1 first children, 2 the rest of the CTU
+int orc_analysis_speculate(void *h, int level)
+{
+    if (level < 0 || level > 2) return -1;
+    static_cast<Handle *>(h)->an.speculate = level;
+    return 0;
+}
 void orc_analysis_destroy(void *h) { delete static_cast<Handle *>(h); }
 
 // set != 0: load the carried state; else read it back. Arrays: rows * cols * 5 (sum, count, avg), rows (frac).
@@ -420,6 +427,12 @@ int orc_encoder_configure(void *h, int lanes, int spin_us)
 {
     static_cast<EncHandle *>(h)->enc.analyser().lanes = lanes;
     static_cast<EncHandle *>(h)->enc.analyser().spin_us = spin_us;
+    return 0;
+}
+int orc_encoder_speculate(void *h, int level)
+{
+    if (level < 0 || level > 2) return -1;
+    static_cast<EncHandle *>(h)->enc.analyser().speculate = level;
     return 0;
 }
 // one picture: packed source planes at coded size, slice_type 1 = P / 2 = I; returns the access unit's size

@@ -98,7 +98,7 @@ def p(a):
 class Runner:
     """create / state / p_picture of either library, same argument lists (prefix orc_analysis_ or xmi_analysis_)."""
 
-    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0):
+    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0, speculate=None):
         self.lib, self.w, self.h = lib, w, h
         self.create, self.destroy = getattr(lib, prefix + "create"), getattr(lib, prefix + "destroy")
         self.state, self.picture = getattr(lib, prefix + "state"), getattr(lib, prefix + "p_picture")
@@ -116,6 +116,13 @@ class Runner:
             conf.argtypes = [C.c_void_p, C.c_int, C.c_int]
             rc = conf(self.handle, lanes or 1, spin_us)
             assert rc == 0, f"configure({lanes}, {spin_us}) returned {rc}"
+        # How far a request reaches ahead is a switch of the CPU harness only (the library always runs at 2). On the CPU every
+        # request costs its full pixel work, so the harness runs at 1 unless a test asks for more.
+        if prefix.startswith("orc_") or speculate is not None:
+            spec = getattr(lib, prefix + "speculate")
+            spec.restype = C.c_int
+            spec.argtypes = [C.c_void_p, C.c_int]
+            assert spec(self.handle, 1 if speculate is None else speculate) == 0
 
     def close(self):
         self.destroy(self.handle)

@@ -115,6 +115,18 @@ def test_row_lanes_and_polling_do_not_change_the_result(lib, lanes, spin, tag):
     check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin), tag)
 
 
+@pytest.mark.parametrize("level,lanes,tag", [(0, 1, "416x240_q32_p2"), (2, 1, "416x240_q32_p1"), (2, 2, "416x240_q22_p1")])
+def test_speculation_depth_does_not_change_the_result(lib, level, lanes, tag):
+    """one request per CU; requests that take the rest of the CTU along under a guessed vector (answers are used only where
+    the guess came true): same picture, fewer or more calls"""
+    out = check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, 0, speculate=level), tag)
+    base = check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, 0, speculate=1), tag)
+    if level == 2:
+        assert out["counters"][0] < base["counters"][0], "tree speculation saved no call"
+    else:
+        assert out["counters"][0] > base["counters"][0]
+
+
 def test_hand_over_survives_many_pictures_and_settings(lib):
     """The rows hand their requests to the coordinators without a lock; the same picture again and again, with lane counts
     and polling times drawn at random (3 us: waiters usually run out of polling time and go to sleep in mid hand-over)."""

@@ -66,14 +66,14 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
             "what": f"{segments} GOP segments of {width}x{height} analysed concurrently on one GPU, aggregate P pictures per second"}
 
 
-def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=200, lib=None):
+def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=200, lib=None, speculate=None):
     from x265_amd import capi
     from tests import ctu_trace as T
     L = lib or capi.load()
     capi.check(L.xmi_init(0))
     w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     frames = [synth(w, h, t, seed) for t in range(pictures + 1)]
-    r = T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us)
+    r = T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us, speculate=speculate)
     times, rounds, cus = [], [], []
     try:
         for t in range(1, pictures + 1):
@@ -126,8 +126,9 @@ if __name__ == "__main__":
     ap.add_argument("--segments", type=int, default=1)
     ap.add_argument("--lanes", type=int, default=None)
     ap.add_argument("--spin-us", type=int, default=None)
+    ap.add_argument("--speculate", type=int, default=None)
     a = ap.parse_args()
     if a.segments > 1:
         print(json.dumps(run_segments(a.width, a.height, a.qp, a.pictures, a.segments, a.lanes, a.spin_us or 0)))
     else:
-        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes, spin_us=200 if a.spin_us is None else a.spin_us)))
+        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes, spin_us=200 if a.spin_us is None else a.spin_us, speculate=a.speculate)))

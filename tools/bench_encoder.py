@@ -19,13 +19,13 @@ def clip(w, h, n, seed=None):
     return [frame(w, h, t, rng) for t in range(n)]
 
 
-def run(w=1920, h=1080, n=6, qp=32, lanes=1, spin_us=200, verbose=False):
+def run(w=1920, h=1080, n=6, qp=32, lanes=1, spin_us=200, verbose=False, speculate=None):
     """one picture stream: the clip of the CPU baseline (tools/gen_yuv.py, seed 7 at 1080p), picture 0 intra; wall clock of the
     encode calls (pictures resident in host memory; the call uploads them)"""
     import hashlib
     from x265_amd.encoder import Encoder
     pics = clip(w, h, n)
-    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us)
+    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us, speculate=speculate)
     try:
         warm = Encoder(w, h, qp)        # first call of a process: code objects, buffers - on an instance of its own, so that the
         warm.encode(*pics[0], True)     # timed instance starts from a new encoder's state, as the reference's run does
@@ -101,7 +101,8 @@ def main():
     a = sys.argv[1:]
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
     lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (1, 200)
-    print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True)))
+    spec = int(a[6]) if len(a) >= 7 else None
+    print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True, speculate=spec)))
     from x265_amd import capi
     L = capi.load()
     if hasattr(L, "xmi_debug_intra_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING): workgroup time per job type

@@ -874,7 +874,7 @@ public:
         uint64_t t_prepare = 0, t_launch = 0, t_wait = 0, t_collect = 0, rounds = 0;
         char err[256] = "";
     };
-    int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0;
+    int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0, lane_rows = 0;
     uint8_t *d_src[3] = {}, *d_ref[3] = {}, *d_planes = nullptr;
     LaneRes lane[kMaxLanes];
     size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, intra_scratch = 0;
@@ -1028,15 +1028,18 @@ public:
         XMI_ARG(nlanes >= 1 && nlanes <= kMaxLanes, "analysis: %d lanes (1..%d)", nlanes, kMaxLanes);
         release_lanes();
         lanes = nlanes;
-        const int lane_rows = (h / 64 + lanes - 1) / lanes;
-        max_cu = 4 * lane_rows;               // per CTU row and round a CU and its chain of first children (64, 32, 16, 8)
+        lane_rows = (h / 64 + lanes - 1) / lanes;
+        max_cu = 85 * lane_rows;              // per CTU row and round at most every CU of a CTU: 64 + 16 + 4 + 1
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);
         off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
         jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, (sizeof(IntraChromaJob) + sizeof(IntraQuadJob) + sizeof(IntraChromaQuadJob)) * (size_t)lane_rows));
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
-        out_bytes = (size_t)lane_rows * 2 * (align_up(sizeof(LumaHead)) + 3 * 4096 + 2 * 8192) + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
+        size_t cu_bytes = 0;
+        for (int n = 8, count = 64; n <= 64; n *= 2, count /= 4)
+            cu_bytes += (size_t)count * (align_up(sizeof(LumaHead)) + 3 * align_up((size_t)n * n) + 2 * align_up(2 * (size_t)n * n));
+        out_bytes = (size_t)lane_rows * cu_bytes + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
         const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
         for (int i = 0; i < lanes; i++) {
             LaneRes &l = lane[i];
@@ -1048,7 +1051,11 @@ public:
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_out), out_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_flag), 256, flags));
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_jobs), l.h_jobs, 0));
+#ifdef XMI_EXP_DEV_OUT
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.g_out), out_bytes));
+#else
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_out), l.h_out, 0));
+#endif
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_flag), l.h_flag, 0));
             std::memset(l.h_out, 0, out_bytes);
             *l.h_flag = 0;
@@ -1154,7 +1161,7 @@ private:
     {
         IntraEval *const *pu = bt.pu;
         IntraChromaEval *const *ch = bt.chroma;
-        const int npu = bt.npu, nch = bt.nchroma, nq = bt.nquad, ncq = bt.ncquad, lane_rows = max_cu / 4;
+        const int npu = bt.npu, nch = bt.nchroma, nq = bt.nquad, ncq = bt.ncquad;
         XMI_ARG(npu <= max_cu && nch <= lane_rows && nq <= lane_rows && ncq <= lane_rows, "analysis: intra requests (%d, %d, %d, %d) exceed the round capacity", npu, nch, nq,
                 ncq);
         const auto t0 = std::chrono::steady_clock::now();
@@ -1382,11 +1389,19 @@ private:
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
         const auto t1 = std::chrono::steady_clock::now();
+#ifdef XMI_EXP_LDS_PAD
+        hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), XMI_EXP_LDS_PAD, R.st, p);
+#else
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
+#endif
         XMI_HIP(hipGetLastError());
         const auto t2 = std::chrono::steady_clock::now();
         const int wrc = wait_round(R, seq);
         if (wrc != XMI_OK) return wrc;
+#ifdef XMI_EXP_DEV_OUT
+        XMI_HIP(hipMemcpyAsync(h_out, R.g_out, out, hipMemcpyDeviceToHost, R.st));
+        XMI_HIP(hipStreamSynchronize(R.st));
+#endif
         const auto t3 = std::chrono::steady_clock::now();
 
         for (int i = 0; i < ncu; i++) {
@@ -1452,6 +1467,14 @@ xmi_analysis *xmi_analysis_create(int width, int height)
 }
 
 void xmi_analysis_destroy(xmi_analysis *a) { delete a; }
+
+int xmi_analysis_speculate(xmi_analysis *a, int level)
+{
+    XMI_ARG(a, "xmi_analysis_speculate: null handle");
+    XMI_ARG(level >= 0 && level <= 2, "xmi_analysis_speculate: level %d (0..2)", level);
+    a->an.speculate = level;
+    return XMI_OK;
+}
 
 int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 {
@@ -1575,6 +1598,14 @@ int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us)
     }
     if (rc == XMI_OK) e->enc.analyser().spin_us = spin_us;
     return rc;
+}
+
+int xmi_encoder_speculate(xmi_encoder *e, int level)
+{
+    XMI_ARG(e, "xmi_encoder_speculate: null handle");
+    XMI_ARG(level >= 0 && level <= 2, "xmi_encoder_speculate: level %d (0..2)", level);
+    e->enc.analyser().speculate = level;
+    return XMI_OK;
 }
 
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out, size_t capacity)

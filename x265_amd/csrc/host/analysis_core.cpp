@@ -203,13 +203,35 @@ struct Row {
     // Requests per CU size 8 / 16 / 32 / 64. A CU's request takes the requests of its first child, that child's first child
     // and so on along: they sit at the same corner, so their neighbours are the CU's own and nothing the CU decides
     // changes what they ask for. A child that finds its answer waiting (spec_ok) saves the round trip.
-    CuEval cu_spec[4];
-    bool spec_ok[4] = { false, false, false, false };
+    // With tree speculation the request also takes every CU that may still be decided in this CTU - the rest of the CU's
+    // own quadtree and of its parents' - asked for as if every CU decided from here on ended up with one guessed vector
+    // (the first merge candidate of the CU that has to ask): their neighbours are then known. Whoever later finds that its
+    // real neighbours are the guessed ones (same_request) has its answer waiting; where motion is coherent a CTU takes one
+    // round trip. Answers live until the row's next call.
+    CuEval tree[85];            // 64 CUs of 8x8, 16 of 16x16, 4 of 32x32, the 64x64 CU
+    bool tree_ok[85] = {};
+    std::vector<CuEval *> spec_list;
+    static int node(int li, int px, int py)
+    {
+        static const int first[4] = { 0, 64, 80, 84 };
+        const int log2 = li + 3;
+        return first[li] + (py >> log2) * (64 >> log2) + (px >> log2);
+    }
+    void fill_request(CuEval &r, const Mv *cnd, int nm, int px, int py, int sz);
+    void spec_node(int px, int py, int size);
+    void spec_subtree(int px, int py, int size, Mv g, int floor);
+    void mark_decided(int px, int py, int size, Mv g);
+    bool guessed = false;       // the row's last call carried requests made under a guess ...
+    int guess_hits = 0;         // ... and so many of them have been of use since
+    int barren = 0;             // calls in a row whose guess helped nobody
+    int asked_px = -1, asked_py = -1;
     // host time of the row between two requests (nanoseconds) and the number of requests: what a round trip waits for
     // besides the evaluator
     uint64_t busy_ns = 0, requests = 0;
     std::chrono::steady_clock::time_point t_resume = std::chrono::steady_clock::now();
     std::vector<ChromaEval> chroma_req;
+    std::vector<int> chroma_list;      // the CUs chroma_req stands for: px | py << 8 | size << 16
+    int chroma_waiting = -1;           // CTU whose chroma requests travel with the next CTU's first luma request, or -1
     // I pictures: the unfiltered reconstruction next to the CTU - the row above from x0 - 1 to x0 + 127 and the column to the
     // left (the reference's aucTopPix line buffers and the left column of its CTU cache) -, the requests per PU size
     // 4 / 8 / 16 / 32 (a PU's request carries those of its chain of first children, as for inter CUs) and the chroma request
@@ -231,7 +253,7 @@ struct Row {
     // answers are in place. Only a waiter whose polling time has run out takes the mutex, to sleep.
     std::atomic<bool> pending{ false };
     bool in_flight = false;     // (coordinator only) ... that is part of the call its lane is making right now
-    CuEval *req_cu[4] = {};
+    CuEval *req_cu[85] = {};
     int n_req_cu = 0;
     bool req_chroma = false;     // ... that is part of the call its lane is making right now
     int need = -1;
@@ -243,7 +265,9 @@ struct Row {
 
     int fill_candidates(Mv out[7], int r4, int c4, int r8, int c8, int size);
     uint32_t decide(int px, int py, int size, int depth);
-    void chroma_pass();
+    void chroma_prepare();
+    void chroma_apply(int xp);
+    void ctu_done(int xp);
     int sample_y(int yy, int xx) const
     {
         if (yy < 0) return top_y[xx + 1];
@@ -288,7 +312,8 @@ struct Shared {
     std::atomic<int> sleepers{ 0 };     // rows asleep on cv_rows: a round that finds none wakes nobody (no system call)
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
-    bool speculate = true;          // a CU's request carries those of its chain of first children
+    int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
+    bool defer_chroma = true;       // a CTU's chroma requests travel with the next CTU's first luma request
     std::deque<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row
     std::deque<Row> rows;
@@ -342,6 +367,58 @@ void block_in(void *dst, int dst_pitch, const void *src, int src_pitch, int rows
     for (int i = 0; i < rows; i++) std::memcpy((char *)dst + (size_t)i * dst_pitch, (const char *)src + (size_t)i * src_pitch, bytes);
 }
 
+void Row::fill_request(CuEval &r, const Mv *cnd, int nm, int px, int py, int sz)
+{
+    const int qmin_x = 4 * (min_ipel.x - 4), qmin_y = 4 * (min_ipel.y - 4), qmax_x = 4 * (max_ipel.x - 4), qmax_y = 4 * (max_ipel.y - 4);
+    r.x0 = ctu_x * 64 + px, r.y0 = y * 64 + py, r.size = sz;
+    r.n_merge = nm;
+    for (int k = 0; k < nm; k++) {
+        r.merge_mv[k] = cnd[2 + k];
+        r.merge_ok[k] = cnd[2 + k].x >= qmin_x && cnd[2 + k].x <= qmax_x && cnd[2 + k].y >= qmin_y && cnd[2 + k].y <= qmax_y;
+        // a vector that an earlier usable candidate already has cannot win (the first smallest is taken): not evaluated
+        for (int e = 0; e < k && r.merge_ok[k]; e++)
+            if (r.merge_ok[e] && cnd[2 + e].x == cnd[2 + k].x && cnd[2 + e].y == cnd[2 + k].y) r.merge_ok[k] = 0;
+    }
+    r.amvp[0] = cnd[0], r.amvp[1] = cnd[1];
+    r.mv_min_ipel = min_ipel, r.mv_max_ipel = max_ipel;
+    r.lambda = lambda, r.qp = qp;
+}
+
+// the request of the CU at (px, py) as the caches stand
+void Row::spec_node(int px, int py, int size)
+{
+    Mv c[7];
+    const int nm = fill_candidates(c, py / 4, px / 4, py / 8, px / 8, size);
+    const int idx = node(ilog2(size) - 3, px, py);
+    fill_request(tree[idx], c, nm, px, py, size);
+    tree_ok[idx] = true;
+    spec_list.push_back(&tree[idx]);
+}
+
+// requests for the CUs below the one at (px, py) down to size `floor`, in coding order, each seeing the CUs before it decided
+// with vector g; afterwards the CU's own area stands in the caches as decided with g
+void Row::spec_subtree(int px, int py, int size, Mv g, int floor)
+{
+    if (size / 2 >= floor && size > 8) {
+        const int half = size / 2;
+        for (int part = 0; part < 4; part++) {
+            const int cx = px + (part & 1) * half, cy = py + (part >> 1) * half;
+            spec_node(cx, cy, half);
+            spec_subtree(cx, cy, half, g, floor);
+        }
+        return;      // the four children have covered the area
+    }
+    mark_decided(px, py, size, g);
+}
+
+void Row::mark_decided(int px, int py, int size, Mv g)
+{
+    for (int i = 0; i < size / 4; i++)
+        for (int j = 0; j < size / 4; j++) M(py / 4 + i, px / 4 + j) = kValid;
+    for (int i = 0; i < size / 8; i++)
+        for (int j = 0; j < size / 8; j++) V(py / 8 + i, px / 8 + j) = g;
+}
+
 // xEncDecideCU_Inter (src/encode.cpp:3080-3639), FAST_MD build: returns the RD cost as the reference's callers see it,
 // truncated to 32 bits by the function's declared return type.
 uint32_t Row::decide(int px, int py, int size, int depth)
@@ -352,47 +429,70 @@ uint32_t Row::decide(int px, int py, int size, int depth)
     Mv cand[7];
     const int nmerge = fill_candidates(cand, r4, c4, r8, c8, size);
     const Mv *mg = cand + 2;
-    const int qmin_x = 4 * (min_ipel.x - 4), qmin_y = 4 * (min_ipel.y - 4), qmax_x = 4 * (max_ipel.x - 4), qmax_y = 4 * (max_ipel.y - 4);
-    const bool skip_left = (I1(r4, c4 - 1) & kMaskSkip) && M(r4 + b4 - 1, c4 - 1) != kInvalid;
-    const bool skip_above = (I1(r4 - 1, c4) & kMaskSkip) && M(r4 - 1, c4 + b4 - 1) != kInvalid;
-    const int ctx_skip = kCtxSkip + (skip_left ? 1 : 0) + (skip_above ? 1 : 0);
 
-    CuEval &q = cu_spec[li];
-    auto fill = [&](CuEval &r, const Mv *cnd, int nm, int sz) {
-        r.x0 = ctu_x * 64 + px, r.y0 = y * 64 + py, r.size = sz;
-        r.n_merge = nm;
-        for (int k = 0; k < nm; k++) {
-            r.merge_mv[k] = cnd[2 + k];
-            r.merge_ok[k] = cnd[2 + k].x >= qmin_x && cnd[2 + k].x <= qmax_x && cnd[2 + k].y >= qmin_y && cnd[2 + k].y <= qmax_y;
-            // a vector that an earlier usable candidate already has cannot win (the first smallest is taken): not evaluated
-            for (int e = 0; e < k && r.merge_ok[k]; e++)
-                if (r.merge_ok[e] && cnd[2 + e].x == cnd[2 + k].x && cnd[2 + e].y == cnd[2 + k].y) r.merge_ok[k] = 0;
-        }
-        r.amvp[0] = cnd[0], r.amvp[1] = cnd[1];
-        r.mv_min_ipel = min_ipel, r.mv_max_ipel = max_ipel;
-        r.lambda = lambda, r.qp = qp;
-    };
+    const int idx = node(li, px, py);
+    CuEval &q = tree[idx];
     auto same_request = [&](const CuEval &r) {      // was the waiting answer asked for with what this CU sees now?
         if (r.x0 != ctu_x * 64 + px || r.y0 != y * 64 + py || r.size != size || r.n_merge != nmerge) return false;
         for (int k = 0; k < nmerge; k++)
             if (r.merge_mv[k].x != mg[k].x || r.merge_mv[k].y != mg[k].y) return false;
         return r.amvp[0].x == cand[0].x && r.amvp[0].y == cand[0].y && r.amvp[1].x == cand[1].x && r.amvp[1].y == cand[1].y;
     };
-    if (!(spec_ok[li] && same_request(q))) {
-        CuEval *list[4];
-        int n = 0;
-        fill(q, cand, nmerge, size);
-        list[n++] = &q;
-        for (int sz = size / 2, l = li - 1; sh->speculate && sz >= 8; sz /= 2, l--) {
-            Mv c2[7];
-            const int nm2 = fill_candidates(c2, r4, c4, r8, c8, sz);
-            fill(cu_spec[l], c2, nm2, sz);
-            spec_ok[l] = true;
-            list[n++] = &cu_spec[l];
+    if (!(tree_ok[idx] && same_request(q))) {
+        std::memset(tree_ok, 0, sizeof tree_ok);      // a new call: the answers of the last one are gone
+        spec_list.clear();
+        fill_request(q, cand, nmerge, px, py, size);
+        spec_list.push_back(&q);
+        if (sh->speculate == 1) {
+            for (int sz = size / 2; sz >= 8; sz /= 2) spec_node(px, py, sz);      // same corner: the CU's own neighbours
+        } else if (sh->speculate >= 2) {
+            uint8_t keep_mode[sizeof mode];
+            Mv keep_mv[sizeof mv / sizeof mv[0]];
+            std::memcpy(keep_mode, mode, sizeof mode), std::memcpy(keep_mv, mv, sizeof mv);
+            const Mv g = nmerge ? mg[0] : cand[0];
+            // A call whose guess helped nobody is followed by a modest one: the CU's chain of first children and the later
+            // children of its parent with theirs. Where a guess comes true again, the next call takes the rest of the CTU.
+            if (guessed) barren = guess_hits > 0 ? 0 : barren + 1;
+            const bool wide = barren < 2 || size == 64;
+            // Most CTUs are decided at 64x64 .. 16x16: 8x8 CUs are asked for ahead of time only next to a CU of 16x16 or
+            // 8x8 that has to ask itself
+            const int near_floor = size <= 16 ? 8 : 16;
+            if (wide) {
+                spec_subtree(px, py, size, g, near_floor);
+            } else {
+                for (int sz = size / 2; sz >= 8; sz /= 2) spec_node(px, py, sz);
+                mark_decided(px, py, size, g);
+            }
+            for (int cx = px, cy = py, sz = size; sz < 64; sz *= 2) {      // the later children of every parent
+                const int ox = cx & ~(2 * sz - 1), oy = cy & ~(2 * sz - 1);
+                const int floor = sz <= 16 && size <= 16 ? 8 : 16;
+                for (int part = ((cy - oy) / sz) * 2 + (cx - ox) / sz + 1; part < 4; part++) {
+                    const int nx = ox + (part & 1) * sz, ny = oy + (part >> 1) * sz;
+                    spec_node(nx, ny, sz);
+                    if (wide) {
+                        spec_subtree(nx, ny, sz, g, floor);
+                    } else {
+                        for (int s2 = sz / 2; s2 >= 8; s2 /= 2) spec_node(nx, ny, s2);
+                        mark_decided(nx, ny, sz, g);
+                    }
+                }
+                if (!wide) break;
+                cx = ox, cy = oy;
+            }
+            std::memcpy(mode, keep_mode, sizeof mode), std::memcpy(mv, keep_mv, sizeof mv);
+            guessed = spec_list.size() > 1;
+            guess_hits = 0;
+            asked_px = px, asked_py = py;
         }
-        evaluate_cus(list, n);
+        evaluate_cus(spec_list.data(), (int)spec_list.size());
+    } else if (px != asked_px || py != asked_py) {
+        guess_hits++;      // not one of the asking CU's first children, whose neighbours were never in question
     }
-    spec_ok[li] = false;
+    tree_ok[idx] = false;
+    // read after the evaluation: the call may have brought the chroma of the CTU to the left, which sets its skip flags
+    const bool skip_left = (I1(r4, c4 - 1) & kMaskSkip) && M(r4 + b4 - 1, c4 - 1) != kInvalid;
+    const bool skip_above = (I1(r4 - 1, c4) & kMaskSkip) && M(r4 - 1, c4 + b4 - 1) != kInvalid;
+    const int ctx_skip = kCtxSkip + (skip_left ? 1 : 0) + (skip_above ? 1 : 0);
 
     double best = kDoubleMax;
     int merge_idx = 0, skip = 0;
@@ -471,8 +571,6 @@ uint32_t Row::decide(int px, int py, int size, int depth)
     }
 
     bool replace = size == 8 || skip;
-    if (skip)
-        for (int l = 0; l < li; l++) spec_ok[l] = false;      // no children: their answers are dropped
     if (size > 8 && !skip) {
         Analyser &an = *sh->an;
         const int cols = sh->cols;
@@ -494,7 +592,6 @@ uint32_t Row::decide(int px, int py, int size, int depth)
             if (best < avg && avg > 0) {
                 replace = true;
                 descend = false;
-                for (int l = 0; l < li; l++) spec_ok[l] = false;
             }
         }
         if (descend) {
@@ -566,60 +663,83 @@ void Row::collect_cus(int px, int py, int size, std::vector<int> &list)
     for (int part = 0; part < 4; part++) collect_cus(px + (part & 1) * half, py + (part >> 1) * half, half, list);
 }
 
-// xEncInterCTU (src/encode.cpp:3641-3791)
-void Row::chroma_pass()
+// xEncInterCTU (src/encode.cpp:3641-3791) in two halves. Nothing the luma decisions of the next CTU ask the evaluator for depends
+// on this CTU's chroma (what depends on it - the skip flags of the left neighbours - is read when the answers are back), so
+// the chroma requests of a CTU travel with the first luma request of the CTU to its right instead of in a round trip of
+// their own; the CTU counts as done, for the row below, once they are applied.
+void Row::chroma_prepare()
 {
-    std::vector<int> list;
-    collect_cus(0, 0, 64, list);
-    chroma_req.resize(list.size());
-    for (size_t i = 0; i < list.size(); i++) {
-        const int px = list[i] & 255, py = (list[i] >> 8) & 255, size = list[i] >> 16;
+    chroma_list.clear();
+    collect_cus(0, 0, 64, chroma_list);
+    chroma_req.resize(chroma_list.size());
+    for (size_t i = 0; i < chroma_list.size(); i++) {
+        const int px = chroma_list[i] & 255, py = (chroma_list[i] >> 8) & 255, size = chroma_list[i] >> 16;
         ChromaEval &c = chroma_req[i];
         c.x0 = ctu_x * 64 + px, c.y0 = y * 64 + py, c.size = size;
         c.mv = V(py / 8, px / 8);
         c.skip = I1(py / 4, px / 4) & 1 & (I0(0, 0) >> 7);
         c.qpc = chroma_qp(qp);
     }
-    evaluate_chroma();
-    for (size_t n = 0; n < list.size(); n++) {
-        const int px = list[n] & 255, py = (list[n] >> 8) & 255, size = list[n] >> 16, r4 = py / 4, c4 = px / 4, b4 = size / 4, sc = size / 2;
+}
+
+// the answers of chroma_prepare()'s requests go into the picture-level arrays of CTU xp, whose luma part is there already
+void Row::chroma_apply(int xp)
+{
+    PictureResult &out = *sh->out;
+    const int w4 = sh->w / 4, wc = sh->w / 2;
+    auto G0 = [&](int r, int c) -> uint16_t & { return out.info0[(size_t)(y * 16 + r) * w4 + xp * 16 + c]; };
+    auto G1 = [&](int r, int c) -> uint8_t & { return out.info1[(size_t)(y * 16 + r) * w4 + xp * 16 + c]; };
+    uint8_t *const gu = &out.rec_u[(size_t)(y * 32) * wc + xp * 32], *const gv = &out.rec_v[(size_t)(y * 32) * wc + xp * 32];
+    int16_t *const cu = &out.coef_u[(size_t)(y * 32) * wc + xp * 32], *const cv = &out.coef_v[(size_t)(y * 32) * wc + xp * 32];
+    for (size_t n = 0; n < chroma_list.size(); n++) {
+        const int px = chroma_list[n] & 255, py = (chroma_list[n] >> 8) & 255, size = chroma_list[n] >> 16, r4 = py / 4, c4 = px / 4, b4 = size / 4, sc = size / 2;
         const ChromaEval &c = chroma_req[n];
-        block_in(rec_u + (py / 2) * 32 + px / 2, 32, c.rec_u, sc, sc, sc);
-        block_in(rec_v + (py / 2) * 32 + px / 2, 32, c.rec_v, sc, sc, sc);
-        if (c.skip) {
-            for (int i = 0; i < sc; i++) {
-                std::memset(coef_u + (py / 2 + i) * 32 + px / 2, 0, (size_t)sc * 2);
-                std::memset(coef_v + (py / 2 + i) * 32 + px / 2, 0, (size_t)sc * 2);
-            }
-            continue;
-        }
-        block_in(coef_u + (py / 2) * 32 + px / 2, 64, c.level_u, sc * 2, sc, sc * 2);
-        block_in(coef_v + (py / 2) * 32 + px / 2, 64, c.level_v, sc * 2, sc, sc * 2);
-        const int merge_idx = I0(r4, c4) & 0x3f;
+        block_in(gu + (size_t)(py / 2) * wc + px / 2, wc, c.rec_u, sc, sc, sc);
+        block_in(gv + (size_t)(py / 2) * wc + px / 2, wc, c.rec_v, sc, sc, sc);
+        if (c.skip) continue;                      // the levels stay zero
+        block_in(cu + (size_t)(py / 2) * wc + px / 2, wc * 2, c.level_u, sc * 2, sc, sc * 2);
+        block_in(cv + (size_t)(py / 2) * wc + px / 2, wc * 2, c.level_v, sc * 2, sc, sc * 2);
+        const int merge_idx = G0(r4, c4) & 0x3f;
         if (size == 64) {
             int any = 0;
             for (int j = 0; j < 2; j++)
                 for (int i = 0; i < 2; i++) {
                     const int cbf_c = (c.sum_v[j * 2 + i] ? 2 : 0) | (c.sum_u[j * 2 + i] ? 1 : 0);
-                    const int cbf_y = (I1(r4 + j * 8, c4 + i * 8) >> kOffCbfY) & 1;
+                    const int cbf_y = (G1(r4 + j * 8, c4 + i * 8) >> kOffCbfY) & 1;
                     any |= cbf_y | cbf_c;
-                    const uint16_t first = I0(r4 + j * 8, c4 + i * 8);
+                    const uint16_t first = G0(r4 + j * 8, c4 + i * 8);
                     for (int ii = 0; ii < 8; ii++)
-                        for (int jj = 0; jj < 8; jj++) I0(r4 + j * 8 + ii, c4 + i * 8 + jj) = (uint16_t)(first | (cbf_c << kOffCbfC));
+                        for (int jj = 0; jj < 8; jj++) G0(r4 + j * 8 + ii, c4 + i * 8 + jj) = (uint16_t)(first | (cbf_c << kOffCbfC));
                 }
             if (merge_idx && any == 0)
                 for (int ii = 0; ii < 16; ii++)
-                    for (int jj = 0; jj < 16; jj++) I1(r4 + ii, c4 + jj) |= kMaskSkip;
+                    for (int jj = 0; jj < 16; jj++) G1(r4 + ii, c4 + jj) |= kMaskSkip;
         } else {
-            const int cbf_c = (c.sum_v[0] ? 2 : 0) | (c.sum_u[0] ? 1 : 0), cbf_y = (I1(r4, c4) >> kOffCbfY) & 1;
+            const int cbf_c = (c.sum_v[0] ? 2 : 0) | (c.sum_u[0] ? 1 : 0), cbf_y = (G1(r4, c4) >> kOffCbfY) & 1;
             const bool skipped = merge_idx && (cbf_y | cbf_c) == 0;
-            const uint16_t first0 = I0(r4, c4);
-            const uint8_t first1 = I1(r4, c4);
+            const uint16_t first0 = G0(r4, c4);
+            const uint8_t first1 = G1(r4, c4);
             for (int ii = 0; ii < b4; ii++)
                 for (int jj = 0; jj < b4; jj++) {
-                    I0(r4 + ii, c4 + jj) = (uint16_t)(first0 | kFlagInter | (cbf_c << kOffCbfC));
-                    I1(r4 + ii, c4 + jj) = (uint8_t)(first1 | (skipped ? kMaskSkip : 0));
+                    G0(r4 + ii, c4 + jj) = (uint16_t)(first0 | kFlagInter | (cbf_c << kOffCbfC));
+                    G1(r4 + ii, c4 + jj) = (uint8_t)(first1 | (skipped ? kMaskSkip : 0));
                 }
+        }
+    }
+}
+
+// CTU xp of this row is complete: the row below may go on
+void Row::ctu_done(int xp)
+{
+    Shared &S = *sh;
+    std::lock_guard<std::mutex> lk(S.m);
+    S.done[y] = xp + 1;
+    if (y + 1 < S.nrows) {
+        Row &below = S.rows[y + 1];
+        if (below.need >= 0 && S.done[y] >= below.need) {
+            below.need = -1;
+            S.lanes[(y + 1) % S.lanes.size()].running++;
+            S.cv_need.notify_all();
         }
     }
 }
@@ -666,9 +786,20 @@ void Row::evaluate_cus(CuEval *const *list, int n)
 {
     for (int i = 0; i < n; i++) req_cu[i] = list[i];
     n_req_cu = n;
-    req_chroma = false;
+    req_chroma = chroma_waiting >= 0;
     post_and_wait();
     n_req_cu = 0;
+    if (req_chroma) {
+        req_chroma = false;
+        const int xp = chroma_waiting;
+        chroma_waiting = -1;
+        chroma_apply(xp);
+        ctu_done(xp);
+        // the left neighbours of the CTU being decided are CTU xp's last column
+        const PictureResult &out = *sh->out;
+        const int w4 = sh->w / 4;
+        for (int r = 0; r < 16; r++) I1(r, -1) = out.info1[(size_t)(y * 16 + r) * w4 + ctu_x * 16 - 1];
+    }
 }
 
 void Row::evaluate_chroma()
@@ -930,7 +1061,7 @@ void Row::run()
     try {
         for (int x = 0; x < cols; x++) {
             ctu_x = x;
-            spec_ok[0] = spec_ok[1] = spec_ok[2] = spec_ok[3] = false;
+            std::memset(tree_ok, 0, sizeof tree_ok);
             in_ok[0] = in_ok[1] = in_ok[2] = in_ok[3] = false;
             quad_ok = false;
             if (y > 0) {   // top-right neighbour done (or the whole row above)
@@ -1002,7 +1133,7 @@ void Row::run()
                 intra_chroma_pass();
             } else {
                 out.rd_cost[(size_t)y * cols + x] = decide(0, 0, 64, 0);
-                chroma_pass();
+                chroma_prepare();
             }
 
             last = cab[0];
@@ -1019,22 +1150,22 @@ void Row::run()
             }
             block_in(&out.rec_y[(size_t)(y * 64) * S.w + x * 64], S.w, rec_y, 64, 64, 64);
             block_in(&out.coef_y[(size_t)(y * 64) * S.w + x * 64], S.w * 2, coef_y, 128, 64, 128);
-            block_in(&out.rec_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_u, 32, 32, 32);
-            block_in(&out.rec_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_v, 32, 32, 32);
-            block_in(&out.coef_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_u, 64, 32, 64);
-            block_in(&out.coef_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_v, 64, 32, 64);
-            {
+            if (x == 1 && y != S.nrows - 1) {
                 std::lock_guard<std::mutex> lk(S.m);
-                if (x == 1 && y != S.nrows - 1) S.saved[y] = cab[0];
-                S.done[y] = x + 1;
-                if (y + 1 < S.nrows) {
-                    Row &below = S.rows[y + 1];
-                    if (below.need >= 0 && S.done[y] >= below.need) {
-                        below.need = -1;
-                        S.lanes[(y + 1) % S.lanes.size()].running++;
-                        S.cv_need.notify_all();
-                    }
-                }
+                S.saved[y] = cab[0];
+            }
+            if (S.intra) {
+                block_in(&out.rec_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_u, 32, 32, 32);
+                block_in(&out.rec_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_v, 32, 32, 32);
+                block_in(&out.coef_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_u, 64, 32, 64);
+                block_in(&out.coef_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_v, 64, 32, 64);
+                ctu_done(x);
+            } else if (x + 1 < cols && S.defer_chroma) {
+                chroma_waiting = x;                 // with the next CTU's first request
+            } else {
+                evaluate_chroma();
+                chroma_apply(x);
+                ctu_done(x);
             }
         }
     } catch (const Abort &) {
@@ -1109,6 +1240,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     S.rows = std::deque<Row>(rows_);
     S.spin_us = spin_us;
     S.speculate = speculate;
+    S.defer_chroma = speculate != 0;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
     S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {

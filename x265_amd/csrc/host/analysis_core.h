@@ -201,9 +201,12 @@ public:
     // block: a round trip is shorter than the time a sleeping thread needs to come back. 0 = block at once (the choice when
     // many analysers share the host's cores).
     int spin_us = 0;
-    // A CU's request also asks for its first child, that child's first child, ... (same corner, same neighbours): fewer
-    // round trips, more pixel work, some of it for CUs the decision never descends to. Results do not depend on it.
-    bool speculate = true;
+    // 1: a CU's request also asks for its first child, that child's first child, ... (same corner, same neighbours). 2: it asks
+    // for every CU that may still be decided in the CTU, under the guess that all of them end up with the vector of the
+    // asking CU's first merge candidate; a CU whose neighbours turn out as guessed finds its answer waiting. Fewer round
+    // trips, more pixel work, some of it for CUs the decision never comes to. 0: one request per CU. Results do not
+    // depend on it.
+    int speculate = 2;
 
     // One P picture: decisions and reconstruction of every CTU, rows advancing as a wavefront (a CTU starts when its
     // left neighbour and the CTU above and to the right are done). The evaluator is bound to the picture pair (source,

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
 
 #include "bitstream.h"
 
@@ -567,6 +568,16 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     }
     const auto t3 = clock::now();
 
+    // The picture hash of the final reconstruction (src/encode.cpp:6012-6053) follows the slice in the access unit and does not
+    // depend on it: MD5 runs at about 0.8 GB/s and cannot be split within a plane, so luma and the two chroma planes are
+    // hashed on two threads while this one writes the slice.
+    uint8_t digest[3][16];
+    std::thread hash_y([&] { bitstream::md5_plane(rec_[0].data(), (size_t)w_, (size_t)w_, (size_t)h_, digest[0]); });
+    std::thread hash_c([&] {
+        bitstream::md5_plane(rec_[1].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[1]);
+        bitstream::md5_plane(rec_[2].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[2]);
+    });
+
     // ---- slice header, then the slice data: one substream per CTU row (xCompressCU, src/encode.cpp:5594-5750) ----
     bitstream::write_slice_header(bs, slice_type, poc_, sao_on_[0], sao_on_[1], qp_);
     sub_.resize(ny * 3 + 4096);
@@ -633,11 +644,15 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     cabac.flush();      // the reference flushes the coder a second time, into the access unit (src/encode.cpp:5749)
     bs.trailing_bits();
 
-    // ---- picture hash SEI (src/encode.cpp:6012-6053) ----
-    uint8_t digest[3][16];
-    bitstream::md5_plane(rec_[0].data(), (size_t)w_, (size_t)w_, (size_t)h_, digest[0]);
-    bitstream::md5_plane(rec_[1].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[1]);
-    bitstream::md5_plane(rec_[2].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[2]);
+    // ---- the reconstruction becomes the reference of the next picture ----
+    for (int c = 0; c < 3; c++) {
+        const int pw = c ? wc : w_, ph = c ? hc : h_, pad = c ? kPadC : kPad, stride = pw + 2 * pad;
+        for (int i = 0; i < ph; i++) std::memcpy(&ref_[c][(size_t)(pad + i) * stride + pad], &rec_[c][(size_t)i * pw], (size_t)pw);
+    }
+    have_ref_ = true;
+
+    // ---- picture hash SEI ----
+    hash_y.join(), hash_c.join();
     bs.flush();
     start_code(0x50);
     bs.put(0x01, 8), bs.put(0x84, 8), bs.put(0x31, 8), bs.put(0x00, 8);
@@ -645,13 +660,6 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
         for (int j = 0; j < 16; j++) bs.put(digest[c][j], 8);
     bs.trailing_bits();
     bs.flush();
-
-    // ---- the reconstruction becomes the reference of the next picture ----
-    for (int c = 0; c < 3; c++) {
-        const int pw = c ? wc : w_, ph = c ? hc : h_, pad = c ? kPadC : kPad, stride = pw + 2 * pad;
-        for (int i = 0; i < ph; i++) std::memcpy(&ref_[c][(size_t)(pad + i) * stride + pad], &rec_[c][(size_t)i * pw], (size_t)pw);
-    }
-    have_ref_ = true;
     int len = bs.flush();
     if (out[len - 1] == 0) out[len++] = 0x03;
     const auto t4 = clock::now();
