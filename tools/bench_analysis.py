@@ -96,6 +96,11 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=
                     if cnt:
                         print(f"{n}x{n} {name}: {cnt} workgroups, us each: merge selection {m / cnt / 100:.2f}, search {sr / cnt / 100:.2f}, "
                               f"chain {ch / cnt / 100:.2f}", file=sys.stderr)
+        if hasattr(L, "xmi_debug_clock_ticks"):
+            ct = (C.c_uint64 * 2)()
+            L.xmi_debug_clock_ticks(ct)
+            if ct[1]:
+                print(f"shader clock inside the round kernel: {ct[0] / ct[1] * 100:.0f} MHz (s_memtime ticks per 100 MHz tick)", file=sys.stderr)
         if hasattr(L, "xmi_debug_chain_ticks"):
             ck = (C.c_uint64 * 24)()
             L.xmi_debug_chain_ticks(ck)

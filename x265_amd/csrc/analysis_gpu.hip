@@ -54,11 +54,6 @@ struct LumaHead {                 // per transform unit: a 64x64 CU has four, ea
     int16_t mv[2];
     uint32_t ssd_me[4], sum_me[4];
 };
-struct LumaGroup {                // what one workgroup of the luma part does
-    uint16_t job;
-    uint8_t path;                 // 0 = merge candidate, 1 = motion search
-    uint8_t unit;
-};
 struct ChromaJob {
     int32_t plane;                // 0 = U, 1 = V
     int32_t x, y, n;              // unit in plane samples: 4, 8 or 16 square
@@ -70,9 +65,9 @@ struct ChromaJob {
 
 struct RoundParams {
     const LumaJob *jobs;
-    const LumaGroup *groups;
     const ChromaJob *cjobs;
     int nluma, nchroma;           // workgroups of the luma part, chroma jobs
+    int n64;                      // 64x64 CUs, which are the first jobs of the table
     const uint8_t *src[3];        // source planes, rows width / width/2 apart
     const uint8_t *planes;        // 16 quarter-pel luma planes of the padded reference
     const uint8_t *ref_c[2];      // sample (0,0) of the padded chroma reference planes
@@ -245,7 +240,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     const bool known = path == 1 && (n_zero == 0 || n_ok == 1);
     uint32_t best_ssd = 0xffffffffu;
     int best = -1;
-    if (!known) {
+    auto select = [&] {
         uint32_t acc[5] = { 0, 0, 0, 0, 0 };
         for (int i = tid * 4; i < N * N; i += 1024) {
             const int y = i / N, x = i - y * N;
@@ -276,7 +271,11 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
             const uint32_t ssd = L.red5[0][k] + L.red5[1][k] + L.red5[2][k] + L.red5[3][k];
             if (cand[k] && ssd < best_ssd) best_ssd = ssd, best = k;      // the first smallest (src/encode.cpp:3281)
         }
-    }
+    };
+    // A search on the whole workgroup (32x32, 64x64) asks for the bit only when its first stage shows that it matters, and
+    // the selection is made then.
+    constexpr bool kLazy = N >= 32;
+    if (!known && !(kLazy && path == 1)) select();
     LumaHead *head = reinterpret_cast<LumaHead *>(p.out + j.out_head);
     XMI_STAMP(t_merge);
     int mvx, mvy;
@@ -288,13 +287,21 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         xmi_me_request rq;
         rq.x0 = j.x0, rq.y0 = j.y0, rq.size = N;
         rq.mvp[0][0] = j.amvp[0][0], rq.mvp[0][1] = j.amvp[0][1], rq.mvp[1][0] = j.amvp[1][0], rq.mvp[1][1] = j.amvp[1][1];
-        rq.zero_mv_tested = known ? n_zero != 0 : (best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0);
+        auto zero_won = [&] { return best >= 0 && j.merge_mv[best][0] == 0 && j.merge_mv[best][1] == 0; };
+        rq.zero_mv_tested = known ? n_zero != 0 : zero_won();
         rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
         rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
         rq.sqrt_lambda = j.sqrt_lambda;
         MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
-        if constexpr (N >= 32) {
-            search<N, false, false, 4>(mp, rq, 0, tid, L.win, L.red36);      // the whole workgroup shares the block
+        if constexpr (kLazy) {      // the whole workgroup shares the block
+            if (known) {
+                search<N, false, false, 4>(mp, rq, 0, tid, L.win, L.red36);
+            } else {
+                search<N, false, false, 4>(mp, rq, 0, tid, L.win, L.red36, [&] {
+                    select();
+                    return zero_won();
+                });
+            }
         } else {
             if (tid < 64) search<N, false>(mp, rq, 0, tid, L.win);
         }
@@ -390,19 +397,33 @@ __device__ __forceinline__ void round_done(unsigned *counter, unsigned target, u
     }
 }
 
-__global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p)
+// A round of a picture with coherent motion brings several hundred workgroups; registers are held to 128 so that four of
+// them fit on a CU (the compiler needs no spill for it).
+#ifndef XMI_ROUND_WAVES
+#define XMI_ROUND_WAVES 4
+#endif
+#ifdef XMI_EXP_ROUND_TIMING
+__device__ unsigned long long g_clock_ticks[2];      // shader clock ticks and 100 MHz ticks, summed over workgroups
+#endif
+__global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(const RoundParams p)
 {
     __shared__ RoundLds L;
     __shared__ uint8_t s_cpred[16 * 16];
     const int b = blockIdx.x;
+#ifdef XMI_EXP_ROUND_TIMING
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (b < p.nluma) {
-        const LumaGroup g = p.groups[b];
-        const LumaJob j = p.jobs[g.job];
+        // The job table lies in host memory, a read of it is a trip over the bus: which job a workgroup serves follows from its
+        // index alone - the 64x64 CUs come first, eight workgroups each (two candidates x four transform units), then two per CU
+        const int rest = b - 8 * p.n64;
+        const int job = rest < 0 ? b >> 3 : p.n64 + (rest >> 1), path = rest < 0 ? (b >> 2) & 1 : rest & 1, unit = rest < 0 ? b & 3 : 0;
+        const LumaJob j = p.jobs[job];
         switch (j.size) {
-        case 8: luma_job<8>(p, L, j, g.path, 0); break;
-        case 16: luma_job<16>(p, L, j, g.path, 0); break;
-        case 32: luma_job<32>(p, L, j, g.path, 0); break;
-        case 64: luma_job<64>(p, L, j, g.path, g.unit & 3); break;
+        case 8: luma_job<8>(p, L, j, path, 0); break;
+        case 16: luma_job<16>(p, L, j, path, 0); break;
+        case 32: luma_job<32>(p, L, j, path, 0); break;
+        case 64: luma_job<64>(p, L, j, path, unit); break;
         default: break;
         }
     } else if (b - p.nluma < p.nchroma) {
@@ -414,6 +435,12 @@ __global__ void __launch_bounds__(256) analysis_round_kernel(const RoundParams p
         default: break;
         }
     }
+#ifdef XMI_EXP_ROUND_TIMING
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_clock_ticks[0], __builtin_amdgcn_s_memtime() - c0);
+        atomicAdd(&g_clock_ticks[1], __builtin_amdgcn_s_memrealtime() - r0);
+    }
+#endif
     round_done(p.counter, p.target, p.flag, p.seq);
 }
 
@@ -870,6 +897,7 @@ public:
         unsigned *g_flag = nullptr;
         unsigned issued = 0, seq = 0;
         std::vector<ChromaPlace> place;
+        std::vector<int> order;
         // where a round trip's time goes, nanoseconds (xmi_analysis_counters): table set-up, launch call, wait, result read-back
         uint64_t t_prepare = 0, t_launch = 0, t_wait = 0, t_collect = 0, rounds = 0;
         char err[256] = "";
@@ -1032,7 +1060,7 @@ public:
         max_cu = 85 * lane_rows;              // per CTU row and round at most every CU of a CTU: 64 + 16 + 4 + 1
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);
-        off_cjobs = off_groups + align_up(sizeof(LumaGroup) * max_cu * 8);
+        off_cjobs = off_groups + align_up(sizeof(IntraGroup) * max_cu * 8);
         jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, (sizeof(IntraChromaJob) + sizeof(IntraQuadJob) + sizeof(IntraChromaQuadJob)) * (size_t)lane_rows));
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
@@ -1306,12 +1334,17 @@ private:
         uint8_t *const h_jobs = R.h_jobs, *const h_out = R.h_out;
         std::vector<ChromaPlace> &place = R.place;
         LumaJob *jobs = reinterpret_cast<LumaJob *>(h_jobs);
-        LumaGroup *groups = reinterpret_cast<LumaGroup *>(h_jobs + off_groups);
         ChromaJob *cjobs = reinterpret_cast<ChromaJob *>(h_jobs + off_cjobs);
         size_t out = 0;
-        int nluma = 0;
+        int nluma = 0, n64 = 0;
+        std::vector<int> &order = R.order;      // job k serves request order[k]: the 64x64 CUs first
+        order.resize(ncu);
+        for (int i = 0; i < ncu; i++)
+            if (cu[i]->size == 64) order[n64++] = i;
+        for (int i = 0, k = n64; i < ncu; i++)
+            if (cu[i]->size != 64) order[k++] = i;
         for (int i = 0; i < ncu; i++) {
-            const CuEval &q = *cu[i];
+            const CuEval &q = *cu[order[i]];
             LumaJob &j = jobs[i];
             XMI_ARG(q.size == 8 || q.size == 16 || q.size == 32 || q.size == 64, "analysis: CU size %d", q.size);
             XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 8 == 0 && q.y0 % 8 == 0 && q.x0 + q.size <= w && q.y0 + q.size <= h && q.n_merge >= 0 && q.n_merge <= 5,
@@ -1340,8 +1373,7 @@ private:
             j.out_rec_me = (uint32_t)out, out = align_up(out + px);
             j.out_level_merge = (uint32_t)out, out = align_up(out + 2 * px);
             j.out_level_me = (uint32_t)out, out = align_up(out + 2 * px);
-            for (int path = 0; path < 2; path++)
-                for (int u = 0; u < (q.size == 64 ? 4 : 1); u++) groups[nluma++] = { (uint16_t)i, (uint8_t)path, (uint8_t)u };
+            nluma += q.size == 64 ? 8 : 2;
         }
         int nc = 0;
         place.resize(nch);
@@ -1373,9 +1405,8 @@ private:
 
         RoundParams p;
         p.jobs = reinterpret_cast<const LumaJob *>(R.g_jobs);
-        p.groups = reinterpret_cast<const LumaGroup *>(R.g_jobs + off_groups);
         p.cjobs = reinterpret_cast<const ChromaJob *>(R.g_jobs + off_cjobs);
-        p.nluma = nluma, p.nchroma = nc;
+        p.nluma = nluma, p.nchroma = nc, p.n64 = n64;
         for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
         p.planes = d_planes;
         p.ref_c[0] = d_ref[1] + (size_t)kPadC * stride_c + kPadC, p.ref_c[1] = d_ref[2] + (size_t)kPadC * stride_c + kPadC;
@@ -1405,7 +1436,7 @@ private:
         const auto t3 = std::chrono::steady_clock::now();
 
         for (int i = 0; i < ncu; i++) {
-            CuEval &q = *cu[i];
+            CuEval &q = *cu[order[i]];
             const LumaJob &j = jobs[i];
             const LumaHead &hd = *reinterpret_cast<const LumaHead *>(h_out + j.out_head);
             q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
@@ -1491,6 +1522,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 }
 
 #ifdef XMI_EXP_ROUND_TIMING
+int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 int xmi_debug_intra_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_intra_ticks), sizeof(unsigned long long) * 18) == hipSuccess ? 0 : -1; }
 int xmi_debug_chain_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ticks), sizeof(unsigned long long) * 24) == hipSuccess ? 0 : -1; }

@@ -65,15 +65,21 @@ __device__ __forceinline__ u32 row_sum(u32 x)
 // WAVES = 4 (32x32 and 64x64 only): the whole workgroup of 256 threads runs one search - every thread of it must call, with
 // the same request - and the partial sums of its wavefronts meet in s_red (4 x 9 words of LDS); a 64x64 candidate is then 4
 // dwords per thread instead of 16, and a stage's candidates fit in registers together.
-template <int N, bool SURF, bool PACK = false, int WAVES = 1>
-__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win, u32 *s_red = nullptr)
+// zero_fn (optional): the caller's answer to "was (0,0) tested already?", asked for only when it matters - when (0,0) would
+// beat the predictor's integer position - instead of rq.zero_mv_tested; every thread that shares the block calls it together.
+// n_int_sads of the result then counts (0,0) only when it was asked.
+template <int N, bool SURF, bool PACK = false, int WAVES = 1, class ZeroFn = std::nullptr_t>
+__device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win, u32 *s_red = nullptr,
+                                       ZeroFn zero_fn = nullptr)
 {
     static_assert(!PACK || N == 8, "only 8x8 blocks fit four to a wavefront");
     static_assert(WAVES == 1 || (WAVES == 4 && N >= 32 && !PACK), "a workgroup search is for the large blocks");
     constexpr int GT = PACK ? 16 : 64 * WAVES;       // threads that share the block
     constexpr int DW = N * N / 4, DPR = N / 4;       // dwords per block / per block row
     constexpr int J = DW < GT ? 1 : DW / GT;         // block dwords per lane
-    constexpr int KC = J == 1 ? 9 : J == 4 ? 4 : 1;  // candidates evaluated together (bounds the registers)
+    // candidates evaluated together, i.e. whose loads are in flight at once (bounds the registers): a 64x64 search on a whole
+    // workgroup takes a sub-pel round's nine in one memory round trip
+    constexpr int KC = J == 1 ? 9 : J == 4 ? (WAVES == 4 ? 9 : 4) : 1;
     const int lane = PACK ? (wave_lane & 15) : wave_lane;
     const bool live = DW >= GT || lane < DW;
     const size_t plane_bytes = (size_t)p.rows * p.stride;
@@ -217,7 +223,15 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     auto mvcost = [&](int x, int y) { return lam * (mv_bits(px - x) + mv_bits(py - y)); };
     u32 bcost = 0x7fffffffu;
     int bmx = 0, bmy = 0, best_k = -1;
-    if (!rq.zero_mv_tested) {
+    int omx = px >> 2, omy = py >> 2;
+    bool zero_tested = rq.zero_mv_tested != 0;
+    if constexpr (!std::is_same<ZeroFn, std::nullptr_t>::value) {
+        // (0,0) goes first and the predictor's position replaces it unless it costs more: testing (0,0) changes nothing when
+        // it costs more than the predictor's position, or is that position
+        const bool matters = s5[2] + mvcost(0, 0) <= (mvp_idx ? s5[4] : s5[3]) + mvcost(omx * 4, omy * 4) && (omx != 0 || omy != 0);
+        zero_tested = matters ? zero_fn() : true;
+    }
+    if (!zero_tested) {
         const u32 c = s5[2] + mvcost(0, 0);
         n_int++;
         if (c < bcost) {
@@ -225,7 +239,6 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
             bmx = bmy = 0;
         }
     }
-    int omx = px >> 2, omy = py >> 2;
     {
         const u32 c = (mvp_idx ? s5[4] : s5[3]) + mvcost(omx * 4, omy * 4);
         n_int++;
