@@ -239,6 +239,13 @@ private:
             std::memcpy(rec_out + r * size, rec + r * 80, (size_t)size);
             std::memcpy(lev_out + r * size, lev + r * stride, (size_t)size * 2);
         }
+        // the evaluator contract leaves the levels of a unit undefined when their sum is zero (the GPU does not store them):
+        // poisoned here, so that host code that reads them anyway fails the parity tests on the CPU already
+        const int units = size == full ? 4 : 1, un = units == 4 ? size / 2 : size;
+        for (int u = 0; u < units; u++)
+            if (!sum[u])
+                for (int r = 0; r < un; r++)
+                    for (int c = 0; c < un; c++) lev_out[((units == 4 ? (u >> 1) * un : 0) + r) * size + (units == 4 ? (u & 1) * un : 0) + c] = 0x2bad;
         return orc_ssd(size, pix, stride, rec, 80);
     }
 

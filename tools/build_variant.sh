@@ -8,7 +8,7 @@ for f in x265_amd/csrc/*.hip; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $extra "$@" -c $f -o build/variants/obj_$name/$(basename $f .hip).o &
 done
 for f in x265_amd/csrc/host/*.cpp; do
-  g++ -O2 -std=c++17 -fPIC -pthread -c $f -o build/variants/obj_$name/$(basename $f .cpp).o &
+  g++ -O2 -std=c++17 -fPIC -pthread $HOSTFLAGS -c $f -o build/variants/obj_$name/$(basename $f .cpp).o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC build/variants/obj_$name/*.o -o build/variants/libx265_amd_$name.so -pthread

@@ -117,7 +117,9 @@ __device__ unsigned long long g_chain_ticks[4][6];      // per unit size 4/8/16/
 // DST-VII matrix of 4x4 intra luma blocks (xSubDST4, src/pixel.cpp:1567)
 __constant__ int8_t k_dst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
 
-template <int N, bool INTRA = false, bool DST = false>
+// LAZY: the levels go out only when one of them is not zero - the caller reads a unit's levels only when its sum says so, and
+// most units of a P picture quantise to nothing (the result area is host memory: every store crosses the bus).
+template <int N, bool INTRA = false, bool DST = false, bool LAZY = false>
 __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
                            uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd, uint8_t *rec_copy = nullptr, int copy_stride = 0)
 {
@@ -155,6 +157,8 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
     const int qbits = 14 + qp / 6 + (15 - 8 - LG), q = k_quant_scales[qp % 6], qrnd = (INTRA ? 171 : 85) << (qbits - 9);      // xQuant (src/pixel.cpp:1060)
     const int dshift = 20 - 14 - (15 - 8 - LG), dscale = k_inv_quant_scales[qp % 6] << (qp / 6);
     uint32_t local = 0;
+    uint2 held = make_uint2(0u, 0u);      // (a unit has at most 1024 samples: one step per thread)
+    static_assert(N <= 32, "one quantiser step per thread");
     for (int e = tid * 4; e < N * N; e += 1024) {
         const int k = e / N, i = e % N;
         int lv[4];
@@ -166,8 +170,8 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
             lv[t] = clip16(c < 0 ? -mag : mag);
             L.b[(i + t) * LD + k] = (int16_t)clip16((lv[t] * dscale + (1 << (dshift - 1))) >> dshift);
         }
-        *reinterpret_cast<uint2 *>(level + (size_t)k * out_stride + i) =
-            make_uint2((uint32_t)(lv[0] & 0xffff) | ((uint32_t)lv[1] << 16), (uint32_t)(lv[2] & 0xffff) | ((uint32_t)lv[3] << 16));
+        held = make_uint2((uint32_t)(lv[0] & 0xffff) | ((uint32_t)lv[1] << 16), (uint32_t)(lv[2] & 0xffff) | ((uint32_t)lv[3] << 16));
+        if (!LAZY) *reinterpret_cast<uint2 *>(level + (size_t)k * out_stride + i) = held;
     }
     __syncthreads();
     XMI_CSTAMP(c3);
@@ -200,6 +204,7 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
     sum = L.red5[0][0] + L.red5[1][0] + L.red5[2][0] + L.red5[3][0];
     ssd = L.red5[0][1] + L.red5[1][1] + L.red5[2][1] + L.red5[3][1];
     __syncthreads();
+    if (LAZY && sum && tid * 4 < N * N) *reinterpret_cast<uint2 *>(level + (size_t)((tid * 4) / N) * out_stride + (tid * 4) % N) = held;
 #ifdef XMI_EXP_ROUND_TIMING
     if (tid == 0) {
         const unsigned long long c5 = __builtin_amdgcn_s_memrealtime();
@@ -316,7 +321,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     const int ux = (u & 1) * 32, uy = (u >> 1) * 32;      // u is 0 unless the CU is 64x64
     const size_t o = (size_t)uy * N + ux;
     uint32_t sum, ssd;
-    chain_unit<UN>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
+    chain_unit<UN, false, false, true>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
                    pred_out ? pred_out + o : nullptr, N, sum, ssd);
     if (tid == 0) {
         (path ? head->sum_me : head->sum_merge)[u] = sum;
@@ -377,7 +382,7 @@ __device__ void chroma_job(const RoundParams &p, RoundLds &L, const ChromaJob &j
         return;
     }
     uint32_t sum, ssd;
-    chain_unit<N>(L, p.src[1 + j.plane] + (size_t)j.y * (p.width / 2) + j.x, p.width / 2, pred_lds, N, p.qpc,
+    chain_unit<N, false, false, true>(L, p.src[1 + j.plane] + (size_t)j.y * (p.width / 2) + j.x, p.width / 2, pred_lds, N, p.qpc,
                   reinterpret_cast<int16_t *>(p.out + j.out_level), rec, nullptr, j.rec_stride, sum, ssd);
     if (tid == 0) *reinterpret_cast<uint32_t *>(p.out + j.out_sum) = sum;
 }

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <thread>
@@ -228,6 +229,10 @@ struct Row {
     // host time of the row between two requests (nanoseconds) and the number of requests: what a round trip waits for
     // besides the evaluator
     uint64_t busy_ns = 0, requests = 0;
+#ifdef XMI_EXP_HOST_TIMING
+    uint64_t cat[4] = {};
+    static uint64_t tick() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#endif
     std::chrono::steady_clock::time_point t_resume = std::chrono::steady_clock::now();
     std::vector<ChromaEval> chroma_req;
     std::vector<int> chroma_list;      // the CUs chroma_req stands for: px | py << 8 | size << 16
@@ -256,7 +261,7 @@ struct Row {
     CuEval *req_cu[85] = {};
     int n_req_cu = 0;
     bool req_chroma = false;     // ... that is part of the call its lane is making right now
-    int need = -1;
+    std::atomic<int> need{ -1 };     // CTUs of the row above this row waits for, or -1 (changed under the mutex, polled without)
 
     uint8_t &M(int r, int c) { return mode[(r + 1) * 18 + c + 1]; }
     uint8_t &I1(int r, int c) { return info1[(r + 1) * 17 + c + 1]; }
@@ -310,6 +315,7 @@ struct Shared {
     std::condition_variable cv_rows;    // rows whose polling time ran out sleep here until their answers are in place
     std::condition_variable cv_need;    // rows that wait for the row above sleep here
     std::atomic<int> sleepers{ 0 };     // rows asleep on cv_rows: a round that finds none wakes nobody (no system call)
+    int need_sleepers = 0;              // rows asleep on cv_need (under the mutex)
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
@@ -419,6 +425,21 @@ void Row::mark_decided(int px, int py, int size, Mv g)
         for (int j = 0; j < size / 8; j++) V(py / 8 + i, px / 8 + j) = g;
 }
 
+// Levels of an n x n block whose transform units are `units` (1, or the 4 quadrants): an evaluator leaves the levels of a
+// unit undefined when their sum is zero (CuEval, ChromaEval), so those are not read.
+void take_levels(int16_t *dst, int dst_stride, const int16_t *src, int n, const uint32_t *sums, int units)
+{
+    const int un = units == 4 ? n / 2 : n;
+    for (int u = 0; u < units; u++) {
+        const int ox = units == 4 ? (u & 1) * un : 0, oy = units == 4 ? (u >> 1) * un : 0;
+        for (int i = 0; i < un; i++) {
+            int16_t *d = dst + (size_t)(oy + i) * dst_stride + ox;
+            if (sums[u]) std::memcpy(d, src + (size_t)(oy + i) * n + ox, (size_t)un * 2);
+            else std::memset(d, 0, (size_t)un * 2);
+        }
+    }
+}
+
 // xEncDecideCU_Inter (src/encode.cpp:3080-3639), FAST_MD build: returns the RD cost as the reference's callers see it,
 // truncated to 32 bits by the function's declared return type.
 uint32_t Row::decide(int px, int py, int size, int depth)
@@ -439,6 +460,9 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         return r.amvp[0].x == cand[0].x && r.amvp[0].y == cand[0].y && r.amvp[1].x == cand[1].x && r.amvp[1].y == cand[1].y;
     };
     if (!(tree_ok[idx] && same_request(q))) {
+#ifdef XMI_EXP_HOST_TIMING
+        const uint64_t ts0 = tick();
+#endif
         std::memset(tree_ok, 0, sizeof tree_ok);      // a new call: the answers of the last one are gone
         spec_list.clear();
         fill_request(q, cand, nmerge, px, py, size);
@@ -484,6 +508,9 @@ uint32_t Row::decide(int px, int py, int size, int depth)
             guess_hits = 0;
             asked_px = px, asked_py = py;
         }
+#ifdef XMI_EXP_HOST_TIMING
+        cat[1] += tick() - ts0;
+#endif
         evaluate_cus(spec_list.data(), (int)spec_list.size());
     } else if (px != asked_px || py != asked_py) {
         guess_hits++;      // not one of the asking CU's first children, whose neighbours were never in question
@@ -528,7 +555,7 @@ uint32_t Row::decide(int px, int py, int size, int depth)
                 best_cbf[li] = 0;
             } else {
                 std::memcpy(best_rec[li], q.rec_merge, (size_t)size * size);
-                std::memcpy(best_coef[li], q.level_merge, (size_t)size * size * 2);
+                take_levels(best_coef[li], size, q.level_merge, size, q.sum_merge, size == 64 ? 4 : 1);
                 best_cbf[li] = cbf;
             }
         }
@@ -565,7 +592,7 @@ uint32_t Row::decide(int px, int py, int size, int depth)
             rate.bin(0, ctx_skip);                 // the skip flag joins the estimate here without a fresh start of the counter (:3452)
             cab[depth] = work;
             std::memcpy(best_rec[li], q.rec_me, (size_t)size * size);
-            std::memcpy(best_coef[li], q.level_me, (size_t)size * size * 2);
+            take_levels(best_coef[li], size, q.level_me, size, q.sum_me, size == 64 ? 4 : 1);
             best_cbf[li] = cbf;
         }
     }
@@ -697,8 +724,8 @@ void Row::chroma_apply(int xp)
         block_in(gu + (size_t)(py / 2) * wc + px / 2, wc, c.rec_u, sc, sc, sc);
         block_in(gv + (size_t)(py / 2) * wc + px / 2, wc, c.rec_v, sc, sc, sc);
         if (c.skip) continue;                      // the levels stay zero
-        block_in(cu + (size_t)(py / 2) * wc + px / 2, wc * 2, c.level_u, sc * 2, sc, sc * 2);
-        block_in(cv + (size_t)(py / 2) * wc + px / 2, wc * 2, c.level_v, sc * 2, sc, sc * 2);
+        take_levels(cu + (size_t)(py / 2) * wc + px / 2, wc, c.level_u, sc, c.sum_u, size == 64 ? 4 : 1);
+        take_levels(cv + (size_t)(py / 2) * wc + px / 2, wc, c.level_v, sc, c.sum_v, size == 64 ? 4 : 1);
         const int merge_idx = G0(r4, c4) & 0x3f;
         if (size == 64) {
             int any = 0;
@@ -736,10 +763,11 @@ void Row::ctu_done(int xp)
     S.done[y] = xp + 1;
     if (y + 1 < S.nrows) {
         Row &below = S.rows[y + 1];
-        if (below.need >= 0 && S.done[y] >= below.need) {
-            below.need = -1;
-            S.lanes[(y + 1) % S.lanes.size()].running++;
-            S.cv_need.notify_all();
+        const int wanted = below.need.load(std::memory_order_relaxed);
+        if (wanted >= 0 && S.done[y] >= wanted) {
+            S.lanes[(y + 1) % S.lanes.size()].running++;      // on the waiter's behalf, before it can ask for anything
+            below.need.store(-1, std::memory_order_release);
+            if (S.need_sleepers > 0) S.cv_need.notify_all();
         }
     }
 }
@@ -793,8 +821,14 @@ void Row::evaluate_cus(CuEval *const *list, int n)
         req_chroma = false;
         const int xp = chroma_waiting;
         chroma_waiting = -1;
+#ifdef XMI_EXP_HOST_TIMING
+        const uint64_t tc0 = tick();
+#endif
         chroma_apply(xp);
         ctu_done(xp);
+#ifdef XMI_EXP_HOST_TIMING
+        cat[3] += tick() - tc0;
+#endif
         // the left neighbours of the CTU being decided are CTU xp's last column
         const PictureResult &out = *sh->out;
         const int w4 = sh->w / 4;
@@ -1068,15 +1102,26 @@ void Row::run()
                 const int need = x + 2 < cols ? x + 2 : cols;
                 std::unique_lock<std::mutex> lk(S.m);
                 if (S.done[y - 1] < need) {
-                    this->need = need;
+                    this->need.store(need, std::memory_order_relaxed);
                     Lane &ln = S.lanes[y % S.lanes.size()];
                     if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
+                    lk.unlock();
                     const auto t0 = std::chrono::steady_clock::now();
-                    S.cv_need.wait(lk, [&] { return this->need < 0; });
+                    // the row above is a round trip or two away: poll first, as for answers
+                    if (!poll_until(S.spin_us, [&] { return this->need.load(std::memory_order_acquire) < 0; })) {
+                        lk.lock();
+                        S.need_sleepers++;
+                        S.cv_need.wait(lk, [&] { return this->need.load(std::memory_order_relaxed) < 0; });
+                        S.need_sleepers--;
+                        lk.unlock();
+                    }
                     t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
                     if (S.error) throw Abort();
                 }
             }
+#ifdef XMI_EXP_HOST_TIMING
+            const uint64_t tp0 = tick();
+#endif
             // caches: neighbours from the picture-level arrays of the CTUs already done
             std::memset(mode, kInvalid, sizeof mode);
             std::memset(info1, 0, sizeof info1);
@@ -1106,6 +1151,9 @@ void Row::run()
             min_ipel.x = (int16_t)clip64(-64 * x - 64), max_ipel.x = (int16_t)clip64(64 * (cols - x));
             min_ipel.y = (int16_t)clip64(-64 * y - 64), max_ipel.y = (int16_t)clip64(64 * (S.nrows - y));
 
+#ifdef XMI_EXP_HOST_TIMING
+            cat[0] += tick() - tp0;
+#endif
             if (S.intra) {
                 // the unfiltered reconstruction above and to the left of the CTU, as far as the picture has it
                 const int wc = S.w / 2;
@@ -1136,6 +1184,9 @@ void Row::run()
                 chroma_prepare();
             }
 
+#ifdef XMI_EXP_HOST_TIMING
+            const uint64_t te0 = tick();
+#endif
             last = cab[0];
             std::memcpy(&out.ctx_out[((size_t)y * cols + x) * 256], cab[0].m, 256);
             for (int r = 0; r < 16; r++) {
@@ -1162,6 +1213,9 @@ void Row::run()
                 ctu_done(x);
             } else if (x + 1 < cols && S.defer_chroma) {
                 chroma_waiting = x;                 // with the next CTU's first request
+#ifdef XMI_EXP_HOST_TIMING
+                cat[2] += tick() - te0;
+#endif
             } else {
                 evaluate_chroma();
                 chroma_apply(x);
@@ -1307,7 +1361,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                 out.evaluator_calls++, out.cu_requests += cu.size() + pu.size() + quads.size(), out.chroma_requests += chroma.size() + ichroma.size() + cquads.size();
                 if (S.error) {       // an error ends the picture: rows waiting for a neighbour leave as well
                     for (Row &r : S.rows)
-                        if (r.need >= 0) r.need = -1, S.lanes[r.y % nl].running.fetch_add(1);
+                        if (r.need.load() >= 0) S.lanes[r.y % nl].running.fetch_add(1), r.need.store(-1);
                     for (Lane &o : S.lanes) o.cv_main.notify_one();
                     S.cv_need.notify_all();
                 }
@@ -1320,6 +1374,15 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     for (std::thread &t : threads) t.join();
     out.row_busy_ns = out.row_requests = 0;
     for (const Row &r : S.rows) out.row_busy_ns += r.busy_ns, out.row_requests += r.requests;
+#ifdef XMI_EXP_HOST_TIMING
+    {
+        uint64_t c[4] = {};
+        for (const Row &r : S.rows)
+            for (int k = 0; k < 4; k++) c[k] += r.cat[k];
+        std::fprintf(stderr, "host us per CTU: busy %.2f, prologue %.2f, speculation %.2f, epilogue %.2f, chroma apply %.2f; calls %llu\n", out.row_busy_ns / 1e3 / nctu,
+                     c[0] / 1e3 / nctu, c[1] / 1e3 / nctu, c[2] / 1e3 / nctu, c[3] / 1e3 / nctu, (unsigned long long)out.row_requests);
+    }
+#endif
     return S.error.load();
 }
 

@@ -36,7 +36,7 @@ struct CuEval {
     int best_merge;                   // index into merge_mv, -1 when no candidate was usable
     uint32_t ssd_skip;                // SSD(source, prediction of best_merge)
     uint32_t ssd_merge;               // SSD(source, reconstruction of best_merge)
-    uint32_t sum_merge[4];            // sum |level| per transform unit
+    uint32_t sum_merge[4];            // sum |level| per transform unit; the levels of a unit are defined only where it is not zero
     const uint8_t *pred_merge, *rec_merge;
     const int16_t *level_merge;
     Mv mv_me;
@@ -55,7 +55,7 @@ struct ChromaEval {
     int qpc;
     const uint8_t *rec_u, *rec_v;
     const int16_t *level_u, *level_v;
-    uint32_t sum_u[4], sum_v[4];
+    uint32_t sum_u[4], sum_v[4];      // (levels of a unit are defined only where its sum is not zero)
 };
 
 // One square intra PU of an I picture, everything xEncDecideCU_Intra asks of the pixel primitives for it

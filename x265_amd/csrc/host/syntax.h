@@ -8,6 +8,7 @@
 // One call of ep() stands for one command of the reference: a command word keeps 16 bits of the value
 // (FLAG_OFF_VAL, inc/x265.h:412), which the writing sink reproduces.
 #pragma once
+#include <cstring>
 #include <cstdint>
 #include <cstdlib>
 
@@ -128,19 +129,31 @@ void code_coefficients(S &s, const int16_t *coef, int stride, int size, bool lum
     const int log2 = ilog2(size), side = size >> 2;
     const uint16_t *scan = coef_scan(scan_idx, log2);
     const uint8_t *scan_cg = group_scan(scan_idx, log2);
+    // which 4x4 groups hold a coefficient (four 8-byte looks per group), the last of them in scan order, and in it the last
+    // coefficient: positions 16 set .. 16 set + 15 of every scan are the samples of group scan_cg[set]
     uint8_t cg_flag[64] = {};
-    unsigned remaining = 0;
-    for (int y = 0; y < size; y++)
-        for (int x = 0; x < size; x++) remaining += coef[y * stride + x] != 0;
-    int last = -1, lx = 0, ly = 0;
-    do {
-        const int p = scan[++last];
-        ly = p >> log2, lx = p - (ly << log2);
-        if (coef[ly * stride + lx]) {
-            cg_flag[side * (ly >> 2) + (lx >> 2)] = 1;
-            remaining--;
+    int top_set = -1;
+    for (int set = side * side - 1; set >= 0; set--) {
+        const int g = scan_cg[set], gy = g / side, gx = g - gy * side;
+        const int16_t *c = coef + (gy * 4) * stride + gx * 4;
+        uint64_t any = 0;
+        for (int r = 0; r < 4; r++) {
+            uint64_t v;
+            std::memcpy(&v, c + r * stride, 8);
+            any |= v;
         }
-    } while (remaining > 0);
+        if (any) {
+            cg_flag[g] = 1;
+            if (top_set < 0) top_set = set;
+        }
+    }
+    if (top_set < 0) top_set = 0;                       // (the callers code blocks with a coefficient only)
+    int last = top_set * 16 + 15, lx = 0, ly = 0;
+    for (;; last--) {
+        const int p = scan[last];
+        ly = p >> log2, lx = p - (ly << log2);
+        if (coef[ly * stride + lx] || last == 0) break;
+    }
     code_last_xy(s, lx, ly, log2, luma, scan_idx);
 
     const int base_cg = kCtxSigCg + (luma ? 0 : kNumSigCg), base_sig = kCtxSig + (luma ? 0 : kNumSigLuma);
