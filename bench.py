@@ -187,9 +187,16 @@ def analysis_rate(L, qp=32, pictures=4, segments=True):
         out = bench_analysis.run(1920, 1080, qp, pictures, lib=L)
         # GOP segments are independent (each starts at an I picture), so several are analysed at the same time on one GPU,
         # one handle and one host thread group each; the aggregate is what a segment-parallel encode sees
+        # With several analysers on one GPU the pixel work counts, not the round trips: how far requests reach ahead
+        # (xmi_analysis_speculate) is the caller's choice, so both settings are measured and the better one is quoted.
         if segments:
-            seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L)
-            out["analysis_fps_8_segments"] = seg.get("analysis_fps", seg.get("error"))
+            by_level = {}
+            for level in (1, 2):
+                seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L, speculate=level)
+                by_level[level] = seg.get("analysis_fps", seg.get("error"))
+            ok = {k: v for k, v in by_level.items() if isinstance(v, (int, float))}
+            out["analysis_fps_8_segments"] = max(ok.values()) if ok else by_level[2]
+            out["analysis_fps_8_segments_by_speculate"] = {str(k): v for k, v in by_level.items()}
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}
