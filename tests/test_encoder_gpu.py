@@ -38,6 +38,29 @@ def test_stream_equals_the_recorded_stream(key):
     assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
 
 
+def test_2160p_segments_equal_the_recorded_streams():
+    """The 3840x2160 configuration through the library's own encoder: two GOP segments (I + P, a new encoder each) of the clip
+    recorded in tests/golden/segment_md5_2160p.json - written by the reference's sources built with MAX_HEIGHT 2176 on CPU
+    primitives (oracle/Makefile, enc_2160p) - byte for byte. Coded size 3840x2176: 34 CTU rows of 60."""
+    from x265_amd.encoder import encode_clip
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "segment_md5_2160p.json")))["3840x2160_q32_seed11_gop2"]
+    rng = np.random.default_rng(11)
+    pics = [frame(3840, 2160, t, rng) for t in range(4)]
+    for b in (0, 2):
+        stream = encode_clip(pics[b:b + 2], 3840, 2160, 32)
+        want = gold[f"{b}-{b + 2}"]
+        assert len(stream) == want["bytes"], f"segment {b}: {len(stream)} bytes, recorded {want['bytes']}"
+        assert hashlib.md5(stream).hexdigest() == want["md5"], f"segment {b}"
+
+
+def test_speculation_depth_does_not_change_the_stream():
+    from x265_amd.encoder import encode_clip
+    pics = clip(416, 240, 4)
+    a = encode_clip(pics, 416, 240, 27)
+    for level in (0, 1):
+        assert encode_clip(pics, 416, 240, 27, speculate=level) == a, level
+
+
 def test_lanes_and_polling_do_not_change_the_stream():
     from x265_amd.encoder import encode_clip
     pics = clip(416, 240, 3)
