@@ -382,6 +382,13 @@ int orc_analysis_speculate(void *h, int level)
     static_cast<Handle *>(h)->an.speculate = level;
     return 0;
 }
+// worker threads the CTU rows are dealt to as fibers (Analyser::workers; 0 = by the host's cores)
+int orc_analysis_workers(void *h, int n)
+{
+    if (n < 0) return -1;
+    static_cast<Handle *>(h)->an.workers = n;
+    return 0;
+}
 void orc_analysis_destroy(void *h) { delete static_cast<Handle *>(h); }
 
 // set != 0: load the carried state; else read it back. Arrays: rows * cols * 5 (sum, count, avg), rows (frac).

@@ -98,7 +98,7 @@ def p(a):
 class Runner:
     """create / state / p_picture of either library, same argument lists (prefix orc_analysis_ or xmi_analysis_)."""
 
-    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0, speculate=None):
+    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0, speculate=None, workers=None):
         self.lib, self.w, self.h = lib, w, h
         self.create, self.destroy = getattr(lib, prefix + "create"), getattr(lib, prefix + "destroy")
         self.state, self.picture = getattr(lib, prefix + "state"), getattr(lib, prefix + "p_picture")
@@ -118,6 +118,11 @@ class Runner:
             assert rc == 0, f"configure({lanes}, {spin_us}) returned {rc}"
         # How far a request reaches ahead is a switch of the CPU harness only (the library always runs at 2). On the CPU every
         # request costs its full pixel work, so the harness runs at 1 unless a test asks for more.
+        if workers is not None:      # (CPU harness only) threads the CTU rows share as fibers
+            wk = getattr(lib, prefix + "workers")
+            wk.restype = C.c_int
+            wk.argtypes = [C.c_void_p, C.c_int]
+            assert wk(self.handle, workers) == 0
         if prefix.startswith("orc_") or speculate is not None:
             spec = getattr(lib, prefix + "speculate")
             spec.restype = C.c_int

@@ -127,6 +127,12 @@ def test_speculation_depth_does_not_change_the_result(lib, level, lanes, tag):
         assert out["counters"][0] > base["counters"][0]
 
 
+@pytest.mark.parametrize("workers,lanes,spin,tag", [(1, 1, 0, "416x240_q32_p2"), (2, 1, 20, "416x240_q22_p1"), (3, 2, 0, "416x240_q32_p7")])
+def test_rows_sharing_worker_threads_do_not_change_the_result(lib, workers, lanes, spin, tag):
+    """the four CTU rows of the picture as fibers of one, two or three threads: a row that waits hands its thread on"""
+    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin, workers=workers), tag)
+
+
 def test_hand_over_survives_many_pictures_and_settings(lib):
     """The rows hand their requests to the coordinators without a lock; the same picture again and again, with lane counts
     and polling times drawn at random (3 us: waiters usually run out of polling time and go to sleep in mid hand-over)."""
@@ -135,8 +141,8 @@ def test_hand_over_survives_many_pictures_and_settings(lib):
     pic, before, rec_md5 = fixture_picture(g, "416x240_q22_p1")
     rnd = random.Random(5)
     for _ in range(12):
-        lanes, spin = rnd.choice([1, 1, 2, 3, 4]), rnd.choice([0, 3, 30, 300])
-        r = T.Runner(lib, "orc_analysis_", pic["w"], pic["h"], lanes, spin)
+        lanes, spin, workers = rnd.choice([1, 1, 2, 3, 4]), rnd.choice([0, 3, 30, 300]), rnd.choice([0, 0, 1, 2, 3])
+        r = T.Runner(lib, "orc_analysis_", pic["w"], pic["h"], lanes, spin, workers=workers)
         try:
             for _rep in range(3):
                 r.set_state(before, pic)

@@ -17,7 +17,12 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <fstream>
+#include <memory>
+#include <string>
 #include <thread>
+
+#include <ucontext.h>
 
 namespace xmi {
 namespace analysis {
@@ -262,6 +267,24 @@ struct Row {
     int n_req_cu = 0;
     bool req_chroma = false;     // ... that is part of the call its lane is making right now
     std::atomic<int> need{ -1 };     // CTUs of the row above this row waits for, or -1 (changed under the mutex, polled without)
+    // A row runs as a fiber of a worker thread (rows y, y + workers, ... share one): a picture has more CTU rows than a host
+    // has cores to poll on, and a row that waits - for answers, for the row above - hands its thread to the next one.
+    enum Wait { kReady, kAnswers, kRowAbove };
+    ucontext_t fiber, *home = nullptr;
+    std::unique_ptr<char[]> stack;
+    Wait wait = kReady;
+    bool started = false, done = false;
+    bool runnable() const
+    {
+        return wait == kReady || (wait == kAnswers && !pending.load(std::memory_order_acquire)) ||
+               (wait == kRowAbove && need.load(std::memory_order_acquire) < 0);
+    }
+    void block(Wait why)      // back to the worker until the reason has gone
+    {
+        wait = why;
+        swapcontext(&fiber, home);
+        wait = kReady;
+    }
 
     uint8_t &M(int r, int c) { return mode[(r + 1) * 18 + c + 1]; }
     uint8_t &I1(int r, int c) { return info1[(r + 1) * 17 + c + 1]; }
@@ -297,6 +320,8 @@ struct Row {
     void evaluate_intra_chroma(bool quad);
     void fill_quad(int px, int py);
     void post_and_wait();
+    static void fiber_main(unsigned lo, unsigned hi);
+    void make_fiber();
 };
 
 // Rows are dealt to lanes (row y -> lane y % lanes). A lane is the unit of one round trip: its rows block, their requests go to
@@ -312,10 +337,8 @@ struct Lane {
 
 struct Shared {
     std::mutex m;
-    std::condition_variable cv_rows;    // rows whose polling time ran out sleep here until their answers are in place
-    std::condition_variable cv_need;    // rows that wait for the row above sleep here
-    std::atomic<int> sleepers{ 0 };     // rows asleep on cv_rows: a round that finds none wakes nobody (no system call)
-    int need_sleepers = 0;              // rows asleep on cv_need (under the mutex)
+    std::condition_variable cv_rows;    // workers none of whose rows could go on for their whole polling time sleep here
+    std::atomic<int> sleepers{ 0 };     // workers asleep on cv_rows: a round that finds none wakes nobody (no system call)
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
@@ -767,9 +790,46 @@ void Row::ctu_done(int xp)
         if (wanted >= 0 && S.done[y] >= wanted) {
             S.lanes[(y + 1) % S.lanes.size()].running++;      // on the waiter's behalf, before it can ask for anything
             below.need.store(-1, std::memory_order_release);
-            if (S.need_sleepers > 0) S.cv_need.notify_all();
+            if (S.sleepers.load(std::memory_order_relaxed) > 0) S.cv_rows.notify_all();
         }
     }
+}
+
+void Row::make_fiber()
+{
+    constexpr size_t kStack = 512 * 1024;
+    stack.reset(new char[kStack]);
+    getcontext(&fiber);
+    fiber.uc_stack.ss_sp = stack.get();
+    fiber.uc_stack.ss_size = kStack;
+    fiber.uc_link = nullptr;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(this);
+    makecontext(&fiber, reinterpret_cast<void (*)()>(&Row::fiber_main), 2, (unsigned)(a & 0xffffffffu), (unsigned)(a >> 32));
+    started = true;
+}
+
+void Row::fiber_main(unsigned lo, unsigned hi)
+{
+    Row *r = reinterpret_cast<Row *>((uintptr_t)lo | ((uintptr_t)hi << 32));
+    r->run();
+    r->done = true;
+    swapcontext(&r->fiber, r->home);      // for good
+}
+
+// cores this process may use: the hardware's, or the CPU time its control group grants if that is less
+int host_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    long long quota = 0, period = 0;
+    std::string q;
+    if (f >> q >> period && q != "max" && period > 0) {
+        quota = std::atoll(q.c_str());
+        const int granted = (int)((quota + period - 1) / period);
+        if (granted >= 1 && granted < n) n = granted;
+    }
+    return n;
 }
 
 // A round trip takes tens of microseconds, and a thread that sleeps on a condition variable needs about ten more to come
@@ -800,12 +860,7 @@ void Row::post_and_wait()
         { std::lock_guard<std::mutex> lk(sh->m); }
         ln.cv_main.notify_one();
     }
-    if (!poll_until(sh->spin_us, [&] { return !pending.load(std::memory_order_acquire); })) {
-        std::unique_lock<std::mutex> lk(sh->m);
-        sh->sleepers.fetch_add(1, std::memory_order_relaxed);
-        sh->cv_rows.wait(lk, [&] { return !pending.load(std::memory_order_acquire); });
-        sh->sleepers.fetch_sub(1, std::memory_order_relaxed);
-    }
+    block(kAnswers);
     t_resume = std::chrono::steady_clock::now();
     if (sh->error) throw Abort();
 }
@@ -1107,14 +1162,7 @@ void Row::run()
                     if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
                     lk.unlock();
                     const auto t0 = std::chrono::steady_clock::now();
-                    // the row above is a round trip or two away: poll first, as for answers
-                    if (!poll_until(S.spin_us, [&] { return this->need.load(std::memory_order_acquire) < 0; })) {
-                        lk.lock();
-                        S.need_sleepers++;
-                        S.cv_need.wait(lk, [&] { return this->need.load(std::memory_order_relaxed) < 0; });
-                        S.need_sleepers--;
-                        lk.unlock();
-                    }
+                    block(kRowAbove);
                     t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
                     if (S.error) throw Abort();
                 }
@@ -1301,9 +1349,42 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
         S.rows[y].sh = &S, S.rows[y].y = y;
         S.lanes[y % nl].rows++, S.lanes[y % nl].running++;
     }
+    // Worker threads: one per CTU row while the host has cores for them, fewer otherwise (a core is left to each coordinator).
+    // Worker w runs the rows w, w + workers, ... as fibers, going round those that can go on; when none can for the polling
+    // time, it sleeps.
+    int nw = workers > 0 ? workers : host_cores() - nl;
+    nw = nw < 1 ? 1 : nw > rows_ ? rows_ : nw;
+    auto work = [&S, nw, this](int w) {
+        ucontext_t home;
+        std::vector<Row *> mine;
+        for (int y = w; y < rows_; y += nw) mine.push_back(&S.rows[y]);
+        size_t left = mine.size();
+        auto any = [&] {
+            for (Row *r : mine)
+                if (!r->done && r->runnable()) return true;
+            return false;
+        };
+        while (left) {
+            bool ran = false;
+            for (Row *r : mine) {
+                if (r->done || !r->runnable()) continue;
+                r->home = &home;
+                if (!r->started) r->make_fiber();
+                swapcontext(&home, &r->fiber);
+                ran = true;
+                if (r->done) left--;
+            }
+            if (!ran && left && !poll_until(S.spin_us, any)) {
+                std::unique_lock<std::mutex> lk(S.m);
+                S.sleepers.fetch_add(1, std::memory_order_relaxed);
+                S.cv_rows.wait(lk, any);
+                S.sleepers.fetch_sub(1, std::memory_order_relaxed);
+            }
+        }
+    };
     std::vector<std::thread> threads;
-    threads.reserve(rows_ + nl);
-    for (int y = 0; y < rows_; y++) threads.emplace_back([&S, y] { S.rows[y].run(); });
+    threads.reserve(nw + nl);
+    for (int w = 0; w < nw; w++) threads.emplace_back(work, w);
 
     // one coordinator per lane: when none of its rows is busy on the host, whatever they asked for goes out in one call
     auto coordinate = [&S, &ev, &out, nl](int lane) {
@@ -1363,7 +1444,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                     for (Row &r : S.rows)
                         if (r.need.load() >= 0) S.lanes[r.y % nl].running.fetch_add(1), r.need.store(-1);
                     for (Lane &o : S.lanes) o.cv_main.notify_one();
-                    S.cv_need.notify_all();
+                    S.cv_rows.notify_all();
                 }
             }
             if (S.sleepers.load(std::memory_order_relaxed) > 0 || S.error) S.cv_rows.notify_all();

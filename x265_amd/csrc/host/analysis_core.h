@@ -201,6 +201,9 @@ public:
     // block: a round trip is shorter than the time a sleeping thread needs to come back. 0 = block at once (the choice when
     // many analysers share the host's cores).
     int spin_us = 0;
+    // Threads that run the CTU rows (each row a fiber of one of them); 0 = as many as the host has cores for, at most one per
+    // row. Results do not depend on it.
+    int workers = 0;
     // 1: a CU's request also asks for its first child, that child's first child, ... (same corner, same neighbours). 2: it asks
     // for every CU that may still be decided in the CTU, under the guess that all of them end up with the vector of the
     // asking CU's first merge candidate; a CU whose neighbours turn out as guessed finds its answer waiting. Fewer round
