@@ -96,6 +96,17 @@ t = timeit(lambda: capi.check(L.xmi_interp_planes_dev(ref.data_ptr(), stride, ro
 by = rows * stride * 17
 print(json.dumps({"kernel": "interp_planes 1080p (+pad 80)", "ms": round(t * 1e3, 3), "GBps": round(by / t / 1e9, 1),
                   "frac_hbm_peak": round(by / t / 1e9 / PEAK, 4)}))
+# the same with rows 128 bytes apart (a wavefront's store is then two whole lines per plane), and on a 2160p frame
+for tag, (w2, h2) in (("1080p", (1920, 1088)), ("2160p", (3840, 2176))):
+    rows2, cols2 = h2 + 2 * PAD, w2 + 2 * PAD
+    stride2 = (cols2 + 127) // 128 * 128
+    ref2 = torch.randint(0, 256, (rows2, stride2), dtype=torch.uint8, device="cuda")
+    planes2 = torch.zeros((16, rows2, stride2), dtype=torch.uint8, device="cuda")
+    t = timeit(lambda: capi.check(L.xmi_interp_planes_dev(ref2.data_ptr(), stride2, rows2, cols2, planes2.data_ptr(), s)))
+    by2 = rows2 * cols2 * 17
+    print(json.dumps({"kernel": f"interp_planes {tag} (+pad 80), stride {stride2}", "ms": round(t * 1e3, 3), "GBps": round(by2 / t / 1e9, 1),
+                      "frac_hbm_peak": round(by2 / t / 1e9 / PEAK, 4)}))
+    del ref2, planes2
 rng = np.random.default_rng(3)
 for size, nreq in ((8, 28000), (16, 9500), (32, 2400), (64, 600), (0, 39000)):
     reqs = (capi.MeRequest * nreq)()

@@ -25,7 +25,9 @@ constexpr int kTap[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, 
 constexpr int pack4(int f, int o) { return (kTap[f][o] & 255) | ((kTap[f][o + 1] & 255) << 8) | ((kTap[f][o + 2] & 255) << 16) | ((kTap[f][o + 3] & 255) << 24); }
 constexpr int pack2(int f, int o) { return (kTap[f][o] & 0xffff) | ((kTap[f][o + 1] & 0xffff) << 16); }
 
-constexpr int TW = 64, TH = 16;   // output tile
+// Output tile: 128 columns that start on a multiple of 128 of the row - with a 128-byte aligned buffer and stride a
+// wavefront's store is two whole lines per plane - by 8 rows
+constexpr int TW = 128, TH = 8;
 constexpr int RW = TW + 8, RH = TH + 7;
 
 __device__ __forceinline__ int clip8(int v) { return min(255, max(0, v)); }
@@ -61,11 +63,11 @@ __device__ __forceinline__ void h_sums(const u32 (&lo)[4], const u32 (&hi)[4], i
 
 __device__ __forceinline__ void store4(uint8_t *dst, u32 v, int x, int cols, bool aligned)
 {
-    if (x + 4 <= cols - 4 && aligned) {
+    if (x >= 4 && x + 4 <= cols - 4 && aligned) {
         *reinterpret_cast<u32 *>(dst) = v;
     } else {
         for (int e = 0; e < 4; e++)
-            if (x + e < cols - 4) dst[e] = (uint8_t)(v >> (8 * e));
+            if (x + e >= 4 && x + e < cols - 4) dst[e] = (uint8_t)(v >> (8 * e));
     }
 }
 
@@ -75,22 +77,23 @@ __global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t
     __shared__ __align__(16) uint8_t s_ref[RH][RW];          // window rows y0-3 .., columns x0-4 ..
     __shared__ __align__(16) int16_t s_h[3][RH][TW];         // horizontal sums for xf = 1..3 (unbiased, fit 16 bits)
     const int tid = threadIdx.x;
-    const int x0 = 4 + blockIdx.x * TW, y0 = 4 + blockIdx.y * TH;   // first output sample of the tile
+    const int x0 = blockIdx.x * TW, y0 = 4 + blockIdx.y * TH;       // first output sample of the tile (columns 0..3 are not written)
     const size_t plane_bytes = (size_t)rows * stride;
 
-    // window: rows y0-3 .., columns x0-4 .. x0+67 (one column more on the left than the filters need, so that it starts
-    // on a dword of the buffer); whole dwords when the buffer allows it, clamped bytes at the right edge otherwise
+    // window: rows y0-3 .., columns x0-4 .. x0+131 (one column more on the left than the filters need, so that it starts
+    // on a dword of the buffer); whole dwords when the buffer allows it, clamped bytes at the right edge otherwise. The
+    // columns left of the buffer (first tile of a row) only feed the four outputs that are not written.
     const bool dwords = ((reinterpret_cast<uintptr_t>(ref) | (uintptr_t)stride) & 3) == 0 && x0 + RW - 4 <= cols;
     if (dwords) {
         for (int e = tid; e < RH * (RW / 4); e += 256) {
             const int ry = e / (RW / 4), c = e % (RW / 4);
-            const int y = min(rows - 1, y0 - 3 + ry);
-            reinterpret_cast<u32 *>(&s_ref[ry][0])[c] = *reinterpret_cast<const u32 *>(ref + (size_t)y * stride + x0 - 4 + 4 * c);
+            const int y = min(rows - 1, y0 - 3 + ry), x = max(0, x0 - 4 + 4 * c);
+            reinterpret_cast<u32 *>(&s_ref[ry][0])[c] = *reinterpret_cast<const u32 *>(ref + (size_t)y * stride + x);
         }
     } else {
         for (int e = tid; e < RH * RW; e += 256) {
             const int ry = e / RW, rx = e % RW;
-            const int y = min(rows - 1, y0 - 3 + ry), x = min(cols - 1, x0 - 4 + rx);
+            const int y = min(rows - 1, y0 - 3 + ry), x = min(cols - 1, max(0, x0 - 4 + rx));
             s_ref[ry][rx] = ref[(size_t)y * stride + x];
         }
     }
@@ -114,7 +117,7 @@ __global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t
     }
     __syncthreads();
     // each thread: 4 consecutive samples of one row, all 16 phases
-    const int ty = tid / 16, tx = (tid % 16) * 4;
+    const int ty = tid / (TW / 4), tx = (tid % (TW / 4)) * 4;
     const int y = y0 + ty, x = x0 + tx;
     if (y >= rows - 4) return;
     u32 out[16];
@@ -194,7 +197,7 @@ extern "C" int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int 
     if (rc != XMI_OK) return rc;
     XMI_ARG(d_ref_base && d_planes, "xmi_interp_planes_dev: null argument");
     XMI_ARG(rows >= 16 && cols >= 16 && stride >= cols, "xmi_interp_planes_dev: bad geometry %d x %d, stride %d", cols, rows, stride);
-    dim3 grid((cols - 8 + TW - 1) / TW, (rows - 8 + TH - 1) / TH);
+    dim3 grid((cols - 4 + TW - 1) / TW, (rows - 8 + TH - 1) / TH);
     hipLaunchKernelGGL(interp_kernel, grid, dim3(256), 0, xmi::as_stream(stream), d_ref_base, d_planes, stride, rows, cols);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
