@@ -64,8 +64,15 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint8_t *win = s_win[SURF ? 0 : wave];
     const int single_blocks = (p.n + 3) >> 2;
-    if ((int)blockIdx.x < single_blocks) {
-        const int idx = blockIdx.x * 4 + wave;
+    // Workgroup b runs on XCD b % 8, each with an L2 of its own: the grid is dealt so that an XCD serves one contiguous
+    // eighth of the requests - neighbouring requests are neighbouring blocks of the picture and read overlapping windows
+    // (each part of the grid, rounded up to a multiple of 8 workgroups, for itself)
+    const int part1 = (single_blocks + 7) & ~7, packed_blocks = (p.n + 15) >> 4, part2 = (packed_blocks + 7) & ~7;
+    const int b = (int)blockIdx.x, in2 = b >= part1, rel = in2 ? b - part1 : b;
+    const int block = (rel & 7) * ((in2 ? part2 : part1) >> 3) + (rel >> 3);
+    if (block >= (in2 ? packed_blocks : single_blocks)) return;
+    if (!in2) {
+        const int idx = block * 4 + wave;
         if (idx >= p.n) return;
         const xmi_me_request rq = p.req[idx];
         if (!request_in_bounds<SURF>(p, rq)) {        // refused: marked, so that the caller can tell
@@ -87,7 +94,7 @@ __global__ void __launch_bounds__(256) me_search_kernel(const MeParams p)
         }
         return;
     }
-    const int base = ((int)blockIdx.x - single_blocks) * 16;
+    const int base = block * 16;
     bool is8 = false;
     if (lane < 16 && base + lane < p.n) {
         const xmi_me_request rq = p.req[base + lane];
@@ -127,7 +134,7 @@ extern "C" int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, con
     rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, rows, pad, d_req, me_range, d_res);
     if (rc != XMI_OK) return rc;
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
-    hipLaunchKernelGGL(me_search_kernel<false>, dim3((n + 3) / 4 + (n + 15) / 16), dim3(256), 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(me_search_kernel<false>, dim3(((n + 3) / 4 + 7) / 8 * 8 + ((n + 15) / 16 + 7) / 8 * 8), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
@@ -150,7 +157,7 @@ extern "C" int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_str
             g->height, g->range);
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, d_sad8, d_sad16, d_sad32, d_sad64,
                    g->range, g->width / 64, (g->width / 64) * (g->height / 64) };
-    hipLaunchKernelGGL(me_search_kernel<true>, dim3((n + 3) / 4 + (n + 15) / 16), dim3(256), 0, xmi::as_stream(stream), p);
+    hipLaunchKernelGGL(me_search_kernel<true>, dim3(((n + 3) / 4 + 7) / 8 * 8 + ((n + 15) / 16 + 7) / 8 * 8), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
 }
