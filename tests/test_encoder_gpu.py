@@ -38,6 +38,21 @@ def test_stream_equals_the_recorded_stream(key):
     assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
 
 
+def test_scene_change_detection_of_the_command_line():
+    """A clip whose scene changes at picture 6, encoded with the reference's scene-change detection on (its default): the
+    detection (src/preProcess.cpp:104, on the library's SAD) turns picture 6 into an I picture; the stream is the recorded one."""
+    from x265_amd.encoder import encode_clip
+    key = "416x240_f8_q32_cut6_scenechange"
+    rng = np.random.default_rng(1234)
+    pics = [frame(416, 240, t, rng, cut=6) for t in range(8)]
+    raw = b"".join(p.tobytes() for pic in pics for p in pic)
+    assert hashlib.md5(raw).hexdigest() == GOLD[key]["input_md5"], "the generator no longer makes the recorded input"
+    stream = encode_clip(pics, 416, 240, 32, scene_change=True)
+    assert len(stream) == GOLD[key]["bytes"], f"{len(stream)} bytes, recorded {GOLD[key]['bytes']}"
+    assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
+    assert stream.count(b"\x00\x00\x00\x01\x40\x01") == 2, "two I pictures, each with its parameter sets"
+
+
 def test_2160p_segments_equal_the_recorded_streams():
     """The 3840x2160 configuration through the library's own encoder: two GOP segments (I + P, a new encoder each) of the clip
     recorded in tests/golden/segment_md5_2160p.json - written by the reference's sources built with MAX_HEIGHT 2176 on CPU

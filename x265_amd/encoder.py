@@ -63,7 +63,7 @@ class Encoder:
 
     def encode(self, y, u, v, intra):
         """-> the access unit's bytes"""
-        if (self.W, self.H) != (self.width, self.height):
+        if y.shape != (self.H, self.W):
             y, u, v = align_frame(y, u, v, self.W, self.H)
         else:
             y, u, v = (np.ascontiguousarray(p) for p in (y, u, v))
@@ -87,14 +87,44 @@ class Encoder:
                                       "read_back": t[9] / 1e3 / n}}
 
 
-def encode_clip(frames, width, height, qp, intra_period=100, **kw):
-    """frames: iterable of (y, u, v); slice types as the reference's command line picks them without scene-change detection
-    (src/x265.cpp:240: picture i is an I slice when i % intra_period == 0 and the picture before it was none) -> stream bytes"""
+def scene_changed(enc, y_aligned, pictures_done, intra_period):
+    """sceneChangeDetection (src/preProcess.cpp:104-152) with the library's SAD: 32x32 blocks of the picture about to be coded
+    against the previous picture's reconstruction; a block with SAD above 320 * 16 is a motion block, and 85 % motion blocks
+    make a scene change. As the reference computes it: its loops over the CTUs never move the two pointers, so it is the four
+    blocks of the first CTU, each counted once per CTU of the picture."""
+    if pictures_done <= 0:
+        return True
+    if intra_period > 1 and pictures_done % intra_period == 0:
+        return False
+    from . import capi
+    L = capi.load()
+    rec_y = enc.reconstruction()[0]
+    ctus = (enc.W // 64) * (enc.H // 64)
+    threshold = int(0.85 * (ctus * 4) + 0.5 + 1e-6)
+    motion = 0
+    for oy, ox in ((0, 0), (0, 32), (32, 0), (32, 32)):
+        a, b = y_aligned[oy:, ox:], rec_y[oy:, ox:]
+        sad = L.xmi_sad(32, a.ctypes.data, enc.W, b.ctypes.data, enc.W)      # xSadN[3]: 32x32
+        if sad < 0:
+            raise XmiError(L.xmi_last_error().decode())
+        motion += ctus * int(sad > 320 * 16)
+    return motion >= threshold
+
+
+def encode_clip(frames, width, height, qp, intra_period=100, scene_change=False, **kw):
+    """frames: iterable of (y, u, v); slice types as the reference's command line picks them (src/x265.cpp:236-252: picture i is
+    an I slice when i % intra_period == 0 - or, with scene_change (its -sceneChange switch, on by default there), when more than
+    SCENE_CHANGE_INTERVAL = 4 P pictures have passed and the detection fires - and the picture before it was none)
+    -> stream bytes"""
     enc = Encoder(width, height, qp, **kw)
     try:
-        out, prev_intra = [], False
+        out, prev_intra, interval = [], False, 0
         for i, (y, u, v) in enumerate(frames):
-            intra = i % intra_period == 0 and not prev_intra
+            if y.shape != (enc.H, enc.W):
+                y, u, v = align_frame(y, u, v, enc.W, enc.H)
+            changed = scene_change and interval > 4 and scene_changed(enc, np.ascontiguousarray(y), i, intra_period)
+            intra = (i % intra_period == 0 or changed) and not prev_intra
+            interval = 0 if intra else interval + 1
             out.append(enc.encode(y, u, v, intra))
             prev_intra = intra
         return b"".join(out)
