@@ -105,6 +105,15 @@ def main():
     print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True, speculate=spec)))
     from x265_amd import capi
     L = capi.load()
+    if hasattr(L, "xmi_debug_quad_ticks"):
+        import ctypes as C
+        qt = (C.c_uint64 * 6)()
+        L.xmi_debug_quad_ticks(qt)
+        if qt[5]:
+            n = qt[5]
+            print(json.dumps({"luma group of four 4x4 PUs, us": {"set-up": round(qt[0] / n / 100, 2), "neighbours x4": round(qt[1] / n / 100, 2),
+                                                               "search x4": round(qt[2] / n / 100, 2), "prediction x4": round(qt[3] / n / 100, 2),
+                                                               "chain x4": round(qt[4] / n / 100, 2)}}))
     if hasattr(L, "xmi_debug_intra_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING): workgroup time per job type
         import ctypes
         tk = (ctypes.c_ulonglong * 18)()

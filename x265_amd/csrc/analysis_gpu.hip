@@ -711,55 +711,129 @@ __device__ __forceinline__ void chain4_wave(const int16_t *M, int16_t *A, int16_
 
 // IntraQuadEval on one wavefront: PU k sees the reconstruction and the modes of the PUs before it. The 8x8 source block and
 // everything the four PUs exchange stay in LDS; nothing in the loop waits for memory or for another wavefront.
+#ifdef XMI_EXP_ROUND_TIMING
+__device__ unsigned long long g_quad_ticks[6];      // set-up, per PU: neighbours, search, prediction, chain, head; count
+#define XMI_QSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#else
+#define XMI_QSTAMP(var)
+#endif
 __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQuadJob &j)
 {
-    const int lane = threadIdx.x & 63;
-    if (threadIdx.x >= 64) return;
-    if (lane < 33) L.outer[0][lane] = j.ref[lane];
-    if (lane < 16) {
-        reinterpret_cast<uint32_t *>(L.r.pix)[lane] = *reinterpret_cast<const uint32_t *>(p.src[0] + (size_t)(j.y0 + (lane >> 1)) * p.width + j.x0 + (lane & 1) * 4);
-        L.r.mat[0][lane] = k_dst4[lane >> 2][lane & 3];
+    // The four PUs follow each other on wavefront 0 (neighbours, prediction, transform chain: a few dozen samples each); the
+    // 35-mode search, nine tenths of the time when one wavefront does it with a lane per mode, is spread over the whole
+    // workgroup: a thread per (mode, row of the block).
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    XMI_QSTAMP(q0);
+    if (tid < 33) L.outer[0][tid] = j.ref[tid];
+    if (tid < 16) {
+        reinterpret_cast<uint32_t *>(L.r.pix)[tid] = *reinterpret_cast<const uint32_t *>(p.src[0] + (size_t)(j.y0 + (tid >> 1)) * p.width + j.x0 + (tid & 1) * 4);
+        L.r.mat[0][tid] = k_dst4[tid >> 2][tid & 3];
     }
     IntraQuadHead *h = reinterpret_cast<IntraQuadHead *>(p.out + j.out_head);
     int16_t *level = reinterpret_cast<int16_t *>(p.out + j.out_level);
     uint8_t *rec = p.out + j.out_rec;
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+#ifdef XMI_EXP_ROUND_TIMING
+    if (tid == 0) atomicAdd(&g_quad_ticks[0], __builtin_amdgcn_s_memrealtime() - q0), atomicAdd(&g_quad_ticks[5], 1ull);
+#endif
+    uint8_t *ref = L.ref[0];
+    const int my_mode = tid >> 2, my_row = tid & 3;      // the thread's share of every search
+    const int my_angle = my_mode > 1 && my_mode < 35 ? k_angle[my_mode] : 0, my_inv = my_mode > 1 && my_mode < 35 ? k_inv_angle[my_mode] : 0;
     for (int k = 0; k < 4; k++) {
         const int ox = (k & 1) * 4, oy = (k >> 1) * 4;
-        if (lane < 8) L.qref[0][lane] = quad_sample(L.outer[0], L.area[0], oy + 7 - lane, ox - 1);
-        else if (lane < 17) L.qref[0][lane] = quad_sample(L.outer[0], L.area[0], oy - 1, ox - 1 + (lane - 8));
-        __builtin_amdgcn_wave_barrier();
-        const int left = (k & 1) ? L.qmode[k - 1] : j.left_mode[k >> 1], top = (k >> 1) ? L.qmode[k - 2] : j.top_mode[k & 1];
-        xmi_intra_request rq;
-        rq.x0 = ox, rq.y0 = oy, rq.size = 4, rq.valids = j.valids[k], rq.strong_smoothing = j.strong;      // position in the LDS copy of the source
-        if (left == top) {      // most probable modes (src/encode.cpp:3980-4003)
-            if (left > 1) rq.mpm[0] = (uint8_t)left, rq.mpm[1] = (uint8_t)(((left + 29) % 32) + 2), rq.mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
-            else rq.mpm[0] = 0, rq.mpm[1] = 1, rq.mpm[2] = 26;
-        } else {
-            rq.mpm[0] = (uint8_t)left, rq.mpm[1] = (uint8_t)top;
-            rq.mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
-        }
-        rq.sqrt_lambda = j.sqrt_lambda;
-        const IntraParams ip = { L.r.pix, L.qref[0], nullptr, nullptr, 8, 1 };
-        search<4, 1>(ip, rq, 0, L.ref[0], L.r.win, lane, 0, L.best_cost, L.best_mode, &L.best);
-        __builtin_amdgcn_wave_barrier();
-        const int mode = L.best;
-        int dc;
-        {
-            int s = lane < 8 ? (lane < 4 ? L.ref[0][7 - lane] : L.ref[0][9 + (lane - 4)]) : 0;
+        XMI_QSTAMP(q1);
+        // ---- neighbouring samples of the PU (17, never smoothed at this size), padded; their DC value ----
+        if (wave == 0) {
+            const unsigned valids = j.valids[k] & 0x1fu;
+            if (lane < 8) ref[lane] = valids ? quad_sample(L.outer[0], L.area[0], oy + 7 - lane, ox - 1) : (uint8_t)0x80;
+            else if (lane < 17) ref[lane] = valids ? quad_sample(L.outer[0], L.area[0], oy - 1, ox - 1 + (lane - 8)) : (uint8_t)0x80;
+            __builtin_amdgcn_wave_barrier();
+            if (valids) pad_ref<4>(ref, valids, lane);
+            __builtin_amdgcn_wave_barrier();
+            int sdc = lane < 8 ? (lane < 4 ? ref[7 - lane] : ref[9 + (lane - 4)]) : 0;
 #pragma unroll
-            for (int m = 1; m < 8; m <<= 1) s += __shfl_xor(s, m);
-            dc = (__shfl(s, 0) + 4) >> 3;
+            for (int m = 1; m < 8; m <<= 1) sdc += __shfl_xor(sdc, m);
+            if (lane == 0) L.last = (sdc + 4) >> 3;
         }
-        if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(L.ref[0], mode, lane / 4, lane % 4, dc, true);
-        __builtin_amdgcn_wave_barrier();
-        uint32_t sum, ssd;
-        chain4_wave(L.r.mat[0], L.r.a, L.r.b, L.r.pix + oy * 8 + ox, 8, L.r.pred, j.qp, level + oy * 8 + ox, rec + oy * 8 + ox, 8, L.area[0] + oy * 8 + ox, 8, sum, ssd, lane);
-        if (lane == 0) {
-            h->best_mode[k] = mode, h->sum[k] = sum, h->ssd[k] = ssd;
-            L.qmode[k] = mode;
+        __syncthreads();
+        XMI_QSTAMP(q2);
+        // ---- the search: SATD (4x4 Hadamard, halved) + {1, 2, 3} sqrt(lambda) by most-probable-mode rank, first smallest ----
+        const int dc = L.last;
+        {
+            const int left = (k & 1) ? L.qmode[k - 1] : j.left_mode[k >> 1], top = (k >> 1) ? L.qmode[k - 2] : j.top_mode[k & 1];
+            int mpm0, mpm1, mpm2;      // most probable modes (src/encode.cpp:3980-4003)
+            if (left == top) {
+                if (left > 1) mpm0 = left, mpm1 = ((left + 29) % 32) + 2, mpm2 = ((left - 1) % 32) + 2;
+                else mpm0 = 0, mpm1 = 1, mpm2 = 26;
+            } else {
+                mpm0 = left, mpm1 = top;
+                mpm2 = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+            }
+            const int mode = my_mode, row = my_row;
+            int hd[4] = { 0, 0, 0, 0 };
+            if (mode < 35) {
+                int d[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) d[x] = (int)L.r.pix[(oy + row) * 8 + ox + x] - pred_sample<4>(ref, mode, my_angle, my_inv, row, x, dc, true);
+                const int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
+                hd[0] = a0 + a2, hd[1] = a1 + a3, hd[2] = a0 - a2, hd[3] = a1 - a3;
+            }
+            // the other direction across the four threads of the mode (signs and order of the outputs do not matter to the sum)
+            int sum = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                int v = hd[c];
+                const int o1 = __shfl_xor(v, 1);
+                v = (row & 1) ? o1 - v : v + o1;
+                const int o2 = __shfl_xor(v, 2);
+                v = (row & 2) ? o2 - v : v + o2;
+                sum += abs(v);
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum >>= 1;
+            double best_cost = 1.7976931348623157e308;
+            int best_mode = 64;
+            if (mode < 35 && row == 0) {
+                const double bits = mode == mpm0 ? 1.0 : (mode == mpm1 || mode == mpm2) ? 2.0 : 3.0;
+                best_cost = bits * j.sqrt_lambda + (double)(uint32_t)sum;
+                best_mode = mode;
+            }
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const double oc = __shfl_xor(best_cost, m);
+                const int om = __shfl_xor(best_mode, m);
+                if (oc < best_cost || (oc == best_cost && om < best_mode)) best_cost = oc, best_mode = om;
+            }
+            if (lane == 0) L.best_cost[wave] = best_cost, L.best_mode[wave] = best_mode;
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        XMI_QSTAMP(q3);
+        if (wave == 0) {
+            double bc = L.best_cost[0];
+            int mode = L.best_mode[0];
+#pragma unroll
+            for (int w = 1; w < 3; w++)      // modes 16 w .. 16 w + 15 were wavefront w's
+                if (L.best_cost[w] < bc || (L.best_cost[w] == bc && L.best_mode[w] < mode)) bc = L.best_cost[w], mode = L.best_mode[w];
+            if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(ref, mode, lane / 4, lane % 4, dc, true);
+            __builtin_amdgcn_wave_barrier();
+            XMI_QSTAMP(q4);
+            uint32_t sum, ssd;
+            chain4_wave(L.r.mat[0], L.r.a, L.r.b, L.r.pix + oy * 8 + ox, 8, L.r.pred, j.qp, level + oy * 8 + ox, rec + oy * 8 + ox, 8, L.area[0] + oy * 8 + ox, 8, sum, ssd, lane);
+            XMI_QSTAMP(q5);
+            if (lane == 0) {
+                h->best_mode[k] = mode, h->sum[k] = sum, h->ssd[k] = ssd;
+                L.qmode[k] = mode;
+            }
+            __builtin_amdgcn_wave_barrier();
+#ifdef XMI_EXP_ROUND_TIMING
+            if (lane == 0) {
+                atomicAdd(&g_quad_ticks[1], q2 - q1), atomicAdd(&g_quad_ticks[2], q3 - q2), atomicAdd(&g_quad_ticks[3], q4 - q3);
+                atomicAdd(&g_quad_ticks[4], q5 - q4);
+            }
+#endif
+        }
+        // (the other wavefronts wait at the next PU's first barrier until wavefront 0 has its neighbours ready)
     }
 }
 
@@ -1527,6 +1601,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 }
 
 #ifdef XMI_EXP_ROUND_TIMING
+int xmi_debug_quad_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_ticks), sizeof(unsigned long long) * 6) == hipSuccess ? 0 : -1; }
 int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 int xmi_debug_intra_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_intra_ticks), sizeof(unsigned long long) * 18) == hipSuccess ? 0 : -1; }

@@ -40,8 +40,9 @@ __device__ __forceinline__ int group_sum_to_last_lane(int v)
 }
 
 // one prediction sample of xEncIntraPred(mode, size, is_luma) at row y, column x; ref = sample array, tl = ref + 2*size
+// (angle, inv: k_angle[mode], k_inv_angle[mode] - table reads by lane, which a caller with a fixed mode makes once)
 template <int N>
-__device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int y, int x, int dc, bool is_luma)
+__device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int angle, int inv, int y, int x, int dc, bool is_luma)
 {
     constexpr int LG = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     const uint8_t *tl = ref + 2 * N;
@@ -55,7 +56,6 @@ __device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int y, 
         return ((y == 0 ? tl[1 + x] : tl[-1 - y]) + 3 * dc + 2) >> 2;
     }
     const bool hor = mode < 18;
-    const int angle = k_angle[mode], inv = k_inv_angle[mode];
     const int k = hor ? x : y, xx = hor ? y : x;      // row / column before the transpose of the horizontal modes
     const int delta = (k + 1) * angle, idx = delta >> 5, fact = delta & 31;
     auto main_ref = [&](int p) {
@@ -67,6 +67,12 @@ __device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int y, 
     if (fact) v = ((32 - fact) * v + fact * main_ref(pos + 1) + 16) >> 5;
     if (is_luma && angle == 0 && xx == 0) v = min(255, max(0, v + (((int)tl[hor ? k + 1 : -(k + 1)] - (int)tl[0]) >> 1)));
     return v;
+}
+
+template <int N>
+__device__ __forceinline__ int pred_sample(const uint8_t *ref, int mode, int y, int x, int dc, bool is_luma)
+{
+    return pred_sample<N>(ref, mode, mode > 1 ? k_angle[mode] : 0, mode > 1 ? k_inv_angle[mode] : 0, y, x, dc, is_luma);
 }
 
 // xPaddingRef (src/encode.cpp:3843) on 4 N + 1 samples in LDS, by one wavefront: the samples below the first available
