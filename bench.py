@@ -30,6 +30,9 @@ PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/conf
 
 ENCODE_FRAMES = 64      # the encode legs (this library's encoder, and the reference's on the host cores) use the published
                         # configuration: 1920x1080, 64 pictures, IPPP, QP 32
+# host threads per encoder / analyser when eight of them share one GPU and the process's cores (xmi_encoder_workers): a
+# handle's CTU rows are fibers of that many threads, and 8 x 2 of them fit the 16 cores a GPU's share of a host has
+SEGMENT_WORKERS = 2
 
 
 def measured_traffic(w, h, rng):
@@ -192,7 +195,7 @@ def analysis_rate(L, qp=32, pictures=4, segments=True):
         if segments:
             by_level = {}
             for level in (1, 2):
-                seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L, speculate=level)
+                seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L, speculate=level, workers=SEGMENT_WORKERS)
                 by_level[level] = seg.get("analysis_fps", seg.get("error"))
             ok = {k: v for k, v in by_level.items() if isinstance(v, (int, float))}
             out["analysis_fps_8_segments"] = max(ok.values()) if ok else by_level[2]
@@ -211,7 +214,7 @@ def encode_rate(L, qp=32, segments=True):
         import bench_encoder
         out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
         if segments:
-            out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8)
+            out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=SEGMENT_WORKERS)
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}
@@ -376,7 +379,7 @@ def main():
         import bench_encoder
         dist.barrier()
         try:
-            mine = bench_encoder.run_segments(1920, 1080, 4, 32, 8)
+            mine = bench_encoder.run_segments(1920, 1080, 4, 32, 8, workers=SEGMENT_WORKERS)
         except Exception as e:      # noqa: BLE001
             mine = {"error": repr(e)}
         enc_ranks = [None] * world

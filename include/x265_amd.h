@@ -412,6 +412,11 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us);
  * with the vector of the asking CU's first merge candidate; a CU whose real neighbours are the guessed ones finds its answer
  * waiting. Fewer round trips where motion is coherent, more pixel work. */
 int xmi_analysis_speculate(xmi_analysis *a, int level);
+/* Host threads that run the CTU rows of a picture (each row is a fiber of one of them; no counterpart in the reference, results
+ * do not depend on it). 0 (default): as many as the process has cores for, at most one per row - the choice for one picture
+ * stream. A caller that runs several handles at once on one host (GOP segments) gives each a share of the cores, so that
+ * their threads can poll (spin_us) instead of sleeping. */
+int xmi_analysis_workers(xmi_analysis *a, int workers);
 /* Measurement aid (no counterpart in the reference): where the round trips of this handle have spent their time so far,
  * summed over its lanes: out = { ns writing job tables, ns in the launch call, ns waiting for the GPU, ns reading results
  * back, round trips, and for the last picture: ns the CTU-row threads spent on decision work between their requests,
@@ -449,6 +454,7 @@ xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_
 void xmi_encoder_destroy(xmi_encoder *e);
 int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us);
 int xmi_encoder_speculate(xmi_encoder *e, int level);      /* xmi_analysis_speculate for the encoder's analysis loop */
+int xmi_encoder_workers(xmi_encoder *e, int workers);      /* xmi_analysis_workers for the encoder's analysis loop */
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
                            size_t capacity);
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);

@@ -25,7 +25,7 @@ def synth(w, h, t, seed):
     return y, u, v
 
 
-def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=None, spin_us=0, lib=None, speculate=None):
+def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=None, spin_us=0, lib=None, speculate=None, workers=None):
     """`segments` independent GOP segments analysed at the same time on one GPU (one handle, one host thread each; the C
     call releases the interpreter lock): aggregate P pictures per second."""
     import threading
@@ -36,7 +36,7 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
     w, h = (width + 63) // 64 * 64, (height + 63) // 64 * 64
     clips = [[synth(w, h, t, 7 + s) for t in range(pictures + 1)] for s in range(segments)]
     refs = [[tuple(np.pad(p, 80 if i == 0 else 40, mode="edge") for i, p in enumerate(f)) for f in clip] for clip in clips]
-    runners = [T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us, speculate=speculate) for _ in range(segments)]
+    runners = [T.Runner(L, "xmi_analysis_", w, h, lanes, spin_us, speculate=speculate, workers=workers) for _ in range(segments)]
     errs = []
 
     def work(s, lo, hi):
@@ -62,7 +62,7 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
         r.close()
     if errs:
         return {"error": errs[0]}
-    return {"segments": segments, "lanes": lanes, "speculate": 2 if speculate is None else speculate, "analysis_fps": round(segments * (pictures - 1) / sec, 3), "qp": qp,
+    return {"segments": segments, "lanes": lanes, "workers": workers, "speculate": 2 if speculate is None else speculate, "analysis_fps": round(segments * (pictures - 1) / sec, 3), "qp": qp,
             "what": f"{segments} GOP segments of {width}x{height} analysed concurrently on one GPU, aggregate P pictures per second"}
 
 

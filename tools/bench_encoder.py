@@ -54,14 +54,14 @@ def run(w=1920, h=1080, n=6, qp=32, lanes=1, spin_us=200, verbose=False, specula
             "p_picture_us_per_round_trip": per[-1]["us_per_round_trip"] if p_ms else None}
 
 
-def run_segments(w=1920, h=1080, n=4, qp=32, segments=8):
+def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0):
     """`segments` independent GOP segments (each its own encoder, I picture first) encoded at the same time on one GPU, one
     host thread per segment (the C call releases the interpreter lock): whole-job pictures per second over all pictures,
     and over the P pictures alone (after a barrier behind the I pictures)"""
     import threading
     from x265_amd.encoder import Encoder
     clips = [clip(w, h, n, seed=7 + s) for s in range(segments)]
-    encs = [Encoder(w, h, qp, spin_us=0) for _ in range(segments)]
+    encs = [Encoder(w, h, qp, spin_us=spin_us, workers=workers) for _ in range(segments)]
     errs, marks = [], {}
     gate = threading.Barrier(segments + 1)
 
@@ -93,12 +93,16 @@ def run_segments(w=1920, h=1080, n=4, qp=32, segments=8):
         e.close()
     if errs:
         return {"error": errs[0]}
-    return {"segments": segments, "pictures_per_segment": n, "encode_fps": round(segments * n / (t1 - t0), 2),
+    return {"segments": segments, "pictures_per_segment": n, "workers": workers, "spin_us": spin_us, "encode_fps": round(segments * n / (t1 - t0), 2),
             "p_pictures_per_s": round(segments * (n - 1) / (t1 - marks["i_done"]), 2), "i_pictures_s": round(marks["i_done"] - t0, 3)}
 
 
 def main():
     a = sys.argv[1:]
+    if a and a[0] == "segments":      # segments N PICTURES WORKERS SPIN_US
+        n, pics, workers, spin = (int(v) for v in a[1:5])
+        print(json.dumps(run_segments(1920, 1080, pics, 32, n, workers or None, spin)))
+        return
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
     lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (1, 200)
     spec = int(a[6]) if len(a) >= 7 else None

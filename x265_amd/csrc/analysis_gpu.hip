@@ -1578,6 +1578,14 @@ xmi_analysis *xmi_analysis_create(int width, int height)
 
 void xmi_analysis_destroy(xmi_analysis *a) { delete a; }
 
+int xmi_analysis_workers(xmi_analysis *a, int workers)
+{
+    XMI_ARG(a, "xmi_analysis_workers: null handle");
+    XMI_ARG(workers >= 0 && workers <= 1024, "xmi_analysis_workers: %d threads", workers);
+    a->an.workers = workers;
+    return XMI_OK;
+}
+
 int xmi_analysis_speculate(xmi_analysis *a, int level)
 {
     XMI_ARG(a, "xmi_analysis_speculate: null handle");
@@ -1710,6 +1718,14 @@ int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us)
     }
     if (rc == XMI_OK) e->enc.analyser().spin_us = spin_us;
     return rc;
+}
+
+int xmi_encoder_workers(xmi_encoder *e, int workers)
+{
+    XMI_ARG(e, "xmi_encoder_workers: null handle");
+    XMI_ARG(workers >= 0 && workers <= 1024, "xmi_encoder_workers: %d threads", workers);
+    e->enc.analyser().workers = workers;
+    return XMI_OK;
 }
 
 int xmi_encoder_speculate(xmi_encoder *e, int level)

@@ -30,7 +30,7 @@ def align_frame(y, u, v, width, height):
 class Encoder:
     """one encoder instance; pictures are (y, u, v) uint8 arrays of the display size given to the constructor"""
 
-    def __init__(self, width, height, qp, strong_intra_smoothing=False, lanes=None, spin_us=0, speculate=None):
+    def __init__(self, width, height, qp, strong_intra_smoothing=False, lanes=None, spin_us=0, speculate=None, workers=None):
         self.lib = load()
         self.width, self.height = width, height
         self.W, self.H = (width + 63) // 64 * 64, (height + 63) // 64 * 64
@@ -49,6 +49,10 @@ class Encoder:
         if lanes is not None or spin_us:
             rc = self.lib.xmi_encoder_configure(self.handle, lanes or 1, spin_us)
             if rc != 0:
+                raise XmiError(self.lib.xmi_last_error().decode())
+        if workers is not None:
+            self.lib.xmi_encoder_workers.argtypes = [C.c_void_p, C.c_int]
+            if self.lib.xmi_encoder_workers(self.handle, workers) != 0:
                 raise XmiError(self.lib.xmi_last_error().decode())
         if speculate is not None:
             self.lib.xmi_encoder_speculate.argtypes = [C.c_void_p, C.c_int]
