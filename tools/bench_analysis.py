@@ -96,6 +96,14 @@ def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=
                     if cnt:
                         print(f"{n}x{n} {name}: {cnt} workgroups, us each: merge selection {m / cnt / 100:.2f}, search {sr / cnt / 100:.2f}, "
                               f"chain {ch / cnt / 100:.2f}", file=sys.stderr)
+        if hasattr(L, "xmi_debug_search_ticks"):
+            stt = (C.c_uint64 * 10)()
+            L.xmi_debug_search_ticks(stt)
+            for i, n in enumerate((32, 64)):
+                cnt = stt[i * 5 + 4]
+                if cnt:
+                    print(f"workgroup search {n}x{n}: {cnt} searches, us each: first stage {stt[i * 5] / cnt / 100:.2f}, diamond walk {stt[i * 5 + 1] / cnt / 100:.2f}, "
+                          f"sub-pel rounds {stt[i * 5 + 2] / cnt / 100:.2f}; integer SADs {stt[i * 5 + 3] / cnt:.1f}", file=sys.stderr)
         if hasattr(L, "xmi_debug_clock_ticks"):
             ct = (C.c_uint64 * 2)()
             L.xmi_debug_clock_ticks(ct)

@@ -1609,6 +1609,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 }
 
 #ifdef XMI_EXP_ROUND_TIMING
+int xmi_debug_search_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_search_ticks), sizeof(unsigned long long) * 10) == hipSuccess ? 0 : -1; }
 int xmi_debug_quad_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_ticks), sizeof(unsigned long long) * 6) == hipSuccess ? 0 : -1; }
 int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }

@@ -68,6 +68,9 @@ __device__ __forceinline__ u32 row_sum(u32 x)
 // zero_fn (optional): the caller's answer to "was (0,0) tested already?", asked for only when it matters - when (0,0) would
 // beat the predictor's integer position - instead of rq.zero_mv_tested; every thread that shares the block calls it together.
 // n_int_sads of the result then counts (0,0) only when it was asked.
+#ifdef XMI_EXP_ROUND_TIMING
+__device__ unsigned long long g_search_ticks[2][5];      // workgroup searches, 32x32 | 64x64: first stage, diamond walk, sub-pel rounds, integer SADs, count
+#endif
 template <int N, bool SURF, bool PACK = false, int WAVES = 1, class ZeroFn = std::nullptr_t>
 __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &rq, int idx, int wave_lane, uint8_t *s_win, u32 *s_red = nullptr,
                                        ZeroFn zero_fn = nullptr)
@@ -201,6 +204,9 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         return LEVEL == 0 ? (u32)p.sad8[e] : LEVEL == 1 ? (u32)p.sad16[e] : LEVEL == 2 ? p.sad32[e] : p.sad64[e];
     };
 
+#ifdef XMI_EXP_ROUND_TIMING
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- predictor choice, (0,0) and the integer start point ----
     const int passes = ((abs(rq.mvp[0][0] - rq.mvp[1][0]) >> 2) + (abs(rq.mvp[0][1] - rq.mvp[1][1]) >> 2) > 4) ? 2 : 1;
     u32 s5[5];
@@ -248,6 +254,9 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
             bmy = omy * 4;
         }
     }
+#ifdef XMI_EXP_ROUND_TIMING
+    const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- small diamond ----
     const int dia4x[4] = { 0, 0, -1, 1 }, dia4y[4] = { -1, 1, 0, 0 };
     for (int i = 0; i < p.me_range; i++) {
@@ -301,6 +310,9 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         bmx = clip3(mnx, mxy, bmx);
         bmy = clip3(mny, mxy, bmy);
     }
+#ifdef XMI_EXP_ROUND_TIMING
+    const unsigned long long st2 = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- half- and quarter-pel rounds ----
     bcost = 0x7fffffffu;
     const int dia9x[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 }, dia9y[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 };
@@ -332,6 +344,13 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         bmy += bdy;
         step >>= 1;
     }
+#ifdef XMI_EXP_ROUND_TIMING
+    if (WAVES == 4 && wave_lane == 0) {
+        const unsigned long long st3 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *t = g_search_ticks[N == 64];
+        atomicAdd(&t[0], st1 - st0), atomicAdd(&t[1], st2 - st1), atomicAdd(&t[2], st3 - st2), atomicAdd(&t[3], (unsigned long long)n_int), atomicAdd(&t[4], 1ull);
+    }
+#endif
     if (wave_lane == 0 || (PACK && lane == 0)) {
         xmi_me_result out;
         out.mv[0] = (int16_t)bmx;
