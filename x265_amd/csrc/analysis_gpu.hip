@@ -537,6 +537,7 @@ struct __align__(16) IntraLds {
     // quads: the 8x8 area(s) being reconstructed, their outer samples, the samples of the PU in hand, the modes so far
     uint8_t area[2][64], outer[2][40], qref[2][20];
     int qmode[4];
+    double qcost[36];                 // quads: cost of every mode of the PU in hand
 };
 
 // sample at (xx, yy) relative to the origin of an 8x8 area: from its 33 outer samples, or from the area itself
@@ -737,8 +738,29 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
     if (tid == 0) atomicAdd(&g_quad_ticks[0], __builtin_amdgcn_s_memrealtime() - q0), atomicAdd(&g_quad_ticks[5], 1ull);
 #endif
     uint8_t *ref = L.ref[0];
-    const int my_mode = tid >> 2, my_row = tid & 3;      // the thread's share of every search
-    const int my_angle = my_mode > 1 && my_mode < 35 ? k_angle[my_mode] : 0, my_inv = my_mode > 1 && my_mode < 35 ? k_inv_angle[my_mode] : 0;
+    // The thread's share of every search: one row of one mode. Which neighbouring samples an angular mode reads for a position,
+    // and with what weight, depends on neither the PU nor the samples (xEncIntraPred: two samples of the main side - or of the
+    // other side projected onto it - blended by the fraction of (k + 1) angle): worked out once, as offsets from the top-left
+    // sample, for the thread's four positions. Bits 0..7 / 8..15: the two offsets (signed), 16..20: fraction, 21: the edge filter
+    // of the pure horizontal / vertical mode applies, 24..31: its sample's offset.
+    const int my_mode = tid >> 2, my_row = tid & 3;
+    uint32_t tap[4] = { 0, 0, 0, 0 };
+    if (my_mode > 1 && my_mode < 35) {
+        const int angle = k_angle[my_mode], inv = k_inv_angle[my_mode];
+        const bool hor = my_mode < 18;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int kk = hor ? x : my_row, xx = hor ? my_row : x;
+            const int delta = (kk + 1) * angle, idx = delta >> 5, fact = delta & 31, pos = xx + idx + 1;
+            auto off = [&](int q) {
+                if (q < 0) q = -((128 - q * inv) >> 8);       // projected side samples
+                return hor ? -q : q;
+            };
+            const bool edge = angle == 0 && xx == 0;
+            const int eo = hor ? kk + 1 : -(kk + 1);
+            tap[x] = (uint32_t)(off(pos) & 255) | ((uint32_t)(off(pos + 1) & 255) << 8) | ((uint32_t)fact << 16) | ((uint32_t)edge << 21) | ((uint32_t)(eo & 255) << 24);
+        }
+    }
     for (int k = 0; k < 4; k++) {
         const int ox = (k & 1) * 4, oy = (k >> 1) * 4;
         XMI_QSTAMP(q1);
@@ -773,48 +795,54 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
             int hd[4] = { 0, 0, 0, 0 };
             if (mode < 35) {
                 int d[4];
+                const uint8_t *tl = ref + 8;
 #pragma unroll
-                for (int x = 0; x < 4; x++) d[x] = (int)L.r.pix[(oy + row) * 8 + ox + x] - pred_sample<4>(ref, mode, my_angle, my_inv, row, x, dc, true);
+                for (int x = 0; x < 4; x++) {
+                    int v;
+                    if (mode < 2) {
+                        v = pred_sample<4>(ref, mode, 0, 0, row, x, dc, true);
+                    } else {
+                        const uint32_t t = tap[x];
+                        const int f = (int)((t >> 16) & 31);
+                        v = ((32 - f) * (int)tl[(int)(int8_t)(t & 255)] + f * (int)tl[(int)(int8_t)((t >> 8) & 255)] + 16) >> 5;
+                        if (t & (1u << 21)) v = min(255, max(0, v + (((int)tl[(int)(int8_t)(t >> 24)] - (int)tl[0]) >> 1)));
+                    }
+                    d[x] = (int)L.r.pix[(oy + row) * 8 + ox + x] - v;
+                }
                 const int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
                 hd[0] = a0 + a2, hd[1] = a1 + a3, hd[2] = a0 - a2, hd[3] = a1 - a3;
             }
             // the other direction across the four threads of the mode (signs and order of the outputs do not matter to the sum)
             int sum = 0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < 4; c++) {      // (the four threads of a mode are a DPP quad)
                 int v = hd[c];
-                const int o1 = __shfl_xor(v, 1);
+                const int o1 = __builtin_amdgcn_mov_dpp(v, 0xb1, 0xf, 0xf, true);      // quad_perm:[1,0,3,2]
                 v = (row & 1) ? o1 - v : v + o1;
-                const int o2 = __shfl_xor(v, 2);
+                const int o2 = __builtin_amdgcn_mov_dpp(v, 0x4e, 0xf, 0xf, true);      // quad_perm:[2,3,0,1]
                 v = (row & 2) ? o2 - v : v + o2;
                 sum += abs(v);
             }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
+            sum += __builtin_amdgcn_mov_dpp(sum, 0xb1, 0xf, 0xf, true);
+            sum += __builtin_amdgcn_mov_dpp(sum, 0x4e, 0xf, 0xf, true);
             sum >>= 1;
-            double best_cost = 1.7976931348623157e308;
-            int best_mode = 64;
             if (mode < 35 && row == 0) {
                 const double bits = mode == mpm0 ? 1.0 : (mode == mpm1 || mode == mpm2) ? 2.0 : 3.0;
-                best_cost = bits * j.sqrt_lambda + (double)(uint32_t)sum;
-                best_mode = mode;
+                L.qcost[mode] = bits * j.sqrt_lambda + (double)(uint32_t)sum;
             }
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) {
-                const double oc = __shfl_xor(best_cost, m);
-                const int om = __shfl_xor(best_mode, m);
-                if (oc < best_cost || (oc == best_cost && om < best_mode)) best_cost = oc, best_mode = om;
-            }
-            if (lane == 0) L.best_cost[wave] = best_cost, L.best_mode[wave] = best_mode;
         }
         __syncthreads();
         XMI_QSTAMP(q3);
         if (wave == 0) {
-            double bc = L.best_cost[0];
-            int mode = L.best_mode[0];
+            // first minimum in mode order: lane m holds mode m's cost and looks at every other one (broadcast reads)
+            const double mine = lane < 35 ? L.qcost[lane] : 1.7976931348623157e308;
+            bool first = lane < 35;
 #pragma unroll
-            for (int w = 1; w < 3; w++)      // modes 16 w .. 16 w + 15 were wavefront w's
-                if (L.best_cost[w] < bc || (L.best_cost[w] == bc && L.best_mode[w] < mode)) bc = L.best_cost[w], mode = L.best_mode[w];
+            for (int o = 0; o < 35; o++) {
+                const double oc = L.qcost[o];
+                first = first && !(oc < mine || (oc == mine && o < lane));
+            }
+            const int mode = __ffsll((long long)__ballot(first)) - 1;
             if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(ref, mode, lane / 4, lane % 4, dc, true);
             __builtin_amdgcn_wave_barrier();
             XMI_QSTAMP(q4);
