@@ -603,8 +603,8 @@ __device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob 
     for (int e = tid; e < N * N; e += 256) pr[e] = (uint8_t)pred_sample<N>(ref, mode, e / N, e % N, dc, N != 32);
     __syncthreads();
     uint32_t sum, ssd;
-    chain_unit<N, true, N == 4>(L.r, p.src[0] + (size_t)j.y0 * p.width + j.x0, p.width, pr, N, j.qp, reinterpret_cast<int16_t *>(p.out + j.out_level),
-                                p.out + j.out_rec, nullptr, N, sum, ssd);
+    // (the source block is in LDS since the search: wavefront 0's copy, rows N apart - no second trip to memory for it)
+    chain_unit<N, true, N == 4>(L.r, L.r.win, N, pr, N, j.qp, reinterpret_cast<int16_t *>(p.out + j.out_level), p.out + j.out_rec, nullptr, N, sum, ssd);
     if (tid == 0) {
         IntraHead *h = reinterpret_cast<IntraHead *>(p.out + j.out_head);
         h->best_mode = mode, h->sum = sum, h->ssd = ssd;
