@@ -76,6 +76,15 @@ def test_speculation_depth_does_not_change_the_stream():
         assert encode_clip(pics, 416, 240, 27, speculate=level) == a, level
 
 
+def test_worker_threads_do_not_change_the_stream():
+    """the CTU rows as fibers of one or two host threads instead of one thread per row"""
+    from x265_amd.encoder import encode_clip
+    pics = clip(416, 240, 3)
+    a = encode_clip(pics, 416, 240, 32)
+    for workers, spin in ((1, 0), (2, 40)):
+        assert encode_clip(pics, 416, 240, 32, workers=workers, spin_us=spin) == a, workers
+
+
 def test_lanes_and_polling_do_not_change_the_stream():
     from x265_amd.encoder import encode_clip
     pics = clip(416, 240, 3)
