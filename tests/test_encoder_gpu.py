@@ -76,6 +76,17 @@ def test_speculation_depth_does_not_change_the_stream():
         assert encode_clip(pics, 416, 240, 27, speculate=level) == a, level
 
 
+def test_gop_segments_on_two_ranks_with_the_library_encoder():
+    """tools/encode_segments.py, two ranks (gloo rendezvous, both on this box's GPU), each encoding its GOP with the library's
+    own encoder: every gathered segment is the stream recorded for it (tests/golden/segment_md5.json), at 416x240 and for two
+    2-picture segments of the 3840x2160 fixture."""
+    from tests.test_segments_gloo import UHD, run_segment_encode
+    res = run_segment_encode("own", 2)
+    assert res["parity"] == "identical" and res["ranks"] == 2 and set(res["segments"]) == {"0-8", "8-16"}
+    res = run_segment_encode("own", 2, clip=UHD)
+    assert res["parity"] == "identical" and res["ranks"] == 2 and set(res["segments"]) == {"0-2", "2-4"}
+
+
 def test_worker_threads_do_not_change_the_stream():
     """the CTU rows as fibers of one or two host threads instead of one thread per row"""
     from x265_amd.encoder import encode_clip

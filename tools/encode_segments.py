@@ -59,6 +59,15 @@ def picture_sizes(stream):
 
 
 def encode(variant, frames, w, h, qp, workdir):
+    if variant == "own":      # the library's own encoder on this rank's GPU: nothing of the reference runs
+        from x265_amd.encoder import encode_clip
+        pics = []
+        for fr in frames:
+            a = np.frombuffer(fr, np.uint8)
+            pics.append((a[:w * h].reshape(h, w), a[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), a[w * h * 5 // 4:].reshape(h // 2, w // 2)))
+        t0 = time.perf_counter()
+        data = encode_clip(pics, w, h, qp, intra_period=100000)
+        return data, time.perf_counter() - t0
     exe = os.path.join(ROOT, "oracle", "_ref", f"x265_{variant}")
     yuv, out = os.path.join(workdir, "seg.yuv"), os.path.join(workdir, "seg.265")
     with open(yuv, "wb") as f:
@@ -72,7 +81,7 @@ def encode(variant, frames, w, h, qp, workdir):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variant", default="refsse", help="oracle/_ref/x265_<variant>: refsse (CPU), gpu_me, gpu_planes, gpu_all")
+    ap.add_argument("--variant", default="refsse", help="own = the library's encoder; else oracle/_ref/x265_<variant>: refsse (CPU), gpu_me, gpu_planes, gpu_all")
     ap.add_argument("--width", type=int, default=416)
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--frames", type=int, default=16)
