@@ -30,6 +30,7 @@ PAD = 80                   # the reference pads luma by MAX_CU_SIZE+16 (inc/conf
 
 ENCODE_FRAMES = 64      # the encode legs (this library's encoder, and the reference's on the host cores) use the published
                         # configuration: 1920x1080, 64 pictures, IPPP, QP 32
+UHD_FRAMES = 6          # pictures of the 3840x2160 encode legs
 # host threads per encoder / analyser when eight of them share one GPU and the process's cores (xmi_encoder_workers): a
 # handle's CTU rows are fibers of that many threads, and 8 x 2 of them fit the 16 cores a GPU's share of a host has
 SEGMENT_WORKERS = 2
@@ -94,6 +95,9 @@ def cpu_baseline(cur, refp, rng, budget_s=12.0):
         enc = cpu_encoder_fps()
         if enc:
             out["encoder"] = enc
+        uhd = cpu_encoder_fps(UHD_FRAMES, width=3840, height=2160, seed=1234)      # the clip of encode.uhd
+        if uhd:
+            out["encoder_2160p"] = uhd
         return out
     finally:
         os.unlink(path)
@@ -111,12 +115,13 @@ def cpu_primitives(ref_lib, seconds_per_case=0.25):
     return {r["cpu"]: {"Mblk_per_s": r["Mblk_per_s"], "GBps": r["GBps"], "kind": r["kind"]} for r in rows}
 
 
-def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32):
+def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32, width=1920, height=1080, seed=7):
     """The reference's encoder (its own sources compiled into oracle/_ref/x265_refsse; the 7 NASM-only SATD/SSD entries
     come from the restatement) on a short 1080p IPPP clip, wall clock of the whole run: one thread, and the reference's
     own OpenMP row threads (x265_refsse_mt, -t up to its limit of 16) on the host cores this process may use."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "x265_refsse")
-    exe_mt = os.path.join(ROOT, "oracle", "_ref", "x265_refsse_mt")
+    big = height > 1088          # beyond the reference's MAX_HEIGHT: the build of its sources with that constant raised (oracle/Makefile)
+    exe = os.path.join(ROOT, "oracle", "_ref", "x265_refsse_2160p" if big else "x265_refsse")
+    exe_mt = os.path.join(ROOT, "oracle", "_ref", "x265_refsse_2160p_mt" if big else "x265_refsse_mt")
     gen = os.path.join(ROOT, "tools", "gen_yuv.py")
     if not (os.path.exists(exe) and os.path.exists(gen)):
         return None
@@ -127,10 +132,10 @@ def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32):
     cores = max(1, min(cores, int(os.environ.get("OMP_NUM_THREADS", cores) or cores)))
     with tempfile.TemporaryDirectory() as d:
         yuv, out = os.path.join(d, "in.yuv"), os.path.join(d, "out.265")
-        subprocess.run([sys.executable, gen, "1920", "1080", str(frames), "7", yuv], check=True, timeout=300)
+        subprocess.run([sys.executable, gen, str(width), str(height), str(frames), str(seed), yuv], check=True, timeout=300)
 
         def run(binary, threads):
-            cmd = [binary, "-i", yuv, "-o", out, "-w", "1920", "-h", "1080", "-f", str(frames), "-q", str(qp), "-ip", "100",
+            cmd = [binary, "-i", yuv, "-o", out, "-w", str(width), "-h", str(height), "-f", str(frames), "-q", str(qp), "-ip", "100",
                    "-sceneChange", "0", "-t", str(threads)]
             t0 = time.perf_counter()
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -142,7 +147,7 @@ def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32):
         if not one:
             return None
         enc = {"fps": one[0], "frames": frames, "qp": qp, "threads": 1, "bytes": one[1],
-               "what": "1920x1080 synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
+               "what": f"{width}x{height} synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
         threads = min(16, cores)
         if os.path.exists(exe_mt) and threads > 1:
             many = run(exe_mt, threads)
@@ -215,6 +220,10 @@ def encode_rate(L, qp=32, segments=True):
         out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
         if segments:
             out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=SEGMENT_WORKERS)
+            # the 3840x2160 configuration (coded 3840x2176), a short clip: to be read beside cpu_baseline.encoder_2160p
+            uhd = bench_encoder.run(3840, 2160, UHD_FRAMES, qp)
+            out["uhd"] = {k: uhd[k] for k in ("what", "encode_fps", "pictures", "bytes", "md5", "i_picture_ms", "p_picture_ms", "p_stage_ms",
+                                              "round_trips_per_p_picture") if k in uhd}
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}
