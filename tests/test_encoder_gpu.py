@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gen_yuv import frame  # noqa: E402
 
+from tests.prereq import needs_ref  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))
 SEED = {416: 1234, 1920: 7}
@@ -51,6 +53,27 @@ def test_scene_change_detection_of_the_command_line():
     assert len(stream) == GOLD[key]["bytes"], f"{len(stream)} bytes, recorded {GOLD[key]['bytes']}"
     assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
     assert stream.count(b"\x00\x00\x00\x01\x40\x01") == 2, "two I pictures, each with its parameter sets"
+
+
+@needs_ref("x265_refsse", how="make -C oracle enc")
+def test_strong_intra_smoothing_and_short_intra_period_against_the_reference_build(tmp_path):
+    """-sis (bStrongIntraSmoothing: the SPS flag and the bilinear smoothing of 32x32 neighbours) with an I picture every third
+    picture, a configuration no recorded stream covers: the reference-control-flow build runs beside the library on the box."""
+    import subprocess
+    from x265_amd.encoder import encode_clip
+    w, h, n, qp = 832, 480, 6, 36
+    rng = np.random.default_rng(11)
+    pics = [frame(w, h, t, rng) for t in range(n)]
+    yuv, out = str(tmp_path / "in.yuv"), str(tmp_path / "ref.265")
+    with open(yuv, "wb") as f:
+        for p in pics:
+            f.write(b"".join(c.tobytes() for c in p))
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "x265_refsse"), "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(n), "-q", str(qp),
+                    "-ip", "3", "-sceneChange", "0", "-t", "1", "-sis"], check=True, capture_output=True, timeout=300)
+    ref = open(out, "rb").read()
+    ours = encode_clip(pics, w, h, qp, intra_period=3, strong_intra_smoothing=True)
+    assert len(ours) == len(ref) and ours == ref
+    assert encode_clip(pics, w, h, qp, intra_period=3, strong_intra_smoothing=False) != ours, "the switch changes the stream (SPS flag)"
 
 
 def test_2160p_segments_equal_the_recorded_streams():
