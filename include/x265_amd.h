@@ -385,9 +385,10 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
  * motion search, prediction, transform chains, distortions - is batched over the rows that are ready and runs on the GPU.
  *
  * xmi_analysis_create: width, height = coded size (multiples of 64). NULL on failure (xmi_last_error()).
- * xmi_analysis_configure: lanes (1..8) = groups the CTU rows are dealt to (row y -> lane y % lanes). Each lane batches the
- *   requests of its rows and makes its own round trips to the GPU, on a stream of its own, so the host work of one lane
- *   overlaps the GPU time of another. spin_us: how long the host threads of the loop poll for a result before they go to
+ * xmi_analysis_configure: lanes (1..8) = coordinators, each with a stream and buffers of its own. All of them serve all CTU
+ *   rows: one takes the requests that are posted when it looks and makes a round trip to the GPU with them; with more than
+ *   one, the requests of rows that were still busy on the host go out with the next coordinator while the first round trip
+ *   is under way. spin_us: how long the host threads of the loop poll for a result before they go to
  *   sleep (a round trip takes about 30 us, waking a sleeping thread 10 more); 0, the default, sleeps at once and is the
  *   choice when several handles share the host's cores. Results depend on neither. Not while a picture is in flight.
  *   (The reference has no counterpart: its -t option sets the number of row threads, src/encode.cpp:5800-5860.)

@@ -66,7 +66,7 @@ def run_segments(width=1920, height=1080, qp=32, pictures=4, segments=4, lanes=N
             "what": f"{segments} GOP segments of {width}x{height} analysed concurrently on one GPU, aggregate P pictures per second"}
 
 
-def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=None, spin_us=200, lib=None, speculate=None):
+def run(width=1920, height=1080, qp=32, pictures=6, seed=7, lanes=2, spin_us=200, lib=None, speculate=None):
     from x265_amd import capi
     from tests import ctu_trace as T
     L = lib or capi.load()
@@ -144,4 +144,4 @@ if __name__ == "__main__":
     if a.segments > 1:
         print(json.dumps(run_segments(a.width, a.height, a.qp, a.pictures, a.segments, a.lanes, a.spin_us or 0, speculate=a.speculate)))
     else:
-        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes, spin_us=200 if a.spin_us is None else a.spin_us, speculate=a.speculate)))
+        print(json.dumps(run(a.width, a.height, a.qp, a.pictures, lanes=a.lanes or 2, spin_us=200 if a.spin_us is None else a.spin_us, speculate=a.speculate)))

@@ -19,7 +19,7 @@ def clip(w, h, n, seed=None):
     return [frame(w, h, t, rng) for t in range(n)]
 
 
-def run(w=1920, h=1080, n=6, qp=32, lanes=1, spin_us=200, verbose=False, speculate=None):
+def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, speculate=None):
     """one picture stream: the clip of the CPU baseline (tools/gen_yuv.py, seed 7 at 1080p), picture 0 intra; wall clock of the
     encode calls (pictures resident in host memory; the call uploads them)"""
     import hashlib
@@ -104,7 +104,7 @@ def main():
         print(json.dumps(run_segments(1920, 1080, pics, 32, n, workers or None, spin)))
         return
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
-    lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (1, 200)
+    lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (2, 200)
     spec = int(a[6]) if len(a) >= 7 else None
     print(json.dumps(run(w, h, n, qp, lanes, spin, verbose=True, speculate=spec)))
     from x265_amd import capi

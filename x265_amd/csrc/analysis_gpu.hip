@@ -1163,7 +1163,7 @@ public:
         XMI_ARG(nlanes >= 1 && nlanes <= kMaxLanes, "analysis: %d lanes (1..%d)", nlanes, kMaxLanes);
         release_lanes();
         lanes = nlanes;
-        lane_rows = (h / 64 + lanes - 1) / lanes;
+        lane_rows = h / 64;                   // every lane may be handed the requests of all rows
         max_cu = 85 * lane_rows;              // per CTU row and round at most every CU of a CTU: 64 + 16 + 4 + 1
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);

@@ -262,7 +262,9 @@ struct Row {
     // lane's `running`; the lane's coordinator reads the slots of the rows it finds pending, and lowers `pending` when the
     // answers are in place. Only a waiter whose polling time has run out takes the mutex, to sleep.
     std::atomic<bool> pending{ false };
-    bool in_flight = false;     // (coordinator only) ... that is part of the call its lane is making right now
+    std::atomic<bool> in_flight{ false };      // ... that a coordinator has taken into the call it is making
+    int served_by = -1;         // lane whose buffers hold the answers the row is working on
+    void release_answers();
     CuEval *req_cu[85] = {};
     int n_req_cu = 0;
     bool req_chroma = false;     // ... that is part of the call its lane is making right now
@@ -324,14 +326,18 @@ struct Row {
     void make_fiber();
 };
 
-// Rows are dealt to lanes (row y -> lane y % lanes). A lane is the unit of one round trip: its rows block, their requests go to
-// the evaluator together, they wake together - while the rows of the other lanes are busy on the host or waiting for
-// their own round trip, so that host work and evaluator latency overlap.
+// A lane is a coordinator with evaluator resources of its own. All lanes serve all rows: a coordinator takes the requests that
+// are posted when it looks, sends them to the evaluator in one call and hands the answers back; with more than one, the rows
+// that were still busy on the host when one call left go out with the next coordinator's call while the first is under
+// way, so a row's cycle is the evaluator's latency plus its own host work, not the slowest row's. The counters of the
+// hand-over are lane 0's. The answers of a call live in the lane's buffers until its next call: a coordinator does not
+// call again while a row still reads (readers).
 struct Lane {
     std::condition_variable cv_main;
-    std::atomic<int> running{ 0 };      // rows of the lane that are busy on the host
-    std::atomic<int> posted{ 0 };       // rows of the lane with a request the coordinator has not picked up yet
+    std::atomic<int> running{ 0 };      // rows that are busy on the host
+    std::atomic<int> posted{ 0 };       // rows with a request no coordinator has picked up yet
     std::atomic<int> finished{ 0 };
+    std::atomic<int> readers{ 0 };      // rows still working on the answers of this lane's last call
     int rows = 0;
 };
 
@@ -341,6 +347,7 @@ struct Shared {
     std::atomic<int> sleepers{ 0 };     // workers asleep on cv_rows: a round that finds none wakes nobody (no system call)
     std::atomic<int> error{ 0 };
     int spin_us = 0;                // how long a waiter polls before it blocks
+    int grace_us = 6;               // how long a polling coordinator waits for the rows still busy before it goes without them
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
     bool defer_chroma = true;       // a CTU's chroma requests travel with the next CTU's first luma request
     std::deque<Lane> lanes;
@@ -788,7 +795,7 @@ void Row::ctu_done(int xp)
         Row &below = S.rows[y + 1];
         const int wanted = below.need.load(std::memory_order_relaxed);
         if (wanted >= 0 && S.done[y] >= wanted) {
-            S.lanes[(y + 1) % S.lanes.size()].running++;      // on the waiter's behalf, before it can ask for anything
+            S.lanes[0].running++;      // on the waiter's behalf, before it can ask for anything
             below.need.store(-1, std::memory_order_release);
             if (S.sleepers.load(std::memory_order_relaxed) > 0) S.cv_rows.notify_all();
         }
@@ -847,18 +854,25 @@ static inline bool poll_until(int spin_us, const std::function<bool()> &ready)
     }
 }
 
+void Row::release_answers()
+{
+    if (served_by >= 0) sh->lanes[served_by].readers.fetch_sub(1, std::memory_order_acq_rel);
+    served_by = -1;
+}
+
 void Row::post_and_wait()
 {
     busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_resume).count();
     requests++;
-    Lane &ln = sh->lanes[y % sh->lanes.size()];
+    release_answers();
+    Lane &ln = sh->lanes[0];
     // `pending` goes up last: a coordinator that sees it finds the two counters already moved
     ln.posted.fetch_add(1, std::memory_order_acq_rel);
     const bool last = ln.running.fetch_sub(1, std::memory_order_acq_rel) == 1;
     pending.store(true, std::memory_order_release);
-    if (last) {      // the last busy row of the lane: its coordinator may be asleep
+    if (last) {      // the last busy row: coordinators may be asleep
         { std::lock_guard<std::mutex> lk(sh->m); }
-        ln.cv_main.notify_one();
+        ln.cv_main.notify_all();
     }
     block(kAnswers);
     t_resume = std::chrono::steady_clock::now();
@@ -1158,8 +1172,9 @@ void Row::run()
                 std::unique_lock<std::mutex> lk(S.m);
                 if (S.done[y - 1] < need) {
                     this->need.store(need, std::memory_order_relaxed);
-                    Lane &ln = S.lanes[y % S.lanes.size()];
-                    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
+                    release_answers();
+                    Lane &ln = S.lanes[0];
+                    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_all();
                     lk.unlock();
                     const auto t0 = std::chrono::steady_clock::now();
                     block(kRowAbove);
@@ -1274,9 +1289,11 @@ void Row::run()
     }
     S.an->frac_bits[y] = rate.frac;
     std::lock_guard<std::mutex> lk(S.m);
-    Lane &ln = S.lanes[y % S.lanes.size()];
+    release_answers();
+    Lane &ln = S.lanes[0];
     ln.finished.fetch_add(1);
-    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_one();
+    ln.running.fetch_sub(1);
+    ln.cv_main.notify_all();
 }
 
 }  // namespace
@@ -1341,13 +1358,14 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     init_contexts(intra ? 2 : 1, qp, S.start.m);
     S.rows = std::deque<Row>(rows_);
     S.spin_us = spin_us;
+    S.grace_us = grace_us;
     S.speculate = speculate;
     S.defer_chroma = speculate != 0;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
     S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {
         S.rows[y].sh = &S, S.rows[y].y = y;
-        S.lanes[y % nl].rows++, S.lanes[y % nl].running++;
+        S.lanes[0].rows++, S.lanes[0].running++;
     }
     // Worker threads: one per CTU row while the host has cores for them, fewer otherwise (a core is left to each coordinator).
     // Worker w runs the rows w, w + workers, ... as fibers, going round those that can go on; when none can for the polling
@@ -1386,9 +1404,11 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     threads.reserve(nw + nl);
     for (int w = 0; w < nw; w++) threads.emplace_back(work, w);
 
-    // one coordinator per lane: when none of its rows is busy on the host, whatever they asked for goes out in one call
+    // A coordinator goes when something is posted and nobody reads its last answers any more - at once when no row is busy on
+    // the host, else (polling configurations only: a sleeping coordinator is woken when the last busy row posts) after a short
+    // wait for the rows that are about to post, so that they share the call.
     auto coordinate = [&S, &ev, &out, nl](int lane) {
-        Lane &ln = S.lanes[lane];
+        Lane &ln = S.lanes[0], &mine = S.lanes[lane];
         std::vector<CuEval *> cu;
         std::vector<ChromaEval *> chroma;
         std::vector<IntraEval *> pu;
@@ -1396,13 +1416,32 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
         std::vector<IntraQuadEval *> quads;
         std::vector<IntraChromaQuadEval *> cquads;
         std::vector<Row *> served;
-        // nothing of the lane is busy on the host, and there is something to do about it
-        auto ready = [&] {
-            return ln.running.load(std::memory_order_acquire) == 0 &&
-                   (ln.posted.load(std::memory_order_acquire) > 0 || ln.finished.load() == ln.rows || S.error.load() != 0);
-        };
+        auto over = [&] { return ln.finished.load() == ln.rows || S.error.load() != 0; };
+        auto idle = [&] { return ln.running.load(std::memory_order_acquire) == 0; };
+        auto work = [&] { return ln.posted.load(std::memory_order_acquire) > 0 && mine.readers.load(std::memory_order_acquire) == 0; };
+        auto ready = [&] { return idle() && (work() || over()); };
         for (;;) {
-            if (!poll_until(S.spin_us, ready)) {
+            bool go = false;
+            if (S.spin_us > 0 && nl > 1) {
+                const auto t0 = std::chrono::steady_clock::now();
+                auto seen = t0;
+                bool waiting = false;
+                for (;;) {
+                    if (ready()) { go = true; break; }
+                    const auto now = std::chrono::steady_clock::now();
+                    if (work()) {
+                        if (!waiting) waiting = true, seen = now;
+                        if (now - seen > std::chrono::microseconds(S.grace_us)) { go = true; break; }
+                    } else {
+                        waiting = false;
+                    }
+                    if (now - t0 > std::chrono::microseconds(S.spin_us)) break;
+                    __builtin_ia32_pause();
+                }
+            } else {
+                go = poll_until(S.spin_us, ready);
+            }
+            if (!go) {
                 std::unique_lock<std::mutex> lk(S.m);
                 ln.cv_main.wait(lk, ready);
             }
@@ -1410,8 +1449,11 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
             // the rows this call serves: a row that another lane's progress wakes during the call asks for the next one
             cu.clear(), chroma.clear(), pu.clear(), ichroma.clear(), quads.clear(), cquads.clear(), served.clear();
             for (Row &r : S.rows) {
-                if (r.y % nl != lane || r.in_flight || !r.pending.load(std::memory_order_acquire)) continue;
-                r.in_flight = true;
+                if (!r.pending.load(std::memory_order_acquire) || r.in_flight.exchange(true, std::memory_order_acq_rel)) continue;
+                if (!r.pending.load(std::memory_order_acquire)) {      // answered by another coordinator between the two looks
+                    r.in_flight.store(false, std::memory_order_release);
+                    continue;
+                }
                 ln.posted.fetch_sub(1, std::memory_order_acq_rel);
                 served.push_back(&r);
                 for (int i = 0; i < r.n_req_cu; i++) cu.push_back(r.req_cu[i]);
@@ -1434,16 +1476,19 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
             if (rc && !S.error) S.error = rc;
             for (Row *r : served) {
                 ln.running.fetch_add(1, std::memory_order_acq_rel);
-                r->in_flight = false;
+                r->served_by = lane;
+                mine.readers.fetch_add(1, std::memory_order_acq_rel);
+                // `pending` falls before the claim: a coordinator that looks in between finds the row claimed and leaves it
                 r->pending.store(false, std::memory_order_release);
+                r->in_flight.store(false, std::memory_order_release);
             }
             {
                 std::lock_guard<std::mutex> lk(S.m);      // also orders the stores above before the wake-up of a sleeping row
                 out.evaluator_calls++, out.cu_requests += cu.size() + pu.size() + quads.size(), out.chroma_requests += chroma.size() + ichroma.size() + cquads.size();
                 if (S.error) {       // an error ends the picture: rows waiting for a neighbour leave as well
                     for (Row &r : S.rows)
-                        if (r.need.load() >= 0) S.lanes[r.y % nl].running.fetch_add(1), r.need.store(-1);
-                    for (Lane &o : S.lanes) o.cv_main.notify_one();
+                        if (r.need.load() >= 0) ln.running.fetch_add(1), r.need.store(-1);
+                    ln.cv_main.notify_all();
                     S.cv_rows.notify_all();
                 }
             }

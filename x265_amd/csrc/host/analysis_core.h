@@ -194,9 +194,16 @@ public:
     std::vector<int32_t> count;
     std::vector<uint64_t> frac_bits;          // [row]
 
-    // Rows are dealt to `lanes` groups (row y -> y % lanes); each group makes its own round trips to the evaluator, so the
-    // host work of one group overlaps the evaluator latency of the others. Results do not depend on it.
+    // Coordinators, each with evaluator resources of its own (lane index of Evaluator::evaluate). All of them serve all rows:
+    // with more than one, the requests of rows that were still busy when one call left go out in the next coordinator's call
+    // while the first is under way. Results do not depend on it.
     int lanes = 1;
+    // (polling configurations, lanes > 1) how long a coordinator waits for the rows that are still busy on the host before it
+    // goes without them, microseconds
+#ifndef XMI_GRACE_US
+#define XMI_GRACE_US 6
+#endif
+    int grace_us = XMI_GRACE_US;
     // Rows waiting for results, and the coordinators waiting for their rows, poll for this many microseconds before they
     // block: a round trip is shorter than the time a sleeping thread needs to come back. 0 = block at once (the choice when
     // many analysers share the host's cores).
