@@ -403,6 +403,9 @@ void block_in(void *dst, int dst_pitch, const void *src, int src_pitch, int rows
     for (int i = 0; i < rows; i++) std::memcpy((char *)dst + (size_t)i * dst_pitch, (const char *)src + (size_t)i * src_pitch, bytes);
 }
 
+#ifdef XMI_EXP_MISS_STATS
+std::atomic<long> g_miss[4][2], g_miss_what[8], g_hit[4];
+#endif
 void Row::fill_request(CuEval &r, const Mv *cnd, int nm, int px, int py, int sz)
 {
     const int qmin_x = 4 * (min_ipel.x - 4), qmin_y = 4 * (min_ipel.y - 4), qmax_x = 4 * (max_ipel.x - 4), qmax_y = 4 * (max_ipel.y - 4);
@@ -490,6 +493,17 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         return r.amvp[0].x == cand[0].x && r.amvp[0].y == cand[0].y && r.amvp[1].x == cand[1].x && r.amvp[1].y == cand[1].y;
     };
     if (!(tree_ok[idx] && same_request(q))) {
+#ifdef XMI_EXP_MISS_STATS
+        g_miss[li][tree_ok[idx] ? 1 : 0]++;      // asked under a guess that did not come true | not asked for at all
+        if (tree_ok[idx]) {
+            int what = 0;      // which part of the request differs: 1 merge count, 2 a merge vector, 4 the AMVP pair
+            if (q.n_merge != nmerge) what |= 1;
+            for (int k = 0; k < nmerge && k < q.n_merge; k++)
+                if (q.merge_mv[k].x != mg[k].x || q.merge_mv[k].y != mg[k].y) what |= 2;
+            if (q.amvp[0].x != cand[0].x || q.amvp[0].y != cand[0].y || q.amvp[1].x != cand[1].x || q.amvp[1].y != cand[1].y) what |= 4;
+            g_miss_what[what]++;
+        }
+#endif
 #ifdef XMI_EXP_HOST_TIMING
         const uint64_t ts0 = tick();
 #endif
@@ -544,6 +558,9 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         evaluate_cus(spec_list.data(), (int)spec_list.size());
     } else if (px != asked_px || py != asked_py) {
         guess_hits++;      // not one of the asking CU's first children, whose neighbours were never in question
+#ifdef XMI_EXP_MISS_STATS
+        g_hit[li]++;
+#endif
     }
     tree_ok[idx] = false;
     // read after the evaluation: the call may have brought the chroma of the CTU to the left, which sets its skip flags
@@ -1500,6 +1517,15 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     for (std::thread &t : threads) t.join();
     out.row_busy_ns = out.row_requests = 0;
     for (const Row &r : S.rows) out.row_busy_ns += r.busy_ns, out.row_requests += r.requests;
+#ifdef XMI_EXP_MISS_STATS
+    if (!intra) {
+        std::fprintf(stderr, "requests that had to be made, by CU size 8/16/32/64 (not asked ahead | guess failed | answers used): ");
+        for (int l = 0; l < 4; l++) std::fprintf(stderr, "%ld|%ld|%ld  ", g_miss[l][0].exchange(0), g_miss[l][1].exchange(0), g_hit[l].exchange(0));
+        std::fprintf(stderr, "; failed guesses by what differed (1 count, 2 merge vector, 4 AMVP): ");
+        for (int k = 1; k < 8; k++) std::fprintf(stderr, "%d:%ld ", k, g_miss_what[k].exchange(0));
+        std::fprintf(stderr, "\n");
+    }
+#endif
 #ifdef XMI_EXP_HOST_TIMING
     {
         uint64_t c[4] = {};
