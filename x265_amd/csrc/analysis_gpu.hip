@@ -1186,11 +1186,7 @@ public:
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_out), out_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_flag), 256, flags));
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_jobs), l.h_jobs, 0));
-#ifdef XMI_EXP_DEV_OUT
-            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.g_out), out_bytes));
-#else
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_out), l.h_out, 0));
-#endif
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_flag), l.h_flag, 0));
             std::memset(l.h_out, 0, out_bytes);
             *l.h_flag = 0;
@@ -1527,19 +1523,11 @@ private:
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
         const auto t1 = std::chrono::steady_clock::now();
-#ifdef XMI_EXP_LDS_PAD
-        hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), XMI_EXP_LDS_PAD, R.st, p);
-#else
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
-#endif
         XMI_HIP(hipGetLastError());
         const auto t2 = std::chrono::steady_clock::now();
         const int wrc = wait_round(R, seq);
         if (wrc != XMI_OK) return wrc;
-#ifdef XMI_EXP_DEV_OUT
-        XMI_HIP(hipMemcpyAsync(h_out, R.g_out, out, hipMemcpyDeviceToHost, R.st));
-        XMI_HIP(hipStreamSynchronize(R.st));
-#endif
         const auto t3 = std::chrono::steady_clock::now();
 
         for (int i = 0; i < ncu; i++) {
