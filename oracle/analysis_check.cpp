@@ -487,6 +487,13 @@ void orc_encoder_sao_stats(void *hv, int32_t *out)
     std::memcpy(out, e.sao_statistics().data(), e.sao_statistics().size() * sizeof(xmi::encoder::SaoStats));
 }
 
+// the last picture after deblocking, before the SAO offsets (what the SAO statistics were taken on)
+void orc_encoder_deblocked(void *hv, uint8_t *y, uint8_t *u, uint8_t *v)
+{
+    const CpuFrameOps &o = static_cast<EncHandle *>(hv)->ops;
+    std::memcpy(y, o.plane[0].data(), o.plane[0].size()), std::memcpy(u, o.plane[1].data(), o.plane[1].size()), std::memcpy(v, o.plane[2].data(), o.plane[2].size());
+}
+
 void orc_encoder_reconstruction(void *hv, uint8_t *y, uint8_t *u, uint8_t *v)
 {
     const xmi::encoder::Encoder &e = static_cast<EncHandle *>(hv)->enc;

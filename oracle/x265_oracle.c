@@ -734,9 +734,14 @@ void orc_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const orc_deblock_par
 {
     const int W = p->width, H = p->height, bsw = W >> 3, qw = W >> 2;   /* QP table: log2_min_coding_block_size = 2 (src/encode.cpp:5060) */
     /* CTB by CTB in raster order, vertical edges of the CTB, then its horizontal edges shifted 8 samples to the left
-     * (ff_hevc_deblocking_filter_CTB, src/Deblock.cpp:244-342; every CTB is visited once by xDeblockFrame, :524-559) */
+     * (ff_hevc_deblocking_filter_CTB, src/Deblock.cpp:244-342). xDeblockFrame (:524-559) visits every CTB once when the
+     * picture has at least two CTB rows and columns: hls_filters (:512-522) filters CTB (x - 1, y - 1) when called for
+     * CTB (x, y) with x, y > 0, the last column and row from their neighbours, and the last CTB after the loop. With one
+     * CTB row or one CTB column hls_filters never does anything, and only the last CTB is filtered. */
+    const int cols = (W + 63) / 64, rows = (H + 63) / 64, only_last = (rows == 1) != (cols == 1);
     for (int y0 = 0; y0 < H; y0 += 64)
         for (int x0 = 0; x0 < W; x0 += 64) {
+            if (only_last && !(x0 == (cols - 1) * 64 && y0 == (rows - 1) * 64)) continue;
             int x_end = x0 + 64 > W ? W : x0 + 64;
             const int y_end = y0 + 64 > H ? H : y0 + 64;
             for (int x = x0 ? x0 : 8; x < x_end; x += 8)

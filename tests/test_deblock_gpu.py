@@ -55,10 +55,11 @@ def test_deblocking_replays_encoder_trace(L):
         assert (Y[:pad] == 99).all() and (Y[:, :pad] == 99).all() and (Y[:, pad + w:] == 99).all() and (U[:pad // 2] == 98).all()
 
 
-@pytest.mark.parametrize("w,h,seed", [(192, 128, 1), (448, 256, 2), (72, 40, 3), (1920, 1088, 4)])
+@pytest.mark.parametrize("w,h,seed", [(192, 128, 1), (448, 256, 2), (72, 40, 3), (1920, 1088, 4), (256, 64, 5), (64, 256, 6), (48, 48, 7)])
 def test_deblocking_matches_oracle(L, w, h, seed):
     """Seeded pictures (smooth ramps with block steps so that weak, strong and no filtering all occur), random
-    boundary strengths 0/1/2 on every segment, QP table 20..51, non-zero offsets."""
+    boundary strengths 0/1/2 on every segment, QP table 20..51, non-zero offsets. The sizes include pictures one CTB high
+    and one CTB wide, of which xDeblockFrame filters the last CTB only (src/Deblock.cpp:512-559)."""
     orc = O.load()
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w]
@@ -77,7 +78,8 @@ def test_deblocking_matches_oracle(L, w, h, seed):
     wy, wu, wv = y.copy(), u.copy(), v.copy()
     oprm = O.OrcDeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
     orc.orc_deblock_frame(O.p(wy), O.p(wu), O.p(wv), C.byref(oprm), O.p(vbs), O.p(hbs), O.p(qp))
-    assert (wy != y).sum() > w * h // 50 and (wu != u).sum() > 0
+    one_ctb = (w <= 64) != (h <= 64)      # only the last CTB of such a picture is filtered
+    assert (wy != y).sum() > (40 if one_ctb else w * h // 50) and (wu != u).sum() > 0
     prm = capi.DeblockParams(w, h, w, w // 2, tco, bo, cb, cr)
     gy, gu, gv = gpu_deblock(L, y, u, v, prm, vbs, hbs, qp)
     np.testing.assert_array_equal(gy, wy)

@@ -64,6 +64,33 @@ def test_host_encoder_writes_the_recorded_stream(key, lanes, speculate):
 
 
 @needs_ref("libx265ref_pixel.so", how="make -C oracle ref")
+@needs_ref("x265_refsse", how="make -C oracle enc")
+@pytest.mark.parametrize("w,h,frames,qp,seed", [(128, 64, 4, 26, 4), (64, 192, 3, 30, 2), (64, 64, 3, 33, 9)])
+def test_pictures_one_ctu_high_or_wide_against_the_reference_build(tmp_path, w, h, frames, qp, seed):
+    """Degenerate geometries follow the reference's control flow to the letter: with one CTU row or column its deblocking
+    gets to the last CTU only (hls_filters, src/Deblock.cpp:512), and a picture one CTU wide never stores the contexts the
+    next row starts from (src/encode.cpp:5482, 5687), which stay zero."""
+    import subprocess
+    lib = checker()
+    rng = np.random.default_rng(seed)
+    pics = [frame(w, h, t, rng) for t in range(frames)]
+    yuv, out = str(tmp_path / "in.yuv"), str(tmp_path / "ref.265")
+    with open(yuv, "wb") as f:
+        for p in pics:
+            f.write(b"".join(c.tobytes() for c in p))
+    subprocess.run([os.path.join(ROOT, "oracle", "_ref", "x265_refsse"), "-i", yuv, "-o", out, "-w", str(w), "-h", str(h), "-f", str(frames), "-q", str(qp),
+                    "-ip", "100", "-sceneChange", "0", "-t", "1"], check=True, capture_output=True, timeout=300)
+    enc = lib.orc_encoder_create(w, h, qp, 0)
+    buf = np.zeros(w * h * 3 + 4096, np.uint8)
+    stream = b""
+    for t, (y, u, v) in enumerate(pics):
+        n = lib.orc_encoder_encode(enc, y.ctypes.data, u.ctypes.data, v.ctypes.data, 2 if t == 0 else 1, buf.ctypes.data, buf.size)
+        assert n > 0, n
+        stream += bytes(buf[:n])
+    lib.orc_encoder_destroy(enc)
+    assert stream == open(out, "rb").read()
+
+
 def test_scan_tables_against_the_reference():
     """the horizontal / vertical / diagonal coefficient scans the writer derives equal the reference's tables
     (xg_ausScanIdx, xg_sigLastScan8x8, xg_sigLastScanCG32x32, src/table.cpp:268-511), read from its compiled table.cpp"""

@@ -26,6 +26,9 @@ struct DbParams {
     uint8_t *y, *u, *v;
     const uint8_t *vbs, *hbs, *qp;
     int width, height, stride_y, stride_c, tc_offset, beta_offset, cb_qp_offset, cr_qp_offset;
+    // first sample column / row whose vertical edges (v_) and horizontal edges (h_) xDeblockFrame gets to: 0 for pictures of at
+    // least two CTB rows and columns (see xmi_deblock_frame_dev)
+    int v_x0, v_y0, h_x0, h_y0;
 };
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(hi, max(lo, v)); }
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(256) deblock_vertical_kernel(const DbParams p)
 {
     const int ex = blockIdx.x * 64 + (threadIdx.x & 63) + 1, sy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int x = 8 * ex, y = 4 * sy;
-    if (x >= p.width || y >= p.height) return;
+    if (x >= p.width || y >= p.height || x < p.v_x0 || y < p.v_y0) return;
     const int bs = p.vbs[ex + sy * (p.width >> 3)];
     if (!bs) return;
     const int qw = p.width >> 2;
@@ -144,7 +147,7 @@ __global__ void __launch_bounds__(256) deblock_horizontal_kernel(const DbParams 
 {
     const int x4 = blockIdx.x * 64 + (threadIdx.x & 63), ey = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
     const int x = 4 * x4, y = 8 * ey;
-    if (x >= p.width || y >= p.height) return;
+    if (x >= p.width || y >= p.height || x < p.h_x0 || y < p.h_y0) return;
     const int bs = p.hbs[(x + y * (p.width >> 3)) >> 2];
     if (!bs) return;
     const int qw = p.width >> 2;
@@ -332,8 +335,16 @@ int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_de
             "xmi_deblock_frame_dev: picture %dx%d must be a multiple of 8, at least 16x16", prm->width, prm->height);
     XMI_ARG(prm->stride_y >= prm->width && prm->stride_y % 4 == 0 && ((uintptr_t)d_y & 3) == 0 && prm->stride_c >= prm->width / 2,
             "xmi_deblock_frame_dev: luma plane and stride (%d) must be 4-byte aligned, strides must cover the picture", prm->stride_y);
+    // xDeblockFrame filters CTB (x - 1, y - 1) when it comes to CTB (x, y) with x, y > 0 - plus the last column and row from
+    // their neighbours - and the last CTB at the end (hls_filters, src/Deblock.cpp:512-522, :556-559): a picture with one CTB
+    // row or one CTB column never gets there, and only its last CTB is filtered - its vertical edges from its left border
+    // on, its horizontal edges from 8 samples further left (ff_hevc_deblocking_filter_CTB, :274, :310-311).
+    const int cols = (prm->width + 63) / 64, rows = (prm->height + 63) / 64;
+    int v_x0 = 0, v_y0 = 0, h_x0 = 0, h_y0 = 0;
+    if (rows == 1 && cols > 1) v_x0 = (cols - 1) * 64, h_x0 = v_x0 - 8;
+    if (cols == 1 && rows > 1) v_y0 = h_y0 = (rows - 1) * 64;
     DbParams p = { d_y, d_u, d_v, d_vertical_bs, d_horizontal_bs, d_qp_tab, prm->width, prm->height, prm->stride_y, prm->stride_c,
-                   prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset };
+                   prm->tc_offset, prm->beta_offset, prm->cb_qp_offset, prm->cr_qp_offset, v_x0, v_y0, h_x0, h_y0 };
     hipStream_t st = xmi::as_stream(stream);
     const int nev = prm->width / 8 - 1, nsv = prm->height / 4;      // vertical edges x segments
     hipLaunchKernelGGL(deblock_vertical_kernel, dim3((nev + 63) / 64, (nsv + 3) / 4), dim3(256), 0, st, p);

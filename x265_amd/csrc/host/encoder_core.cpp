@@ -588,7 +588,7 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     cabac.out = &sb;
     analysis::init_contexts(slice_type, qp_, cabac.ctx);
     cabac.reset();
-    uint8_t saved[256];
+    uint8_t saved[256] = {};      // (a picture one CTU wide never stores them: the reference then starts every further row from its zero-filled set)
     std::vector<int32_t> bytes0((size_t)rows_ + 2, 0), entry((size_t)rows_ + 1, 0);
     for (int y = 0; y < rows_; y++)
         for (int x = 0; x < cols_; x++) {
