@@ -282,7 +282,10 @@ int xmi_frame_padding(uint8_t *plane, int stride, int width, int height, int pad
  * stored for it (ff_hevc_deblocking_boundary_strengths, src/Deblock.cpp:369) is 1 or 2; chroma on the 16-sample luma
  * grid for strength 2. Tables as the reference keeps them: vertical_bs[(x>>3) + (y>>2)*(width>>3)],
  * horizontal_bs[(x + y*(width>>3)) >> 2] (both (width/8)*(height/4) bytes are read, the size xmi_deblock_strengths
- * writes; the reference allocates more), qp_tab one QP per 4x4 block, width/4 per row, (width/4)*(height/4) bytes. tc_offset / beta_offset are the picture's DBParams (inc/x265.h:329), cb/cr_qp_offset the PPS offsets. */
+ * writes; the reference allocates more), qp_tab one QP per 4x4 block, width/4 per row, (width/4)*(height/4) bytes.
+ * tc_offset / beta_offset are the picture's DBParams (inc/x265.h:329), cb/cr_qp_offset the PPS offsets. A picture of one
+ * 64-sample CTB row or column (but not both) has only its last CTB filtered, as the reference's loop gets to no other
+ * (hls_filters, src/Deblock.cpp:512-522). */
 typedef struct xmi_deblock_params {
     int32_t width, height;            /* luma picture size, multiples of 8 */
     int32_t stride_y, stride_c;
