@@ -118,6 +118,12 @@ def main():
             print(json.dumps({"luma group of four 4x4 PUs, us": {"set-up": round(qt[0] / n / 100, 2), "neighbours x4": round(qt[1] / n / 100, 2),
                                                                "search x4": round(qt[2] / n / 100, 2), "prediction x4": round(qt[3] / n / 100, 2),
                                                                "chain x4": round(qt[4] / n / 100, 2)}}))
+    if hasattr(L, "xmi_debug_round_classes"):    # measurement build: the calls of the P pictures by their largest CU
+        import ctypes
+        rc = (ctypes.c_ulonglong * 15)()
+        L.xmi_debug_round_classes(rc)
+        print(json.dumps({n: {"calls": int(rc[3 * i]), "us": round(rc[3 * i + 1] / max(1, rc[3 * i]) / 1e3, 1), "cus": round(rc[3 * i + 2] / max(1, rc[3 * i]), 1)}
+                          for i, n in enumerate(("largest 8", "largest 16", "largest 32", "largest 64", "chroma alone"))}))
     if hasattr(L, "xmi_debug_intra_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING): workgroup time per job type
         import ctypes
         tk = (ctypes.c_ulonglong * 18)()

@@ -41,7 +41,8 @@ struct LumaJob {
     int32_t n_merge;
     int16_t merge_mv[5][2];
     uint8_t merge_ok[5];
-    uint8_t reserved[3];
+    uint8_t urgent;               // the host waits for the merge path of this CU before it takes the round's answers
+    uint8_t reserved[2];
     int16_t amvp[2][2];
     int16_t mv_min_ipel[2], mv_max_ipel[2];
     uint32_t sqrt_lambda;
@@ -53,6 +54,7 @@ struct LumaHead {                 // per transform unit: a 64x64 CU has four, ea
     uint32_t ssd_skip, ssd_merge[4], sum_merge[4];
     int16_t mv[2];
     uint32_t ssd_me[4], sum_me[4];
+    uint32_t done[2][4];          // per path and transform unit: the round's number, written by the workgroup when its results are out
 };
 struct ChromaJob {
     int32_t plane;                // 0 = U, 1 = V
@@ -76,8 +78,11 @@ struct RoundParams {
     uint8_t *out;                 // result area
     unsigned *counter;            // workgroups finished since the handle was made (device memory)
     unsigned target;              // value of the counter when this round is complete
-    unsigned *flag;               // pinned host word the host spins on
+    unsigned *flag;               // pinned host word: the round's number once every workgroup is through
     unsigned seq;
+    unsigned *counter_early;      // the same three for the workgroups whose answers are read first (merge paths of the CUs that
+    unsigned target_early;        // asked, chroma): what the host waits for
+    unsigned *flag_early;
 };
 
 __constant__ int k_chroma_taps[8][4] = { { 0, 64, 0, 0 },   { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
@@ -402,6 +407,28 @@ __device__ __forceinline__ void round_done(unsigned *counter, unsigned target, u
     }
 }
 
+// Completion of a round of a P picture. A row reads the merge results of the CU that asked first and, where a merge candidate
+// ends the CU (most CTUs of a picture with coherent motion end so at 64x64), nothing else of what it asked for; the searches
+// are the longest workgroups. So every luma workgroup reports in a word of its CU's result header, where the host looks when
+// it comes to need that part; the host is told (flag_early) when the workgroups it reads first are through, and `flag` says
+// when every workgroup is - before that the tables and the result area must not be used again.
+__device__ __forceinline__ void round_done_split(const RoundParams &p, unsigned *done_word, bool early)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (done_word) __hip_atomic_store(done_word, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (early && atomicAdd(p.counter_early, 1u) + 1u == p.target_early) {
+            __threadfence_system();
+            __hip_atomic_store(p.flag_early, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (atomicAdd(p.counter, 1u) + 1u == p.target) {
+            __threadfence_system();
+            __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // A round of a picture with coherent motion brings several hundred workgroups; registers are held to 128 so that four of
 // them fit on a CU (the compiler needs no spill for it).
 #ifndef XMI_ROUND_WAVES
@@ -409,12 +436,15 @@ __device__ __forceinline__ void round_done(unsigned *counter, unsigned target, u
 #endif
 #ifdef XMI_EXP_ROUND_TIMING
 __device__ unsigned long long g_clock_ticks[2];      // shader clock ticks and 100 MHz ticks, summed over workgroups
+static std::atomic<uint64_t> g_round_class[5][3];    // host side: calls of P pictures by their largest CU
 #endif
 __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(const RoundParams p)
 {
     __shared__ RoundLds L;
     __shared__ uint8_t s_cpred[16 * 16];
     const int b = blockIdx.x;
+    unsigned *done_word = nullptr;
+    bool early = true;
 #ifdef XMI_EXP_ROUND_TIMING
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -424,6 +454,8 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
         const int rest = b - 8 * p.n64;
         const int job = rest < 0 ? b >> 3 : p.n64 + (rest >> 1), path = rest < 0 ? (b >> 2) & 1 : rest & 1, unit = rest < 0 ? b & 3 : 0;
         const LumaJob j = p.jobs[job];
+        done_word = &reinterpret_cast<LumaHead *>(p.out + j.out_head)->done[path][unit];
+        early = j.urgent && path == 0;
         switch (j.size) {
         case 8: luma_job<8>(p, L, j, path, 0); break;
         case 16: luma_job<16>(p, L, j, path, 0); break;
@@ -446,7 +478,7 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
         atomicAdd(&g_clock_ticks[1], __builtin_amdgcn_s_memrealtime() - r0);
     }
 #endif
-    round_done(p.counter, p.target, p.flag, p.seq);
+    round_done_split(p, done_word, early);
 }
 
 // ---- I pictures: one workgroup per PU request ----
@@ -1003,6 +1035,8 @@ public:
         uint8_t *g_jobs = nullptr, *g_out = nullptr;       // the same buffers as the GPU addresses them
         unsigned *g_flag = nullptr;
         unsigned issued = 0, seq = 0;
+        unsigned issued_early = 0;                         // P rounds: workgroups whose answers are read first
+        bool late_pending = false;                         // the last round may still have workgroups under way
         std::vector<ChromaPlace> place;
         std::vector<int> order;
         // where a round trip's time goes, nanoseconds (xmi_analysis_counters): table set-up, launch call, wait, result read-back
@@ -1052,6 +1086,7 @@ public:
     void release_lanes()
     {
         for (LaneRes &l : lane) {
+            if (l.st) (void)hipStreamSynchronize(l.st);
             if (l.d_counter) (void)hipFree(l.d_counter), l.d_counter = nullptr;
             if (l.d_intra) (void)hipFree(l.d_intra), l.d_intra = nullptr;
             if (l.h_jobs) (void)hipHostFree(l.h_jobs), l.h_jobs = nullptr;
@@ -1189,10 +1224,11 @@ public:
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_out), l.h_out, 0));
             XMI_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&l.g_flag), l.h_flag, 0));
             std::memset(l.h_out, 0, out_bytes);
-            *l.h_flag = 0;
+            std::memset(l.h_flag, 0, 256);
             XMI_HIP(hipStreamCreateWithFlags(&l.st, hipStreamNonBlocking));
             XMI_HIP(hipMemsetAsync(l.d_counter, 0, 256, st));
-            l.issued = l.seq = 0;
+            l.issued = l.seq = l.issued_early = 0;
+            l.late_pending = false;
             l.err[0] = 0;
         }
         XMI_HIP(hipStreamSynchronize(st));
@@ -1203,6 +1239,10 @@ public:
     // quarter-pel planes are built
     int bind(const uint8_t *const src[3], const uint8_t *const ref[3], int qp, int qpc)
     {
+        for (int i = 0; i < lanes; i++) {      // search paths nobody waited for may still read the planes of the last picture
+            const int rc = settle(lane[i]);
+            if (rc != XMI_OK) return rc;
+        }
         XMI_HIP(hipMemcpyAsync(d_src[0], src[0], (size_t)w * h, hipMemcpyHostToDevice, st));
         XMI_HIP(hipMemcpyAsync(d_src[1], src[1], (size_t)w * h / 4, hipMemcpyHostToDevice, st));
         XMI_HIP(hipMemcpyAsync(d_src[2], src[2], (size_t)w * h / 4, hipMemcpyHostToDevice, st));
@@ -1257,6 +1297,66 @@ public:
         return rc;
     }
 
+    // waits for the workgroups of one path of a CU (they started with the round: a wait of microseconds at most)
+    int await_path(const CuEval &q, const LumaHead &hd, int path)
+    {
+        volatile const uint32_t *done = hd.done[path];
+        const uint32_t seq = q.answer_round;
+        const int units = q.size == 64 ? 4 : 1;
+        auto all = [&] {
+            for (int u = 0; u < units; u++)
+                if (done[u] != seq) return false;
+            return true;
+        };
+        for (unsigned spins = 0; !all(); spins++) {
+            if ((spins & 0xfffff) == 0xfffff) {      // a failed kernel must not hang the row
+                const hipError_t e = hipStreamQuery(lane[q.answer_lane].st);
+                if (e != hipErrorNotReady && !all()) {
+                    xmi::set_error("analysis: the workgroups of the CU at (%d,%d) never reported completion (%s)", q.x0, q.y0, hipGetErrorString(e));
+                    return XMI_ERR_HIP;
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return XMI_OK;
+    }
+
+    // Both are called from the row's thread while the lane's answers are still the row's to read.
+    int finish_merge(CuEval &q) override
+    {
+        if (!q.merge_pending) return XMI_OK;
+        const LumaHead &hd = *static_cast<const LumaHead *>(q.merge_pending);
+        const int rc = await_path(q, hd, 0);
+        if (rc != XMI_OK) return rc;
+        q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
+        q.ssd_merge = 0;
+        for (int u = 0; u < 4; u++) {
+            const bool used = u < (q.size == 64 ? 4 : 1);
+            q.sum_merge[u] = used ? hd.sum_merge[u] : 0;
+            q.ssd_merge += used ? hd.ssd_merge[u] : 0;
+        }
+        q.merge_pending = nullptr;
+        return XMI_OK;
+    }
+
+    int finish_search(CuEval &q) override
+    {
+        if (!q.search_pending) return XMI_OK;
+        const LumaHead &hd = *static_cast<const LumaHead *>(q.search_pending);
+        const int rc = await_path(q, hd, 1);
+        if (rc != XMI_OK) return rc;
+        q.mv_me = { hd.mv[0], hd.mv[1] };
+        q.ssd_me = 0;
+        for (int u = 0; u < 4; u++) {
+            const bool used = u < (q.size == 64 ? 4 : 1);
+            q.sum_me[u] = used ? hd.sum_me[u] : 0;
+            q.ssd_me += used ? hd.ssd_me[u] : 0;
+        }
+        q.search_pending = nullptr;
+        return XMI_OK;
+    }
+
     const char *first_error() const
     {
         for (int i = 0; i < lanes; i++)
@@ -1267,9 +1367,9 @@ public:
 private:
     // launch and wait: the host spins on the completion word and looks at the stream now and then, so that a failed launch
     // cannot hang it
-    int wait_round(LaneRes &R, unsigned seq)
+    int wait_round(LaneRes &R, unsigned seq, const unsigned *word = nullptr)
     {
-        volatile unsigned *flag = R.h_flag;
+        volatile const unsigned *flag = word ? word : R.h_flag;
         for (unsigned spins = 0; *flag != seq; spins++) {
             if ((spins & 0xfffff) == 0xfffff) {
                 const hipError_t q = hipStreamQuery(R.st);
@@ -1288,6 +1388,14 @@ private:
         return XMI_OK;
     }
 
+    // every workgroup of the lane's last round is through: its tables and result area may be written again
+    int settle(LaneRes &R)
+    {
+        if (!R.late_pending) return XMI_OK;
+        R.late_pending = false;
+        return wait_round(R, R.seq);
+    }
+
     int run_intra(LaneRes &R, const IntraBatch &bt)
     {
         IntraEval *const *pu = bt.pu;
@@ -1295,6 +1403,8 @@ private:
         const int npu = bt.npu, nch = bt.nchroma, nq = bt.nquad, ncq = bt.ncquad;
         XMI_ARG(npu <= max_cu && nch <= lane_rows && nq <= lane_rows && ncq <= lane_rows, "analysis: intra requests (%d, %d, %d, %d) exceed the round capacity", npu, nch, nq,
                 ncq);
+        const int settled = settle(R);
+        if (settled != XMI_OK) return settled;
         const auto t0 = std::chrono::steady_clock::now();
         IntraJob *jobs = reinterpret_cast<IntraJob *>(R.h_jobs);
         IntraGroup *groups = reinterpret_cast<IntraGroup *>(R.h_jobs + off_groups);
@@ -1433,13 +1543,15 @@ private:
     int run(LaneRes &R, CuEval *const *cu, int ncu, ChromaEval *const *ch, int nch)
     {
         XMI_ARG(ncu <= max_cu, "analysis: %d CU requests exceed the round capacity %d", ncu, max_cu);
+        const int settled = settle(R);
+        if (settled != XMI_OK) return settled;
         const auto t0 = std::chrono::steady_clock::now();
         uint8_t *const h_jobs = R.h_jobs, *const h_out = R.h_out;
         std::vector<ChromaPlace> &place = R.place;
         LumaJob *jobs = reinterpret_cast<LumaJob *>(h_jobs);
         ChromaJob *cjobs = reinterpret_cast<ChromaJob *>(h_jobs + off_cjobs);
         size_t out = 0;
-        int nluma = 0, n64 = 0;
+        int nluma = 0, n64 = 0, n_early = 0;
         std::vector<int> &order = R.order;      // job k serves request order[k]: the 64x64 CUs first
         order.resize(ncu);
         for (int i = 0; i < ncu; i++)
@@ -1471,6 +1583,10 @@ private:
             XMI_ARG(xmi::me_request_reach(rq) + 8 <= kPad, "analysis: the search of the CU at (%d,%d) could leave the padded reference", q.x0, q.y0);
             const size_t px = (size_t)q.size * q.size;
             j.out_head = (uint32_t)out, out = align_up(out + sizeof(LumaHead));
+            XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
+            std::memset(reinterpret_cast<LumaHead *>(h_out + j.out_head)->done, 0, sizeof(LumaHead::done));
+            j.urgent = q.urgent != 0;
+            n_early += j.urgent ? (q.size == 64 ? 4 : 1) : 0;
             j.out_pred_merge = (uint32_t)out, out = align_up(out + px);
             j.out_rec_merge = (uint32_t)out, out = align_up(out + px);
             j.out_rec_me = (uint32_t)out, out = align_up(out + px);
@@ -1518,15 +1634,19 @@ private:
         p.out = R.g_out;
         const unsigned ngroups = (unsigned)(nluma + nc);
         R.issued += ngroups;
+        n_early += nc;
+        R.issued_early += (unsigned)n_early;
         R.seq++;
         const unsigned seq = R.seq;
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
+        p.counter_early = R.d_counter + 16, p.target_early = R.issued_early, p.flag_early = R.g_flag + 16;
+        R.late_pending = true;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
         const auto t1 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
         XMI_HIP(hipGetLastError());
         const auto t2 = std::chrono::steady_clock::now();
-        const int wrc = wait_round(R, seq);
+        const int wrc = wait_round(R, seq, n_early ? R.h_flag + 16 : nullptr);      // (nothing marked: everything is waited for)
         if (wrc != XMI_OK) return wrc;
         const auto t3 = std::chrono::steady_clock::now();
 
@@ -1534,14 +1654,8 @@ private:
             CuEval &q = *cu[order[i]];
             const LumaJob &j = jobs[i];
             const LumaHead &hd = *reinterpret_cast<const LumaHead *>(h_out + j.out_head);
-            q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
-            q.mv_me = { hd.mv[0], hd.mv[1] };
-            q.ssd_merge = q.ssd_me = 0;
-            for (int u = 0; u < 4; u++) {
-                const bool used = u < (q.size == 64 ? 4 : 1);
-                q.sum_merge[u] = used ? hd.sum_merge[u] : 0, q.sum_me[u] = used ? hd.sum_me[u] : 0;
-                q.ssd_merge += used ? hd.ssd_merge[u] : 0, q.ssd_me += used ? hd.ssd_me[u] : 0;
-            }
+            // the results themselves come with finish_merge() / finish_search(), when the row gets to them
+            q.merge_pending = q.search_pending = &hd, q.answer_round = seq, q.answer_lane = (int)(&R - lane);
             q.pred_merge = h_out + j.out_pred_merge, q.rec_merge = h_out + j.out_rec_merge, q.rec_me = h_out + j.out_rec_me;
             q.level_merge = reinterpret_cast<const int16_t *>(h_out + j.out_level_merge);
             q.level_me = reinterpret_cast<const int16_t *>(h_out + j.out_level_me);
@@ -1558,6 +1672,16 @@ private:
         const auto t4 = std::chrono::steady_clock::now();
         auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
         R.t_prepare += ns(t0, t1), R.t_launch += ns(t1, t2), R.t_wait += ns(t2, t3), R.t_collect += ns(t3, t4), R.rounds++;
+#ifdef XMI_EXP_ROUND_TIMING
+        {      // calls by their largest CU (8, 16, 32, 64; none = chroma alone): count, time from launch to completion, CU requests
+            int cls = 4;
+            for (int i = 0; i < ncu; i++) {
+                const int c = cu[i]->size == 64 ? 3 : cu[i]->size == 32 ? 2 : cu[i]->size == 16 ? 1 : 0;
+                cls = cls == 4 ? c : (c > cls ? c : cls);
+            }
+            g_round_class[cls][0]++, g_round_class[cls][1] += ns(t1, t3), g_round_class[cls][2] += (uint64_t)ncu;
+        }
+#endif
         return XMI_OK;
     }
 };
@@ -1627,6 +1751,12 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 #ifdef XMI_EXP_ROUND_TIMING
 int xmi_debug_search_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_search_ticks), sizeof(unsigned long long) * 10) == hipSuccess ? 0 : -1; }
 int xmi_debug_quad_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_quad_ticks), sizeof(unsigned long long) * 6) == hipSuccess ? 0 : -1; }
+int xmi_debug_round_classes(unsigned long long *out)
+{
+    for (int c = 0; c < 5; c++)
+        for (int k = 0; k < 3; k++) out[c * 3 + k] = g_round_class[c][k].exchange(0);
+    return 0;
+}
 int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 int xmi_debug_intra_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_intra_ticks), sizeof(unsigned long long) * 18) == hipSuccess ? 0 : -1; }

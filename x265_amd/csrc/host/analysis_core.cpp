@@ -360,9 +360,22 @@ struct Shared {
     int w = 0, h = 0, cols = 0, nrows = 0, qp = 0;
     bool intra = false;             // I picture
     int strong = 0;                 // its bStrongIntraSmoothing
+    Evaluator *ev = nullptr;
+    void fail(int rc);              // an error that a row found ends the picture like one that a coordinator found
 };
 
 struct Abort {};
+
+void Shared::fail(int rc)
+{
+    std::lock_guard<std::mutex> lk(m);
+    if (!error) error = rc;
+    Lane &ln = lanes[0];
+    for (Row &r : rows)
+        if (r.need.load() >= 0) ln.running.fetch_add(1), r.need.store(-1);
+    ln.cv_main.notify_all();
+    cv_rows.notify_all();
+}
 
 // xFillMvpCand (src/encode.cpp:2703-2809) for a square 2Nx2N PU: out[0..1] the two AMVP predictors, out[2..] the merge
 // candidates; returns their number.
@@ -421,6 +434,8 @@ void Row::fill_request(CuEval &r, const Mv *cnd, int nm, int px, int py, int sz)
     r.amvp[0] = cnd[0], r.amvp[1] = cnd[1];
     r.mv_min_ipel = min_ipel, r.mv_max_ipel = max_ipel;
     r.lambda = lambda, r.qp = qp;
+    r.urgent = 0;
+    r.merge_pending = r.search_pending = nullptr;
 }
 
 // the request of the CU at (px, py) as the caches stand
@@ -510,6 +525,7 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         std::memset(tree_ok, 0, sizeof tree_ok);      // a new call: the answers of the last one are gone
         spec_list.clear();
         fill_request(q, cand, nmerge, px, py, size);
+        q.urgent = 1;      // the answer this row reads first
         spec_list.push_back(&q);
         if (sh->speculate == 1) {
             for (int sz = size / 2; sz >= 8; sz /= 2) spec_node(px, py, sz);      // same corner: the CU's own neighbours
@@ -563,6 +579,13 @@ uint32_t Row::decide(int px, int py, int size, int depth)
 #endif
     }
     tree_ok[idx] = false;
+    if (q.merge_pending) {
+        const int rc = sh->ev->finish_merge(q);
+        if (rc) {
+            sh->fail(rc);
+            throw Abort();
+        }
+    }
     // read after the evaluation: the call may have brought the chroma of the CTU to the left, which sets its skip flags
     const bool skip_left = (I1(r4, c4 - 1) & kMaskSkip) && M(r4 + b4 - 1, c4 - 1) != kInvalid;
     const bool skip_above = (I1(r4 - 1, c4) & kMaskSkip) && M(r4 - 1, c4 + b4 - 1) != kInvalid;
@@ -609,6 +632,13 @@ uint32_t Row::decide(int px, int py, int size, int depth)
         if (skip || cbf == 0) go_me = false;      // FAST_MD: a skipped or residual-free merge ends the CU's own search (:3370-3374)
     }
     if (go_me) {
+        if (q.search_pending) {
+            const int rc = sh->ev->finish_search(q);
+            if (rc) {
+                sh->fail(rc);
+                throw Abort();
+            }
+        }
         const Mv m = q.mv_me;
         work = entry;
         int cbf = 0;
@@ -1376,6 +1406,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     S.rows = std::deque<Row>(rows_);
     S.spin_us = spin_us;
     S.grace_us = grace_us;
+    S.ev = &ev;
     S.speculate = speculate;
     S.defer_chroma = speculate != 0;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;

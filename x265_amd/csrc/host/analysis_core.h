@@ -43,6 +43,15 @@ struct CuEval {
     uint32_t ssd_me, sum_me[4];
     const uint8_t *rec_me;
     const int16_t *level_me;
+    // An evaluator may return before all results are in place: then merge_pending / search_pending are not null, the merge
+    // results (best_merge .. level_merge) resp. the search results (mv_me .. level_me) not yet valid, and
+    // Evaluator::finish_merge() / finish_search() bring them. `urgent` (set by the caller) marks the requests whose merge
+    // results it reads first: an evaluator that returns early must have those under way to completion at least. The other
+    // fields are for the evaluator's own use.
+    uint8_t urgent;
+    const void *merge_pending, *search_pending;
+    uint32_t answer_round;
+    int answer_lane;
 };
 
 // Chroma of one decided CU (xEncInterCTU, src/encode.cpp:3719-3788): prediction of U and V at the CU's vector; unless
@@ -159,6 +168,18 @@ public:
     // `lane` values (0 .. Analyser::lanes - 1) come from different threads and may overlap; calls of one lane never do,
     // and the blocks a call hands out stay valid until the next call of the same lane.
     virtual int evaluate(int lane, CuEval *const *cu, int ncu, ChromaEval *const *chroma, int nchroma) = 0;
+    // Complete a request whose merge_pending / search_pending is set (see CuEval); called from the thread of the CU's row,
+    // before the lane that answered is called again. Return 0 or an error code that ends the picture.
+    virtual int finish_merge(CuEval &q)
+    {
+        q.merge_pending = nullptr;
+        return 0;
+    }
+    virtual int finish_search(CuEval &q)
+    {
+        q.search_pending = nullptr;
+        return 0;
+    }
 };
 
 // What a picture leaves behind, picture-level arrays (CTU caches of the reference laid side by side):
