@@ -124,6 +124,13 @@ def main():
         L.xmi_debug_round_classes(rc)
         print(json.dumps({n: {"calls": int(rc[3 * i]), "us": round(rc[3 * i + 1] / max(1, rc[3 * i]) / 1e3, 1), "cus": round(rc[3 * i + 2] / max(1, rc[3 * i]), 1)}
                           for i, n in enumerate(("largest 8", "largest 16", "largest 32", "largest 64", "chroma alone"))}))
+    if hasattr(L, "xmi_debug_span"):
+        import ctypes
+        sp = (ctypes.c_ulonglong * 5)()
+        L.xmi_debug_span(sp)
+        n = max(1, sp[2])
+        print(json.dumps({"rounds with 64x64 CUs, us on the GPU from the first workgroup's start": {"to the early flag": round(sp[0] / n / 100, 1), "to the full flag": round(sp[1] / n / 100, 1),
+                          "longest early luma workgroup": round(sp[3] / n / 100, 1), "longest chroma workgroup": round(sp[4] / n / 100, 1), "rounds": int(sp[2])}}))
     if hasattr(L, "xmi_debug_intra_ticks"):      # measurement build (-DXMI_EXP_ROUND_TIMING): workgroup time per job type
         import ctypes
         tk = (ctypes.c_ulonglong * 18)()

@@ -223,6 +223,11 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
 #ifdef XMI_EXP_ROUND_TIMING
 // measurement build: per CU size (8, 16, 32, 64) and path, 100 MHz ticks spent in merge selection / search / chain, and counts
 __device__ unsigned long long g_round_ticks[4][2][4];
+// rounds with 64x64 CUs, 100 MHz ticks from the first workgroup's start: to the early flag, to the full flag; rounds; then the
+// longest early luma workgroup and the longest chroma workgroup of a round, summed over rounds
+__device__ unsigned long long g_span[5];
+__device__ unsigned long long g_span_start[1024];
+__device__ unsigned g_span_max[1024][2];
 #define XMI_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #else
 #define XMI_STAMP(var)
@@ -421,10 +426,26 @@ __device__ __forceinline__ void round_done_split(const RoundParams &p, unsigned 
         if (early && atomicAdd(p.counter_early, 1u) + 1u == p.target_early) {
             __threadfence_system();
             __hip_atomic_store(p.flag_early, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef XMI_EXP_ROUND_TIMING
+            if (p.n64 > 0) {
+                const unsigned slot = (p.seq * 2u + (unsigned)((reinterpret_cast<uintptr_t>(p.flag) >> 12) & 1u)) & 1023u;
+                const unsigned long long t0 = atomicAdd(&g_span_start[slot], 0ull);
+                if (t0) atomicAdd(&g_span[0], __builtin_amdgcn_s_memrealtime() - (t0 - 1)), atomicAdd(&g_span[2], 1ull);
+                atomicAdd(&g_span[3], (unsigned long long)atomicExch(&g_span_max[slot][0], 0u));
+                atomicAdd(&g_span[4], (unsigned long long)atomicExch(&g_span_max[slot][1], 0u));
+            }
+#endif
         }
         if (atomicAdd(p.counter, 1u) + 1u == p.target) {
             __threadfence_system();
             __hip_atomic_store(p.flag, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#ifdef XMI_EXP_ROUND_TIMING
+            if (p.n64 > 0) {
+                const unsigned slot = (p.seq * 2u + (unsigned)((reinterpret_cast<uintptr_t>(p.flag) >> 12) & 1u)) & 1023u;
+                const unsigned long long t0 = atomicExch(&g_span_start[slot], 0ull);
+                if (t0) atomicAdd(&g_span[1], __builtin_amdgcn_s_memrealtime() - (t0 - 1));
+            }
+#endif
         }
     }
 }
@@ -447,6 +468,8 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
     bool early = true;
 #ifdef XMI_EXP_ROUND_TIMING
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned slot = (p.seq * 2u + (unsigned)((reinterpret_cast<uintptr_t>(p.flag) >> 12) & 1u)) & 1023u;
+    if (p.n64 > 0 && threadIdx.x == 0 && atomicCAS(&g_span_start[slot], 0ull, r0 + 1) != 0ull) atomicMin(&g_span_start[slot], r0 + 1);      // (0 = unset)
 #endif
     if (b < p.nluma) {
         // The job table lies in host memory, a read of it is a trip over the bus: which job a workgroup serves follows from its
@@ -476,6 +499,7 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
     if (threadIdx.x == 0) {
         atomicAdd(&g_clock_ticks[0], __builtin_amdgcn_s_memtime() - c0);
         atomicAdd(&g_clock_ticks[1], __builtin_amdgcn_s_memrealtime() - r0);
+        if (p.n64 > 0 && early) atomicMax(&g_span_max[slot][done_word ? 0 : 1], (unsigned)(__builtin_amdgcn_s_memrealtime() - r0));
     }
 #endif
     round_done_split(p, done_word, early);
@@ -1757,6 +1781,7 @@ int xmi_debug_round_classes(unsigned long long *out)
         for (int k = 0; k < 3; k++) out[c * 3 + k] = g_round_class[c][k].exchange(0);
     return 0;
 }
+int xmi_debug_span(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 5) == hipSuccess ? 0 : -1; }
 int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 int xmi_debug_intra_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_intra_ticks), sizeof(unsigned long long) * 18) == hipSuccess ? 0 : -1; }
