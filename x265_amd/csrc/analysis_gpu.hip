@@ -257,14 +257,23 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     int best = -1;
     auto select = [&] {
         uint32_t acc[5] = { 0, 0, 0, 0, 0 };
+        // No branch inside the loops: a candidate that is left out reads the block of one that is not and its sum is ignored
+        // below, so the loads of all candidates and (64x64: four) steps go out together instead of one latency after the other.
+        const uint8_t *first = nullptr;
+#pragma unroll
+        for (int k = 4; k >= 0; k--) first = cand[k] ? cand[k] : first;
+        if (!first) return;
+        const uint8_t *blk[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) blk[k] = cand[k] ? cand[k] : first;
+#pragma unroll
         for (int i = tid * 4; i < N * N; i += 1024) {
             const int y = i / N, x = i - y * N;
             const uint32_t a = *reinterpret_cast<const uint32_t *>(src + (size_t)y * p.width + x);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                if (!cand[k]) continue;
                 // four samples of the candidate from the two aligned dwords that hold them; SSD = a.a + b.b - 2 a.b on bytes
-                const uint8_t *bp = cand[k] + (size_t)y * p.stride + x;
+                const uint8_t *bp = blk[k] + (size_t)y * p.stride + x;
                 const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(bp) & 3);
                 const uint32_t *bw = reinterpret_cast<const uint32_t *>(bp - sh);
                 const uint32_t b = __builtin_amdgcn_alignbyte(bw[1], bw[0], sh);
