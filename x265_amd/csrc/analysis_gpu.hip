@@ -17,6 +17,7 @@
 // four 32x32 units one after the other.
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <chrono>
 #include <cstring>
 #include <new>
@@ -48,13 +49,13 @@ struct LumaJob {
     uint32_t sqrt_lambda;
     uint32_t out_head;            // byte offsets into the result area: LumaHead, then the blocks
     uint32_t out_pred_merge, out_rec_merge, out_level_merge, out_rec_me, out_level_me;
+    uint32_t out_done;            // eight words (path x transform unit) in the part of the result area that holds nothing else
 };
 struct LumaHead {                 // per transform unit: a 64x64 CU has four, each written by a workgroup of its own
     int32_t best_merge;
     uint32_t ssd_skip, ssd_merge[4], sum_merge[4];
     int16_t mv[2];
     uint32_t ssd_me[4], sum_me[4];
-    uint32_t done[2][4];          // per path and transform unit: the round's number, written by the workgroup when its results are out
 };
 struct ChromaJob {
     int32_t plane;                // 0 = U, 1 = V
@@ -257,8 +258,10 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     int best = -1;
     auto select = [&] {
         uint32_t acc[5] = { 0, 0, 0, 0, 0 };
-        // No branch inside the loops: a candidate that is left out reads the block of one that is not and its sum is ignored
-        // below, so the loads of all candidates and (64x64: four) steps go out together instead of one latency after the other.
+        // 64x64 (four steps per thread, few CUs, the workgroups a round waits for): no branch inside the loops - a candidate
+        // that is left out reads the block of one that is not and its sum is ignored below - so that the loads of all
+        // candidates and steps go out together instead of one latency after the other. The smaller sizes have one step and
+        // are many: they skip the candidates that are left out.
         const uint8_t *first = nullptr;
 #pragma unroll
         for (int k = 4; k >= 0; k--) first = cand[k] ? cand[k] : first;
@@ -272,6 +275,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
             const uint32_t a = *reinterpret_cast<const uint32_t *>(src + (size_t)y * p.width + x);
 #pragma unroll
             for (int k = 0; k < 5; k++) {
+                if (N < 64 && !cand[k]) continue;
                 // four samples of the candidate from the two aligned dwords that hold them; SSD = a.a + b.b - 2 a.b on bytes
                 const uint8_t *bp = blk[k] + (size_t)y * p.stride + x;
                 const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(bp) & 3);
@@ -431,7 +435,8 @@ __device__ __forceinline__ void round_done_split(const RoundParams &p, unsigned 
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (done_word) __hip_atomic_store(done_word, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (every thread has fenced before the barrier: the word needs no release of its own)
+        if (done_word) __hip_atomic_store(done_word, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (early && atomicAdd(p.counter_early, 1u) + 1u == p.target_early) {
             __threadfence_system();
             __hip_atomic_store(p.flag_early, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -486,7 +491,7 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
         const int rest = b - 8 * p.n64;
         const int job = rest < 0 ? b >> 3 : p.n64 + (rest >> 1), path = rest < 0 ? (b >> 2) & 1 : rest & 1, unit = rest < 0 ? b & 3 : 0;
         const LumaJob j = p.jobs[job];
-        done_word = &reinterpret_cast<LumaHead *>(p.out + j.out_head)->done[path][unit];
+        done_word = reinterpret_cast<unsigned *>(p.out + j.out_done) + path * 4 + unit;
         early = j.urgent && path == 0;
         switch (j.size) {
         case 8: luma_job<8>(p, L, j, path, 0); break;
@@ -511,7 +516,8 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
         if (p.n64 > 0 && early) atomicMax(&g_span_max[slot][done_word ? 0 : 1], (unsigned)(__builtin_amdgcn_s_memrealtime() - r0));
     }
 #endif
-    round_done_split(p, done_word, early);
+    if (p.flag_early) round_done_split(p, done_word, early);
+    else round_done(p.counter, p.target, p.flag, p.seq);      // the host waits for the whole round and reads no completion words
 }
 
 // ---- I pictures: one workgroup per PU request ----
@@ -1079,9 +1085,13 @@ public:
     int device = 0, w = 0, h = 0, stride = 0, rows = 0, stride_c = 0, rows_c = 0, max_cu = 0, max_chroma = 0, lanes = 0, lane_rows = 0;
     uint8_t *d_src[3] = {}, *d_ref[3] = {}, *d_planes = nullptr;
     LaneRes lane[kMaxLanes];
-    size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, intra_scratch = 0;
+    size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, off_done = 0, intra_scratch = 0;
     hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
+    // P rounds: hand the answers out when the merge paths of the asking CUs and the chroma jobs are through (rows then poll
+    // for the rest when they get to it) - for the polling configurations, where latency counts; with sleeping waiters (many
+    // encoders on one GPU, the host cores are what is short) the coordinator waits for the whole round
+    bool early_answers = false;
     // picture-level passes of the encoder (FrameOps): reconstruction before / after the SAO offsets, decision maps, strength
     // tables, statistics and parameters on the device; one pinned staging buffer for the copies in either direction
     uint8_t *d_rec[3] = {}, *d_sao[3] = {}, *d_maps = nullptr, *d_bs = nullptr, *d_qp = nullptr, *h_stage = nullptr;
@@ -1243,6 +1253,10 @@ public:
         for (int n = 8, count = 64; n <= 64; n *= 2, count /= 4)
             cu_bytes += (size_t)count * (align_up(sizeof(LumaHead)) + 3 * align_up((size_t)n * n) + 2 * align_up(2 * (size_t)n * n));
         out_bytes = (size_t)lane_rows * cu_bytes + (size_t)lane_rows * (64 * 5 * 256 + 2 * 1024 + 2 * 2048) + 4096;
+        // the completion words of the P rounds, eight per CU request, behind the blocks: this part only ever holds numbers of
+        // rounds, so a word equal to the current round's number was written in this round and nothing has to be cleared
+        off_done = out_bytes;
+        out_bytes += align_up(32 * (size_t)max_cu);
         const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
         for (int i = 0; i < lanes; i++) {
             LaneRes &l = lane[i];
@@ -1330,10 +1344,32 @@ public:
         return rc;
     }
 
-    // waits for the workgroups of one path of a CU (they started with the round: a wait of microseconds at most)
-    int await_path(const CuEval &q, const LumaHead &hd, int path)
+    static void take_merge(CuEval &q, const LumaHead &hd)
     {
-        volatile const uint32_t *done = hd.done[path];
+        q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
+        q.ssd_merge = 0;
+        for (int u = 0; u < 4; u++) {
+            const bool used = u < (q.size == 64 ? 4 : 1);
+            q.sum_merge[u] = used ? hd.sum_merge[u] : 0;
+            q.ssd_merge += used ? hd.ssd_merge[u] : 0;
+        }
+    }
+
+    static void take_search(CuEval &q, const LumaHead &hd)
+    {
+        q.mv_me = { hd.mv[0], hd.mv[1] };
+        q.ssd_me = 0;
+        for (int u = 0; u < 4; u++) {
+            const bool used = u < (q.size == 64 ? 4 : 1);
+            q.sum_me[u] = used ? hd.sum_me[u] : 0;
+            q.ssd_me += used ? hd.ssd_me[u] : 0;
+        }
+    }
+
+    // waits for the workgroups of one path of a CU (they started with the round: a wait of microseconds at most)
+    int await_path(const CuEval &q, int path)
+    {
+        volatile const uint32_t *done = q.answer_done + 4 * path;
         const uint32_t seq = q.answer_round;
         const int units = q.size == 64 ? 4 : 1;
         auto all = [&] {
@@ -1349,6 +1385,8 @@ public:
                     return XMI_ERR_HIP;
                 }
             }
+            // (with several encoders on one GPU the wait can be that of a full device, and the core has other threads to run)
+            if ((spins & 255) == 255) std::this_thread::yield();
             __builtin_ia32_pause();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
@@ -1360,15 +1398,9 @@ public:
     {
         if (!q.merge_pending) return XMI_OK;
         const LumaHead &hd = *static_cast<const LumaHead *>(q.merge_pending);
-        const int rc = await_path(q, hd, 0);
+        const int rc = await_path(q, 0);
         if (rc != XMI_OK) return rc;
-        q.best_merge = hd.best_merge, q.ssd_skip = hd.ssd_skip;
-        q.ssd_merge = 0;
-        for (int u = 0; u < 4; u++) {
-            const bool used = u < (q.size == 64 ? 4 : 1);
-            q.sum_merge[u] = used ? hd.sum_merge[u] : 0;
-            q.ssd_merge += used ? hd.ssd_merge[u] : 0;
-        }
+        take_merge(q, hd);
         q.merge_pending = nullptr;
         return XMI_OK;
     }
@@ -1377,15 +1409,9 @@ public:
     {
         if (!q.search_pending) return XMI_OK;
         const LumaHead &hd = *static_cast<const LumaHead *>(q.search_pending);
-        const int rc = await_path(q, hd, 1);
+        const int rc = await_path(q, 1);
         if (rc != XMI_OK) return rc;
-        q.mv_me = { hd.mv[0], hd.mv[1] };
-        q.ssd_me = 0;
-        for (int u = 0; u < 4; u++) {
-            const bool used = u < (q.size == 64 ? 4 : 1);
-            q.sum_me[u] = used ? hd.sum_me[u] : 0;
-            q.ssd_me += used ? hd.ssd_me[u] : 0;
-        }
+        take_search(q, hd);
         q.search_pending = nullptr;
         return XMI_OK;
     }
@@ -1512,7 +1538,7 @@ private:
             for (int k = 0; k < 2; k++) j.out_rec[k] = (uint32_t)out, out = align_up(out + 64);
             for (int k = 0; k < 2; k++) j.out_level[k] = (uint32_t)out, out = align_up(out + 128);
         }
-        XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
+        XMI_ARG(out <= off_done, "analysis: result area too small (%zu of %zu bytes)", out, off_done);
         IntraRoundParams p;
         p.jobs = reinterpret_cast<const IntraJob *>(R.g_jobs);
         p.groups = reinterpret_cast<const IntraGroup *>(R.g_jobs + off_groups);
@@ -1616,8 +1642,7 @@ private:
             XMI_ARG(xmi::me_request_reach(rq) + 8 <= kPad, "analysis: the search of the CU at (%d,%d) could leave the padded reference", q.x0, q.y0);
             const size_t px = (size_t)q.size * q.size;
             j.out_head = (uint32_t)out, out = align_up(out + sizeof(LumaHead));
-            XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
-            std::memset(reinterpret_cast<LumaHead *>(h_out + j.out_head)->done, 0, sizeof(LumaHead::done));
+            j.out_done = (uint32_t)(off_done + 32 * (size_t)i);
             j.urgent = q.urgent != 0;
             n_early += j.urgent ? (q.size == 64 ? 4 : 1) : 0;
             j.out_pred_merge = (uint32_t)out, out = align_up(out + px);
@@ -1653,7 +1678,7 @@ private:
                     j.rec_stride = n;
                 }
         }
-        XMI_ARG(out <= out_bytes, "analysis: result area too small (%zu of %zu bytes)", out, out_bytes);
+        XMI_ARG(out <= off_done, "analysis: result area too small (%zu of %zu bytes)", out, off_done);
 
         RoundParams p;
         p.jobs = reinterpret_cast<const LumaJob *>(R.g_jobs);
@@ -1668,18 +1693,19 @@ private:
         const unsigned ngroups = (unsigned)(nluma + nc);
         R.issued += ngroups;
         n_early += nc;
-        R.issued_early += (unsigned)n_early;
+        if (early_answers && n_early > 0) R.issued_early += (unsigned)n_early;
         R.seq++;
         const unsigned seq = R.seq;
         p.counter = R.d_counter, p.target = R.issued, p.flag = R.g_flag, p.seq = seq;
-        p.counter_early = R.d_counter + 16, p.target_early = R.issued_early, p.flag_early = R.g_flag + 16;
-        R.late_pending = true;
+        const bool early_return = early_answers && n_early > 0;      // (nothing marked: everything is waited for)
+        p.counter_early = R.d_counter + 16, p.target_early = R.issued_early, p.flag_early = early_return ? R.g_flag + 16 : nullptr;
+        R.late_pending = early_return;
         std::atomic_thread_fence(std::memory_order_release);       // the job table is complete before the launch
         const auto t1 = std::chrono::steady_clock::now();
         hipLaunchKernelGGL(analysis_round_kernel, dim3(ngroups), dim3(256), 0, R.st, p);
         XMI_HIP(hipGetLastError());
         const auto t2 = std::chrono::steady_clock::now();
-        const int wrc = wait_round(R, seq, n_early ? R.h_flag + 16 : nullptr);      // (nothing marked: everything is waited for)
+        const int wrc = wait_round(R, seq, early_return ? R.h_flag + 16 : nullptr);
         if (wrc != XMI_OK) return wrc;
         const auto t3 = std::chrono::steady_clock::now();
 
@@ -1689,6 +1715,8 @@ private:
             const LumaHead &hd = *reinterpret_cast<const LumaHead *>(h_out + j.out_head);
             // the results themselves come with finish_merge() / finish_search(), when the row gets to them
             q.merge_pending = q.search_pending = &hd, q.answer_round = seq, q.answer_lane = (int)(&R - lane);
+            q.answer_done = reinterpret_cast<const uint32_t *>(h_out + j.out_done);
+            if (!early_return) take_merge(q, hd), take_search(q, hd), q.merge_pending = q.search_pending = nullptr;
             q.pred_merge = h_out + j.out_pred_merge, q.rec_merge = h_out + j.out_rec_merge, q.rec_me = h_out + j.out_rec_me;
             q.level_merge = reinterpret_cast<const int16_t *>(h_out + j.out_level_merge);
             q.level_me = reinterpret_cast<const int16_t *>(h_out + j.out_level_me);
@@ -1777,7 +1805,7 @@ int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
         rc = a->ev.set_lanes(lanes);
         if (rc == XMI_OK) a->an.lanes = lanes;
     }
-    if (rc == XMI_OK) a->an.spin_us = spin_us;
+    if (rc == XMI_OK) a->an.spin_us = spin_us, a->ev.early_answers = spin_us > 0;
     return rc;
 }
 
@@ -1897,7 +1925,7 @@ int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us)
         rc = e->ev.set_lanes(lanes);
         if (rc == XMI_OK) e->enc.analyser().lanes = lanes;
     }
-    if (rc == XMI_OK) e->enc.analyser().spin_us = spin_us;
+    if (rc == XMI_OK) e->enc.analyser().spin_us = spin_us, e->ev.early_answers = spin_us > 0;
     return rc;
 }
 

@@ -52,6 +52,7 @@ struct CuEval {
     const void *merge_pending, *search_pending;
     uint32_t answer_round;
     int answer_lane;
+    const uint32_t *answer_done;
 };
 
 // Chroma of one decided CU (xEncInterCTU, src/encode.cpp:3719-3788): prediction of U and V at the CU's vector; unless
