@@ -393,7 +393,9 @@ int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const
  *   one, the requests of rows that were still busy on the host go out with the next coordinator while the first round trip
  *   is under way. spin_us: how long the host threads of the loop poll for a result before they go to
  *   sleep (a round trip takes about 30 us, waking a sleeping thread 10 more); 0, the default, sleeps at once and is the
- *   choice when several handles share the host's cores. Results depend on neither. Not while a picture is in flight.
+ *   choice when several handles share the host's cores. With spin_us > 0 a round trip of a P picture also hands its answers
+ *   out as soon as the parts that are read first are complete (the merge results of the CUs that asked, chroma), and the
+ *   rows poll for the rest when they come to need it. Results depend on neither. Not while a picture is in flight.
  *   (The reference has no counterpart: its -t option sets the number of row threads, src/encode.cpp:5800-5860.)
  * xmi_analysis_state : the state the reference carries from picture to picture and never resets - per CTU and depth the
  *   FAST_MD cost statistics (dSumOfRdCosts, nRdCounts, dAverageRdCosts, inc/x265.h:379-381: (height/64) x (width/64) x 5
