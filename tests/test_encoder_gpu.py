@@ -127,6 +127,19 @@ def test_lanes_and_polling_do_not_change_the_stream():
     assert a == b
 
 
+def test_early_answers_at_1080p_write_the_recorded_stream():
+    """With polling (spin_us > 0) a round of a P picture hands its answers out when the merge paths of the asking CUs and the
+    chroma jobs are through, and the rows wait for the other parts when they get to them: two and three coordinators on the
+    recorded 1920x1080 clip, where most rounds carry the long 64x64 searches that nobody then waits for."""
+    from x265_amd.encoder import encode_clip
+    key = next(k for k in sorted(GOLD) if k.startswith("1920x1080") and k.endswith("q32"))
+    frames = int(key.split("_")[1][1:])
+    pics = clip(1920, 1080, frames)
+    for lanes, spin in ((2, 200), (3, 30)):
+        stream = encode_clip(pics, 1920, 1080, 32, lanes=lanes, spin_us=spin)
+        assert len(stream) == GOLD[key]["bytes"] and hashlib.md5(stream).hexdigest() == GOLD[key]["md5"], (lanes, spin)
+
+
 def test_picture_hash_matches_the_reconstruction():
     """the SEI carries the MD5 of each reconstructed plane (src/encode.cpp:6012-6053): the writer's digest against hashlib"""
     from x265_amd.encoder import Encoder
