@@ -1379,6 +1379,7 @@ public:
         };
         for (unsigned spins = 0; !all(); spins++) {
             if ((spins & 0xfffff) == 0xfffff) {      // a failed kernel must not hang the row
+                (void)hipSetDevice(device);          // (a row's thread has made no HIP call before)
                 const hipError_t e = hipStreamQuery(lane[q.answer_lane].st);
                 if (e != hipErrorNotReady && !all()) {
                     xmi::set_error("analysis: the workgroups of the CU at (%d,%d) never reported completion (%s)", q.x0, q.y0, hipGetErrorString(e));
