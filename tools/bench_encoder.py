@@ -124,6 +124,11 @@ def main():
         L.xmi_debug_round_classes(rc)
         print(json.dumps({n: {"calls": int(rc[3 * i]), "us": round(rc[3 * i + 1] / max(1, rc[3 * i]) / 1e3, 1), "cus": round(rc[3 * i + 2] / max(1, rc[3 * i]), 1)}
                           for i, n in enumerate(("largest 8", "largest 16", "largest 32", "largest 64", "chroma alone"))}))
+    if hasattr(L, "xmi_debug_merge64_hist"):
+        import ctypes
+        hh = (ctypes.c_ulonglong * 32)()
+        L.xmi_debug_merge64_hist(hh)
+        print(json.dumps({"64x64 merge path, workgroups by length (4 us bins)": [int(v) for v in hh[:16]], "by length of the merge selection (2 us bins)": [int(v) for v in hh[16:]]}))
     if hasattr(L, "xmi_debug_span"):
         import ctypes
         sp = (ctypes.c_ulonglong * 5)()

@@ -229,6 +229,9 @@ __device__ unsigned long long g_round_ticks[4][2][4];
 __device__ unsigned long long g_span[5];
 __device__ unsigned long long g_span_start[1024];
 __device__ unsigned g_span_max[1024][2];
+// 64x64 merge path: workgroups by their length in steps of 4 us (last bin: 60 us and more), and by the length of their
+// merge selection alone in steps of 2 us
+__device__ unsigned long long g_merge64_hist[2][16];
 #define XMI_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #else
 #define XMI_STAMP(var)
@@ -356,6 +359,10 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         atomicAdd(&g_round_ticks[si][path][1], t_search - t_merge);
         atomicAdd(&g_round_ticks[si][path][2], t_end - t_search);
         atomicAdd(&g_round_ticks[si][path][3], 1ull);
+        if (N == 64 && path == 0) {
+            atomicAdd(&g_merge64_hist[0][min(15ull, (t_end - t_begin) / 400)], 1ull);
+            atomicAdd(&g_merge64_hist[1][min(15ull, (t_merge - t_begin) / 200)], 1ull);
+        }
 #endif
     }
 }
@@ -1819,6 +1826,7 @@ int xmi_debug_round_classes(unsigned long long *out)
         for (int k = 0; k < 3; k++) out[c * 3 + k] = g_round_class[c][k].exchange(0);
     return 0;
 }
+int xmi_debug_merge64_hist(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_merge64_hist), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
 int xmi_debug_span(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_span), sizeof(unsigned long long) * 5) == hipSuccess ? 0 : -1; }
 int xmi_debug_clock_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_ticks), sizeof(unsigned long long) * 2) == hipSuccess ? 0 : -1; }
 int xmi_debug_round_ticks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_ticks), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -1; }
