@@ -4,6 +4,7 @@
 // into oracle/libx265_analysis_check.so by `make -C oracle analysis_check`. Nothing in the product links or loads this.
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../x265_amd/csrc/host/analysis_core.h"
@@ -55,7 +56,44 @@ public:
         int16_t *w = words.data();
         for (int i = 0; i < ncu; i++) one_cu(*cu[i], b, w);
         for (int i = 0; i < nch; i++) one_chroma(*ch[i], b, w);
+        if (defer)      // the results are held back as an evaluator with answers still under way would: finish_*() brings them
+            for (int i = 0; i < ncu; i++) {
+                CuEval &q = *cu[i];
+                held[&q] = q;
+                q.best_merge = 0x7bad, q.ssd_skip = q.ssd_merge = q.ssd_me = 0x7bad7badu;
+                q.mv_me = { 0x7bad, 0x7bad };
+                for (int u = 0; u < 4; u++) q.sum_merge[u] = q.sum_me[u] = 0x7bad7badu;
+                q.merge_pending = q.search_pending = &q;
+            }
         return 0;
+    }
+
+    // test switches: hold the results of the CU requests back until finish_merge() / finish_search() ask for them (anything
+    // read before that is poison); let the n-th finish call fail
+    bool defer = false;
+    int fail_at = 0, finish_calls = 0;
+    std::unordered_map<const CuEval *, CuEval> held;
+
+    int finish_merge(CuEval &q) override
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!q.merge_pending) return 0;
+        const CuEval &s = held.at(&q);
+        q.best_merge = s.best_merge, q.ssd_skip = s.ssd_skip, q.ssd_merge = s.ssd_merge;
+        for (int u = 0; u < 4; u++) q.sum_merge[u] = s.sum_merge[u];
+        q.merge_pending = nullptr;
+        return ++finish_calls == fail_at ? -77 : 0;
+    }
+
+    int finish_search(CuEval &q) override
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!q.search_pending) return 0;
+        const CuEval &s = held.at(&q);
+        q.mv_me = s.mv_me, q.ssd_me = s.ssd_me;
+        for (int u = 0; u < 4; u++) q.sum_me[u] = s.sum_me[u];
+        q.search_pending = nullptr;
+        return ++finish_calls == fail_at ? -77 : 0;
     }
 
     int evaluate_intra(int lane, const IntraBatch &bt) override
@@ -387,6 +425,13 @@ int orc_analysis_workers(void *h, int n)
 {
     if (n < 0) return -1;
     static_cast<Handle *>(h)->an.workers = n;
+    return 0;
+}
+// test switches of the harness's evaluator: results held back until the rows ask for them; the n-th such request fails (0: none)
+int orc_analysis_defer(void *h, int on, int fail_at)
+{
+    CpuEvaluator &ev = static_cast<Handle *>(h)->ev;
+    ev.defer = on != 0, ev.fail_at = fail_at, ev.finish_calls = 0;
     return 0;
 }
 void orc_analysis_destroy(void *h) { delete static_cast<Handle *>(h); }

@@ -98,7 +98,7 @@ def p(a):
 class Runner:
     """create / state / p_picture of either library, same argument lists (prefix orc_analysis_ or xmi_analysis_)."""
 
-    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0, speculate=None, workers=None):
+    def __init__(self, lib, prefix, w, h, lanes=None, spin_us=0, speculate=None, workers=None, defer=None):
         self.lib, self.w, self.h = lib, w, h
         self.create, self.destroy = getattr(lib, prefix + "create"), getattr(lib, prefix + "destroy")
         self.state, self.picture = getattr(lib, prefix + "state"), getattr(lib, prefix + "p_picture")
@@ -123,6 +123,11 @@ class Runner:
             wk.restype = C.c_int
             wk.argtypes = [C.c_void_p, C.c_int]
             assert wk(self.handle, workers) == 0
+        if defer is not None:        # (CPU harness only) results held back until the rows ask for them; (on, n-th request fails)
+            df = getattr(lib, prefix + "defer")
+            df.restype = C.c_int
+            df.argtypes = [C.c_void_p, C.c_int, C.c_int]
+            assert df(self.handle, *defer) == 0
         if prefix.startswith("orc_") or speculate is not None:
             spec = getattr(lib, prefix + "speculate")
             spec.restype = C.c_int
@@ -158,6 +163,9 @@ class Runner:
         rc = self.picture(self.handle, *[p(a) for a in src], *[p(a) for a in ref], pic["pad"], pic["qp"],
                           *[p(out[k]) for k in ("info0", "info1", "mv", "mvd", "mvp_idx", "coef_y", "coef_u", "coef_v", "rec_y", "rec_u", "rec_v",
                                                 "rd_cost", "ctx_in", "ctx_out", "counters")])
+        if getattr(self, "expect_rc", 0):
+            assert rc == self.expect_rc, f"p_picture returned {rc}, expected {self.expect_rc}"
+            return None
         assert rc == 0, f"p_picture returned {rc}"
         return out
 

@@ -133,6 +133,38 @@ def test_rows_sharing_worker_threads_do_not_change_the_result(lib, workers, lane
     check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin, workers=workers), tag)
 
 
+@pytest.mark.parametrize("level,lanes,spin,workers", [(2, 1, 0, None), (2, 2, 20, 2), (1, 2, 0, 1)])
+def test_answers_that_arrive_late_are_waited_for(lib, level, lanes, spin, workers):
+    """An evaluator may return while parts of its answers are still under way (CuEval::merge_pending / search_pending): here
+    the harness holds every result back and leaves poison in its place until the row asks for it (Evaluator::finish_merge /
+    finish_search) - a row that read a field before asking would decide differently."""
+    check_fixture_picture(lambda w, h: T.Runner(lib, "orc_analysis_", w, h, lanes, spin, speculate=level, workers=workers, defer=(1, 0)), "416x240_q32_p2")
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("fail_at,lanes,spin,workers", [(1, 1, 0, None), (7, 2, 20, 2), (40, 2, 0, 1), (150, 1, 0, 3)])
+def test_a_failing_late_answer_ends_the_picture(lib, fail_at, lanes, spin, workers):
+    """an error that a row meets while it waits for a late answer ends the picture with that error: rows that wait for a
+    neighbour or for a coordinator leave as well, nothing hangs, and the handle takes the next picture"""
+    g = np.load(GOLDEN)
+    pic, before, _ = fixture_picture(g, "416x240_q32_p2")
+    r = T.Runner(lib, "orc_analysis_", pic["w"], pic["h"], lanes, spin, speculate=2, workers=workers, defer=(1, fail_at))
+    try:
+        r.set_state(before, pic)
+        r.expect_rc = -77
+        assert r.run(pic) is None
+        r.expect_rc = 0
+        df = lib.orc_analysis_defer
+        assert df(r.handle, 0, 0) == 0
+        r.set_state(before, pic)
+        out = r.run(pic)
+        state = r.get_state(pic["rows"], pic["cols"])
+        pic["rec"] = (out["rec_y"], out["rec_u"], out["rec_v"])
+        assert T.compare(pic, out, state) == []
+    finally:
+        r.close()
+
+
 def test_hand_over_survives_many_pictures_and_settings(lib):
     """The rows hand their requests to the coordinators without a lock; the same picture again and again, with lane counts
     and polling times drawn at random (3 us: waiters usually run out of polling time and go to sleep in mid hand-over)."""
