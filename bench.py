@@ -222,7 +222,7 @@ def encode_rate(L, qp=32, segments=True):
             out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=SEGMENT_WORKERS)
             # the 3840x2160 configuration (coded 3840x2176), a short clip: to be read beside cpu_baseline.encoder_2160p
             uhd = bench_encoder.run(3840, 2160, UHD_FRAMES, qp)
-            out["uhd"] = {k: uhd[k] for k in ("what", "encode_fps", "pictures", "bytes", "md5", "i_picture_ms", "p_picture_ms", "p_stage_ms",
+            out["uhd"] = {k: uhd[k] for k in ("stream_matches_fixture", "what", "encode_fps", "pictures", "bytes", "md5", "i_picture_ms", "p_picture_ms", "p_stage_ms",
                                               "round_trips_per_p_picture") if k in uhd}
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own

@@ -18,7 +18,7 @@ from tests.prereq import needs_ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")))
-SEED = {416: 1234, 1920: 7}
+SEED = {416: 1234, 1920: 7, 3840: 1234}
 
 
 def clip(w, h, n):

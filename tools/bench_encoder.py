@@ -19,6 +19,15 @@ def clip(w, h, n, seed=None):
     return [frame(w, h, t, rng) for t in range(n)]
 
 
+def recorded_stream(w, h, n, qp):
+    """what tests/golden/encoder_md5.json holds for this clip (written by the reference-control-flow build, tools/enc_parity.py), or None"""
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "encoder_md5.json")) as f:
+            return json.load(f).get(f"{w}x{h}_f{n}_q{qp}")
+    except OSError:
+        return None
+
+
 def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, speculate=None):
     """one picture stream: the clip of the CPU baseline (tools/gen_yuv.py, seed 7 at 1080p), picture 0 intra; wall clock of the
     encode calls (pictures resident in host memory; the call uploads them)"""
@@ -45,8 +54,11 @@ def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, specula
     finally:
         enc.close()
     p_ms = [p["ms"] for p in per[1:]]
-    return {"what": f"{w}x{h} synthetic IPPP, {n} pictures, QP {qp}: this library's encoder (xmi_encoder_encode), one picture stream",
-            "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": hashlib.md5(stream).hexdigest(),
+    md5 = hashlib.md5(stream).hexdigest()
+    want = recorded_stream(w, h, n, qp)
+    return {"stream_matches_fixture": None if want is None else bool((want["md5"], want["bytes"]) == (md5, len(stream))),
+            "what": f"{w}x{h} synthetic IPPP, {n} pictures, QP {qp}: this library's encoder (xmi_encoder_encode), one picture stream",
+            "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": md5,
             "i_picture_ms": per[0]["ms"], "i_picture_round_trips": per[0]["round_trips"], "i_picture_us_per_round_trip": per[0]["us_per_round_trip"], "p_picture_ms": round(float(np.mean(p_ms)), 2) if p_ms else None,
             "p_pictures_per_s": round(1e3 / float(np.mean(p_ms)), 2) if p_ms else None,
             "p_stage_ms": {k: round(float(np.mean([p[k] for p in per[1:]])), 2) for k in ("analysis_ms", "deblock_ms", "sao_ms", "write_ms")} if p_ms else None,
