@@ -433,6 +433,9 @@ def main():
                 out["encode"] = encode_rate(L, segments=not args.no_segments)
                 if enc_ranks:
                     good = [r for r in enc_ranks if r and "error" not in r]
+                    failed = {str(i): (r or {}).get("error", "no result") for i, r in enumerate(enc_ranks) if not r or "error" in r}
+                    if failed:      # a sum over fewer ranks than ran is not a whole-job figure: say which ranks failed and why
+                        out["encode"]["all_ranks_8_segments_error"] = failed
                     out["encode"]["all_ranks_8_segments"] = {"p_pictures_per_s": round(sum(r["p_pictures_per_s"] for r in good), 2),
                                                              "encode_fps": round(sum(r["encode_fps"] for r in good), 2), "ranks": len(good),
                                                              "per_rank_p_pictures_per_s": [r.get("p_pictures_per_s") if r else None for r in enc_ranks]}

@@ -39,10 +39,14 @@ extern "C" {
 #define XMI_MODE_INVALID 255   /* inc/x265.h:163: "not an intra luma mode" -> DCT, not DST, for 4x4 */
 
 /* ---- library ------------------------------------------------------------------------------ */
-/* Bind the calling process to `device` and make it the calling thread's current device; idempotent. With more than one
- * device visible this call is required before any other entry point (with one device the first call binds device 0).
- * The library never changes a thread's current device afterwards: a call from a thread whose current device is not the
- * bound one fails with XMI_ERR_ARG. */
+/* Bind the calling process to `device` and make it the calling thread's current device; idempotent. Without this call the
+ * first entry point binds the calling thread's current device (HIP's default: device 0). One process, one device: run one
+ * process per GPU. After binding,
+ *   - entry points that take the caller's device pointers and a stream (the *_dev forms) never change a thread's current
+ *     device: called from a thread whose current device is not the bound one they fail with XMI_ERR_ARG;
+ *   - entry points that take host pointers or a handle of this library (per-call primitives, xmi_frame_*, xmi_analysis_*,
+ *     xmi_encoder_*, the host-plane forms of the picture filters) make the bound device current for the calling thread, so
+ *     they may be called from any host thread, also a fresh one. */
 int         xmi_init(int device);
 void        xmi_shutdown(void);        /* free library-owned device memory */
 const char *xmi_last_error(void);
@@ -311,13 +315,14 @@ int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t 
                           uint8_t *vertical_bs, uint8_t *horizontal_bs);
 
 /* xmi_deblock_strengths for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
- * hipMalloc, code around a graph capture): same arguments, same tables, but the maps and tables are staged in an array
+ * hipMalloc): same arguments, same tables, but the maps and tables are staged in an array
  * that is part of the library's device image (2.25 MiB per GPU the library runs on, held until the process ends) instead
  * of a buffer the library allocates, so the call performs no hipMalloc / hipFree. It has no counterpart in the reference.
  * Limit: width * height <= 4096 * 2304 luma samples, larger pictures are refused with XMI_ERR_ARG. Needs xmi_init() (or the
  * implicit binding of a one-device process) on the device it runs on. All calls on one GPU share that GPU's array: calls
  * of one process take turns on an internal mutex; the array keeps the last call's contents, and every byte a call reads
- * is written by that call first. */
+ * is written by that call first. The call copies synchronously and launches on the null stream: it is not for use while
+ * a stream capture is in progress in the process. */
 int xmi_deblock_strengths_static(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
                                  uint8_t *vertical_bs, uint8_t *horizontal_bs);
 
@@ -449,8 +454,13 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
  * xmi_encoder_create   : width, height = coded size (multiples of 64), qp 0..51, strong_intra_smoothing = the -sis switch.
  * xmi_encoder_configure: lanes / spin_us of the analysis loop (xmi_analysis_configure).
  * xmi_encoder_encode   : src_* packed source planes at coded size; slice_type XMI_SLICE_I or XMI_SLICE_P (a P picture needs a
- *                        picture before it); out must hold 3 * width * height + 4096 bytes. Returns the size of the access
- *                        unit or XMI_ERR_*.
+ *                        picture before it); out / capacity: at least 4096 bytes. Returns the size of the access unit or
+ *                        XMI_ERR_*. Nothing is ever written beyond out + capacity: an access unit that does not fit fails with
+ *                        XMI_ERR_ARG ("access unit exceeds capacity"); the slice data itself is limited to 3 * width * height
+ *                        + 4096 bytes, so a capacity of 3 * width * height + 8192 never is the limit. (The reference stops
+ *                        at 16 384 CABAC commands per CTU, inc/x265.h:416, long before that.) After a failed call the handle
+ *                        holds no reference picture: the next picture must be an I picture, and since the statistics
+ *                        carried from picture to picture may have advanced, streams no longer equal the reference's.
  * xmi_encoder_reconstruction: the last picture's reconstruction after the in-loop filters, packed planes.
  * xmi_encoder_timing   : of the last picture, out = { ns analysis, ns deblocking + SAO statistics, ns SAO decision + offsets, ns
  *                        writing, GPU round trips, CU / PU requests, and of the round trips: ns writing job tables, ns in the

@@ -40,13 +40,17 @@ def test_stream_equals_the_recorded_stream(key):
     assert hashlib.md5(stream).hexdigest() == GOLD[key]["md5"]
 
 
-def test_scene_change_detection_of_the_command_line():
-    """A clip whose scene changes at picture 6, encoded with the reference's scene-change detection on (its default): the
-    detection (src/preProcess.cpp:104, on the library's SAD) turns picture 6 into an I picture; the stream is the recorded one."""
+@pytest.mark.parametrize("cut", [6, 5])
+def test_scene_change_detection_of_the_command_line(cut):
+    """A clip whose scene changes at picture `cut`, encoded with the reference's scene-change detection on (its default): the
+    detection (src/preProcess.cpp:104, on the library's SAD) turns picture 6 into an I picture; the stream is the recorded one.
+    Cut at 6: the first picture at which the detection runs (more than four P pictures behind the I picture). Cut at 5: the
+    detection does not run at picture 5 and still fires at picture 6, because it compares with the reconstruction of the
+    picture before the last one (the slot it reads holds the last picture's reference by then)."""
     from x265_amd.encoder import encode_clip
-    key = "416x240_f8_q32_cut6_scenechange"
+    key = f"416x240_f8_q32_cut{cut}_scenechange"
     rng = np.random.default_rng(1234)
-    pics = [frame(416, 240, t, rng, cut=6) for t in range(8)]
+    pics = [frame(416, 240, t, rng, cut=cut) for t in range(8)]
     raw = b"".join(p.tobytes() for pic in pics for p in pic)
     assert hashlib.md5(raw).hexdigest() == GOLD[key]["input_md5"], "the generator no longer makes the recorded input"
     stream = encode_clip(pics, 416, 240, 32, scene_change=True)
@@ -89,6 +93,36 @@ def test_2160p_segments_equal_the_recorded_streams():
         want = gold[f"{b}-{b + 2}"]
         assert len(stream) == want["bytes"], f"segment {b}: {len(stream)} bytes, recorded {want['bytes']}"
         assert hashlib.md5(stream).hexdigest() == want["md5"], f"segment {b}"
+
+
+def test_2160p_eight_segments_at_the_same_time_on_one_gpu():
+    """What one rank of the sharded 3840x2160 configuration does, eight times over on this box's GPU: all eight GOP segments
+    of tests/golden/segment_md5_2160p.json as eight encoder handles that encode at the same time (a host thread and two
+    worker threads each, sleeping waiters). Every stream is the recorded one."""
+    import threading
+    from x265_amd.encoder import encode_clip
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "segment_md5_2160p.json")))["3840x2160_q32_seed11_gop2"]
+    assert len(gold) == 8
+    rng = np.random.default_rng(11)
+    pics = [frame(3840, 2160, t, rng) for t in range(16)]
+    got, errs = {}, []
+
+    def work(b):
+        try:
+            got[b] = encode_clip(pics[b:b + 2], 3840, 2160, 32, workers=2, spin_us=0)
+        except Exception as e:      # noqa: BLE001
+            errs.append((b, repr(e)))
+
+    th = [threading.Thread(target=work, args=(b,)) for b in range(0, 16, 2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for b in range(0, 16, 2):
+        want = gold[f"{b}-{b + 2}"]
+        assert len(got[b]) == want["bytes"], f"segment {b}: {len(got[b])} bytes, recorded {want['bytes']}"
+        assert hashlib.md5(got[b]).hexdigest() == want["md5"], f"segment {b}"
 
 
 def test_speculation_depth_does_not_change_the_stream():

@@ -113,3 +113,31 @@ def test_scan_tables_against_the_reference():
     cg32 = (C.c_uint16 * 64).in_dll(ref, "xg_sigLastScanCG32x32")
     assert [lib.orc_syntax_group_scan(0, 5)[i] for i in range(64)] == list(cg32)
     assert [lib.orc_syntax_group_scan(0, 4)[i] for i in range(16)] == [table[0][1][i] for i in range(16)]
+
+
+def test_small_output_buffer_is_refused_and_nothing_is_written_beyond_it():
+    """An access unit that does not fit the caller's buffer: the call fails, no byte beyond the capacity is touched, and the
+    handle then wants an I picture (it holds no reference picture any more)."""
+    from x265_amd.encoder import align_frame
+    lib = checker()
+    w, h, qp = 416, 240, 22
+    W, H = 448, 256
+    enc = lib.orc_encoder_create(W, H, qp, 0)
+    lib.orc_encoder_configure(enc, 1, 0)
+    rng = np.random.default_rng(1234)
+    pics = [align_frame(*frame(w, h, t, rng), W, H) for t in range(2)]
+    cap = 6000                                   # the I picture of this clip at QP 22 is about 27 KB
+    out = np.full(cap + 4096, 0xA5, np.uint8)
+
+    def call(pic, slice_type, capacity):
+        return lib.orc_encoder_encode(enc, pic[0].ctypes.data, pic[1].ctypes.data, pic[2].ctypes.data, slice_type, out.ctypes.data, capacity)
+
+    assert call(pics[0], 2, 100) == -100         # below the minimum: refused before anything runs
+    n = call(pics[0], 2, cap)
+    assert n == -102, n
+    assert (out[cap:] == 0xA5).all(), "bytes beyond the capacity were written"
+    assert call(pics[1], 1, out.size) == -101    # no reference picture after the failure
+    big = np.zeros(W * H * 3 + 4096, np.uint8)
+    n = lib.orc_encoder_encode(enc, pics[0][0].ctypes.data, pics[0][1].ctypes.data, pics[0][2].ctypes.data, 2, big.ctypes.data, big.size)
+    assert n > cap
+    lib.orc_encoder_destroy(enc)

@@ -14,7 +14,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden", "encoder_md5.json")
 # (width, height, frames, qp, scene cut at picture | None): with a cut the reference's scene-change detection is switched on
-CONFIGS = [(416, 240, 8, 32, None), (416, 240, 3, 22, None), (416, 240, 8, 27, None), (416, 240, 8, 37, None), (416, 240, 8, 32, 6),
+CONFIGS = [(416, 240, 8, 32, None), (416, 240, 3, 22, None), (416, 240, 8, 27, None), (416, 240, 8, 37, None), (416, 240, 8, 32, 6), (416, 240, 8, 32, 5),
            (1920, 1080, 4, 32, None), (1920, 1080, 3, 22, None), (1920, 1080, 3, 27, None), (1920, 1080, 3, 37, None),
            # the clips bench.py's encode legs are timed on: the published 64-picture 1080p configuration and the short 2160p clip
            (1920, 1080, 64, 32, None), (3840, 2160, 6, 32, None)]

@@ -127,9 +127,15 @@ def main():
     b, e = segments.partition_frames(args.frames, world, rank, args.gop)
     frames = clip_frames(w, h, e, args.seed)[b:e]
     # one encoder run per GOP of the span (fresh state each), on this rank's GPU
-    env_dev = os.environ.get("HIP_VISIBLE_DEVICES")
-    if not args.variant.startswith("refsse") and args.backend == "nccl" and world > 1 and env_dev is None:
-        os.environ["HIP_VISIBLE_DEVICES"] = str(local)
+    if args.variant == "own":
+        # the library runs inside this process: bind it to the rank's GPU (ranks of a gloo rehearsal share the devices there are)
+        from x265_amd import capi
+        L = capi.load()
+        capi.check(L.xmi_init(local % max(1, L.xmi_device_count())))
+    elif not args.variant.startswith("refsse") and world > 1 and os.environ.get("HIP_VISIBLE_DEVICES") is None:
+        import torch
+        # the in-situ encoders are child processes: each sees only its rank's GPU (set before the child starts, so it holds)
+        os.environ["HIP_VISIBLE_DEVICES"] = str(local % max(1, torch.cuda.device_count()))
     stream, secs, md5s, recs = b"", 0.0, {}, []
     with tempfile.TemporaryDirectory() as d:
         for g0 in range(b, e, args.gop):

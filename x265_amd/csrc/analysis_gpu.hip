@@ -1768,7 +1768,7 @@ extern "C" {
 
 xmi_analysis *xmi_analysis_create(int width, int height)
 {
-    if (xmi::require_device() != XMI_OK) return nullptr;
+    if (xmi::enter_device() != XMI_OK) return nullptr;
     if (width <= 0 || height <= 0 || width % 64 || height % 64 || width > 8192 || height > 4352) {
         xmi::set_error("xmi_analysis_create: %dx%d: the coded size must be a multiple of 64, at most 8192x4352", width, height);
         return nullptr;
@@ -1805,7 +1805,7 @@ int xmi_analysis_speculate(xmi_analysis *a, int level)
 
 int xmi_analysis_configure(xmi_analysis *a, int lanes, int spin_us)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(a, "xmi_analysis_configure: null handle");
     XMI_ARG(spin_us >= 0 && spin_us <= 1000000, "xmi_analysis_configure: spin_us %d", spin_us);
@@ -1866,7 +1866,7 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
                            int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, uint32_t *rd_cost,
                            uint8_t *ctx_in, uint8_t *ctx_out, uint64_t *counters)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(a && src_y && src_u && src_v && ref_y && ref_u && ref_v, "xmi_analysis_p_picture: null picture");
     XMI_ARG(pad == kPad, "xmi_analysis_p_picture: the reference must be padded by %d luma samples (got %d)", kPad, pad);
@@ -1905,7 +1905,7 @@ extern "C" {
 
 xmi_encoder *xmi_encoder_create(int width, int height, int qp, int strong_intra_smoothing)
 {
-    if (xmi::require_device() != XMI_OK) return nullptr;
+    if (xmi::enter_device() != XMI_OK) return nullptr;
     if (width <= 0 || height <= 0 || width % 64 || height % 64 || width > 8192 || height > 4352 || qp < 0 || qp > 51) {
         xmi::set_error("xmi_encoder_create: %dx%d qp %d: the coded size must be a multiple of 64, at most 8192x4352, qp 0..51", width, height, qp);
         return nullptr;
@@ -1926,7 +1926,7 @@ void xmi_encoder_destroy(xmi_encoder *e) { delete e; }
 
 int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(e, "xmi_encoder_configure: null handle");
     XMI_ARG(spin_us >= 0 && spin_us <= 1000000, "xmi_encoder_configure: spin_us %d", spin_us);
@@ -1956,7 +1956,7 @@ int xmi_encoder_speculate(xmi_encoder *e, int level)
 
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out, size_t capacity)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(e && src_y && src_u && src_v && out, "xmi_encoder_encode: null argument");
     XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_encode: slice type %d", slice_type);
@@ -1966,10 +1966,11 @@ int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *
     }
     const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ev, out, capacity);
     if (n > 0) return n;
-    if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold 3 * width * height + 4096 bytes");
-    else if (n == -101) xmi::set_error("xmi_encoder_encode: a P picture needs a picture before it");
+    if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold at least 4096 bytes");
+    else if (n == -101) xmi::set_error("xmi_encoder_encode: a P picture needs a picture before it (the first picture, or the one after a failed call, is an I picture)");
+    else if (n == -102) xmi::set_error("xmi_encoder_encode: access unit exceeds capacity (%zu bytes; slice data is limited to 3 * width * height + 4096 bytes)", capacity);
     else if (e->ev.first_error()[0]) xmi::set_error("xmi_encoder_encode: %s", e->ev.first_error());
-    return n == -100 || n == -101 ? XMI_ERR_ARG : (n == XMI_ERR_ARG || n == XMI_ERR_NO_DEVICE ? n : XMI_ERR_HIP);
+    return n == -100 || n == -101 || n == -102 ? XMI_ERR_ARG : (n == XMI_ERR_ARG || n == XMI_ERR_NO_DEVICE ? n : XMI_ERR_HIP);
 }
 
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v)

@@ -272,7 +272,7 @@ int xmi_deblock_strengths_dev(int width, int height, int intra_slice, const uint
 int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
                           uint8_t *vertical_bs, uint8_t *horizontal_bs)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(width >= 16 && height >= 16 && width % 8 == 0 && height % 8 == 0, "xmi_deblock_strengths: picture %dx%d must be a multiple of 8, at least 16x16", width,
             height);
@@ -295,7 +295,7 @@ int xmi_deblock_strengths(int width, int height, int intra_slice, const uint8_t 
 int xmi_deblock_strengths_static(int width, int height, int intra_slice, const uint8_t *unit_log2, const uint8_t *cbf, const int16_t *mv,
                                  uint8_t *vertical_bs, uint8_t *horizontal_bs)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(width >= 16 && height >= 16 && width % 8 == 0 && height % 8 == 0, "xmi_deblock_strengths_static: picture %dx%d must be a multiple of 8, at least 16x16",
             width, height);
@@ -357,7 +357,7 @@ int xmi_deblock_frame_dev(uint8_t *d_y, uint8_t *d_u, uint8_t *d_v, const xmi_de
 int xmi_deblock_frame(uint8_t *y, uint8_t *u, uint8_t *v, const xmi_deblock_params *prm, const uint8_t *vertical_bs,
                       const uint8_t *horizontal_bs, const uint8_t *qp_tab)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(y && u && v && prm && vertical_bs && horizontal_bs && qp_tab, "xmi_deblock_frame: null argument");
     XMI_ARG(prm->width >= 16 && prm->height >= 16 && prm->width % 8 == 0 && prm->height % 8 == 0 && prm->stride_y >= prm->width &&

@@ -36,7 +36,7 @@ int xmi_frame_padding_dev(uint8_t *d_plane, int stride, int width, int height, i
 
 int xmi_frame_padding(uint8_t *plane, int stride, int width, int height, int pad)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(plane && width > 0 && height > 0 && pad > 0 && stride >= width + 2 * pad, "xmi_frame_padding: bad argument");
     std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());

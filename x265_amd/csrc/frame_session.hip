@@ -47,7 +47,7 @@ extern "C" {
 
 int xmi_frame_create(int width, int height, int pad, xmi_frame **out)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(out, "xmi_frame_create: null argument");
     XMI_ARG(width > 0 && height > 0 && width % 4 == 0, "xmi_frame_create: %dx%d: width must be a positive multiple of 4", width, height);
@@ -94,7 +94,7 @@ int xmi_frame_destroy(xmi_frame *f)
 
 int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint8_t *ref_padded, int ref_stride)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && cur && ref_padded, "xmi_frame_begin: null argument");
     XMI_ARG(cur_stride >= f->width && ref_stride >= f->stride, "xmi_frame_begin: strides %d / %d too small for %dx%d (+%d)", cur_stride,
             ref_stride, f->width, f->height, f->pad);
@@ -112,7 +112,7 @@ int xmi_frame_begin(xmi_frame *f, const uint8_t *cur, int cur_stride, const uint
 
 int xmi_frame_sad_surface(xmi_frame *f, int range)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_sad_surface: no picture (call xmi_frame_begin first)");
     XMI_ARG(f->width % 64 == 0 && f->height % 64 == 0, "xmi_frame_sad_surface: %dx%d is not a multiple of the 64x64 CTU", f->width, f->height);
     XMI_ARG(range == 16 || range == 32 || range == 64 || range == 128, "xmi_frame_sad_surface: range %d not in {16,32,64,128}", range);
@@ -140,7 +140,7 @@ int xmi_frame_sad_surface(xmi_frame *f, int range)
 
 int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture && planes, "xmi_frame_planes_host: no picture or null destination");
     XMI_HIP(hipMemcpyAsync(planes, f->d_planes, 16 * (size_t)f->rows * f->stride, hipMemcpyDeviceToHost, f->stream));
     XMI_HIP(hipStreamSynchronize(f->stream));
@@ -149,7 +149,7 @@ int xmi_frame_planes_host(xmi_frame *f, uint8_t *planes)
 
 int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_range, xmi_me_result *res)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_me_search: no picture (call xmi_frame_begin first)");
     XMI_ARG(n >= 0 && (n == 0 || (req && res)), "xmi_frame_me_search: bad request table");
     if (n == 0) return XMI_OK;
@@ -183,7 +183,7 @@ int xmi_frame_me_search(xmi_frame *f, const xmi_me_request *req, int n, int me_r
 
 int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_intra_request *req, int n, xmi_intra_result *res)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f && f->has_picture, "xmi_frame_intra_search: no picture (call xmi_frame_begin first)");
     XMI_ARG(n >= 0 && (n == 0 || (req && res && ref_samples)), "xmi_frame_intra_search: bad request table");
     if (n == 0) return XMI_OK;
@@ -211,7 +211,7 @@ int xmi_frame_intra_search(xmi_frame *f, const uint8_t *ref_samples, const xmi_i
 int xmi_frame_tu_chain(xmi_frame *f, int n, int count, const uint8_t *pix, const uint8_t *pred, const uint8_t *qp, const uint8_t *flags,
                        int16_t *level, uint8_t *rec, uint32_t *sum)
 {
-    if (int rc0 = xmi::require_device()) return rc0;   // also makes the library's device current for this thread
+    if (int rc0 = xmi::enter_device()) return rc0;   // also makes the library's device current for this thread
     XMI_ARG(f, "xmi_frame_tu_chain: null session");
     XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32, "xmi_frame_tu_chain: transform size %d not in {4,8,16,32}", n);
     XMI_ARG(count >= 0 && (count == 0 || (pix && pred && qp && flags && level && rec && sum)), "xmi_frame_tu_chain: bad arguments");

@@ -19,6 +19,10 @@ void BitWriter::drain(uint32_t &word, int bits)
     for (int i = 0; i < (bits >> 3); i++) {
         const uint32_t b = word >> 24;
         word <<= 8;
+        if (end_ - p_ < 2) {      // room for the byte and its escape, or nothing
+            overflow_ = true;
+            continue;
+        }
         if (p_[-1] == 0 && p_[-2] == 0 && b <= 3) {
             *p_++ = 0x03;
             escapes++;
@@ -59,6 +63,10 @@ int BitWriter::flush()
 
 void BitWriter::raw_bytes(const uint8_t *src, size_t n)
 {
+    if (n > (size_t)(end_ - p_)) {
+        overflow_ = true;
+        return;
+    }
     std::memcpy(p_, src, n);
     p_ += n;
 }

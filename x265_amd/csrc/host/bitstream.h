@@ -11,14 +11,17 @@ namespace bitstream {
 
 // Bits are collected msb first in a 32-bit cache and leave as bytes; a byte <= 3 that would follow two zero bytes of the
 // output gets 0x03 in front (flushCache_WPP_Amendment_1_YANAN, inc/bitstream.h:48). The caller owns the buffer, and the
-// two bytes in front of `begin` must be readable (the escape test looks back over them).
+// two bytes in front of `begin` must be readable (the escape test looks back over them). Nothing is written at or beyond
+// `end`: bytes that do not fit are dropped and overflowed() says so (the reference's writer has no such limit and no check).
 class BitWriter {
 public:
-    void init(uint8_t *begin)
+    void init(uint8_t *begin, uint8_t *end)
     {
-        p_ = p0_ = begin;
-        cache_ = 0, cached_ = 0, escapes = 0;
+        p_ = p0_ = begin, end_ = end;
+        cache_ = 0, cached_ = 0, escapes = 0, overflow_ = false;
     }
+    bool overflowed() const { return overflow_; }
+    size_t room() const { return (size_t)(end_ - p_); }
     void put(uint32_t bits, int n);                 // xPutBits: n in 0..32, bits < 2^n
     void flag(unsigned v) { put(v ? 1u : 0u, 1); }
     void uvlc(uint32_t v);                          // xWriteUvlc
@@ -30,7 +33,11 @@ public:
         align_zero();
     }
     int flush();                                    // xBitFlush: whole bytes leave the cache; bytes written so far (a partial one counted)
-    void raw_byte(uint8_t b) { *p_++ = b; }         // start codes bypass the cache (xPutBits32); only on a byte boundary
+    void raw_byte(uint8_t b)                        // start codes bypass the cache (xPutBits32); only on a byte boundary
+    {
+        if (p_ < end_) *p_++ = b;
+        else overflow_ = true;
+    }
     void raw_bytes(const uint8_t *src, size_t n);
     uint8_t *pos() const { return p_; }
     int cached_bits() const { return cached_; }
@@ -38,7 +45,8 @@ public:
 
 private:
     void drain(uint32_t &word, int bits);
-    uint8_t *p_ = nullptr, *p0_ = nullptr;
+    uint8_t *p_ = nullptr, *p0_ = nullptr, *end_ = nullptr;
+    bool overflow_ = false;
     uint32_t cache_ = 0;
     int cached_ = 0;
 };

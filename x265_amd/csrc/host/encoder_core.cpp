@@ -487,9 +487,20 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     const bool intra = slice_type == 2;
     if (!intra && !have_ref_) return -101;
     const size_t ny = (size_t)w_ * h_;
-    if (cap < ny * 3 + 4096) return -100;      // an access unit cannot be larger than the reference's own output buffers allow for
-    poc_++;
-    if (intra) poc_ = 0;
+    if (cap < 4096) return -100;               // parameter sets, slice header and the picture hash need a few hundred bytes at most
+    // What the handle carries from picture to picture is committed when the access unit is complete; an error on the way leaves
+    // the handle without a reference picture (its analysis statistics may have advanced: the sequence cannot go on).
+    struct Commit {
+        Encoder &e;
+        bool ok = false;
+        int poc;
+        ~Commit()
+        {
+            if (ok) e.poc_ = poc, e.have_ref_ = true;
+            else e.have_ref_ = false;
+        }
+    } commit{ *this, false, intra ? 0 : poc_ + 1 };
+    const int poc = commit.poc;
     const int wc = w_ / 2, hc = h_ / 2;
     if (!intra) {
         pad_plane(ref_[0].data(), w_, h_, kPad);
@@ -498,7 +509,7 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     }
 
     BitWriter bs;
-    bs.init(out);
+    bs.init(out, out + cap);
     auto start_code = [&](uint8_t nal_type_byte) {
         bs.raw_byte(0), bs.raw_byte(0), bs.raw_byte(1), bs.raw_byte(nal_type_byte);
     };
@@ -571,19 +582,27 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     // The picture hash of the final reconstruction (src/encode.cpp:6012-6053) follows the slice in the access unit and does not
     // depend on it: MD5 runs at about 0.8 GB/s and cannot be split within a plane, so luma and the two chroma planes are
     // hashed on two threads while this one writes the slice.
+    sub_.resize(ny * 3 + 4096);      // (before the threads start: nothing below this line throws while they are joinable)
     uint8_t digest[3][16];
+    struct Joiner {
+        std::thread &t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    };
     std::thread hash_y([&] { bitstream::md5_plane(rec_[0].data(), (size_t)w_, (size_t)w_, (size_t)h_, digest[0]); });
     std::thread hash_c([&] {
         bitstream::md5_plane(rec_[1].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[1]);
         bitstream::md5_plane(rec_[2].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[2]);
     });
+    Joiner join_y{ hash_y }, join_c{ hash_c };
 
     // ---- slice header, then the slice data: one substream per CTU row (xCompressCU, src/encode.cpp:5594-5750) ----
-    bitstream::write_slice_header(bs, slice_type, poc_, sao_on_[0], sao_on_[1], qp_);
-    sub_.resize(ny * 3 + 4096);
+    bitstream::write_slice_header(bs, slice_type, poc, sao_on_[0], sao_on_[1], qp_);
     sub_[0] = sub_[1] = 0xff;
     BitWriter sb;
-    sb.init(sub_.data() + 2);
+    sb.init(sub_.data() + 2, sub_.data() + sub_.size());
     Cabac cabac;
     cabac.out = &sb;
     analysis::init_contexts(slice_type, qp_, cabac.ctx);
@@ -643,13 +662,15 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     cabac.out = &bs;
     cabac.flush();      // the reference flushes the coder a second time, into the access unit (src/encode.cpp:5749)
     bs.trailing_bits();
+    // slice data beyond the substream buffer (more than 3 bytes per luma sample), or an access unit beyond the caller's buffer:
+    // nothing was written past either end; the call fails. 64 bytes cover the picture-hash unit that follows, escapes included.
+    if (sb.overflowed() || bs.overflowed() || bs.room() < 64 + 8) return -102;
 
     // ---- the reconstruction becomes the reference of the next picture ----
     for (int c = 0; c < 3; c++) {
         const int pw = c ? wc : w_, ph = c ? hc : h_, pad = c ? kPadC : kPad, stride = pw + 2 * pad;
         for (int i = 0; i < ph; i++) std::memcpy(&ref_[c][(size_t)(pad + i) * stride + pad], &rec_[c][(size_t)i * pw], (size_t)pw);
     }
-    have_ref_ = true;
 
     // ---- picture hash SEI ----
     hash_y.join(), hash_c.join();
@@ -662,6 +683,8 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     bs.flush();
     int len = bs.flush();
     if (out[len - 1] == 0) out[len++] = 0x03;
+    if (bs.overflowed()) return -102;
+    commit.ok = true;
     const auto t4 = clock::now();
     stage_ns[0] = ns(t0, t1), stage_ns[1] = ns(t1, t2), stage_ns[2] = ns(t2, t3), stage_ns[3] = ns(t3, t4);
     return len;

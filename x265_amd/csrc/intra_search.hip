@@ -184,7 +184,7 @@ extern "C" int xmi_intra_pred_batch_dev(const uint8_t *d_ref_samples, const xmi_
 
 extern "C" int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t stride, uint32_t mode, uint32_t size, uint32_t is_luma)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(dst && ref, "xmi_enc_intra_pred: null argument");
     XMI_ARG(size == 4 || size == 8 || size == 16 || size == 32, "xmi_enc_intra_pred: size %u not in {4,8,16,32}", size);
@@ -211,7 +211,7 @@ extern "C" int xmi_enc_intra_pred(uint8_t *dst, const uint8_t *ref, uint32_t str
 extern "C" int xmi_intra_search(const uint8_t *src, uint32_t src_stride, const uint8_t *ref_samples, const xmi_intra_request *req,
                                 xmi_intra_result *res)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(src && ref_samples && req && res, "xmi_intra_search: null argument");
     const int n = req->size;
@@ -269,7 +269,7 @@ extern "C" int xmi_intra_chroma_search_batch_dev(const uint8_t *d_src_u, const u
 extern "C" int xmi_intra_chroma_search(const uint8_t *src_u, const uint8_t *src_v, uint32_t src_stride, const uint8_t *ref_u, const uint8_t *ref_v,
                                        int size, int luma_mode, xmi_chroma_result *res)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(src_u && src_v && ref_u && ref_v && res, "xmi_intra_chroma_search: null argument");
     XMI_ARG(size == 4 || size == 8 || size == 16, "xmi_intra_chroma_search: size %d not in {4,8,16}", size);

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) mv_store_kernel(const StoreParams p)
 extern "C" int xmi_fill_mvp_cand(int16_t (*mvp)[2], const uint8_t *mode_y, const int16_t (*mv)[2], uint32_t size_x, uint32_t size_y, uint32_t pu_mode,
                                  uint32_t pu_idx)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(mvp && mode_y && mv, "xmi_fill_mvp_cand: null argument");
     XMI_ARG(size_x >= 8 && size_y >= 8 && size_x <= 64 && size_y <= 64 && size_x % 8 == 0 && size_y % 8 == 0, "xmi_fill_mvp_cand: PU %ux%u", size_x, size_y);

@@ -42,7 +42,7 @@ void unpack(T *dst, size_t stride, const T *src, int w, int h)
 
 int64_t metric_call(const char *who, int metric, int n, const uint8_t *a, size_t sa, const uint8_t *b, size_t sb)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(a && b, "%s: null argument", who);
     XMI_ARG(n == 4 || n == 8 || n == 16 || n == 32 || n == 64, "%s: block size %d not in {4,8,16,32,64}", who, n);
@@ -92,7 +92,7 @@ int64_t xmi_satd_hm(int n, const uint8_t *src, uint32_t ss, const uint8_t *ref, 
 int xmi_sub_dct(int16_t *dst, const uint8_t *src, uint32_t stride, const uint8_t *pred, uint32_t stride_pred,
                 int width, uint32_t mode)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(dst && src && pred, "xmi_sub_dct: null argument");
     XMI_ARG(width == 4 || width == 8 || width == 16 || width == 32, "xmi_sub_dct: width %d not in {4,8,16,32}", width);
@@ -115,7 +115,7 @@ int xmi_sub_dct(int16_t *dst, const uint8_t *src, uint32_t stride, const uint8_t
 
 int64_t xmi_quant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, int width, int height, int slice_type)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(dst && src, "xmi_quant: null argument");
     XMI_ARG((width == 4 || width == 8 || width == 16 || width == 32) && height == width, "xmi_quant: %dx%d is not a square TU of 4..32", width, height);
@@ -142,7 +142,7 @@ int64_t xmi_quant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp
 
 int xmi_dequant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, int width, int height)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(dst && src, "xmi_dequant: null argument");
     XMI_ARG((width == 4 || width == 8 || width == 16 || width == 32) && height == width, "xmi_dequant: %dx%d is not a square TU of 4..32", width, height);
@@ -166,7 +166,7 @@ int xmi_dequant(int16_t *dst, const int16_t *src, uint32_t stride, uint32_t qp, 
 int xmi_idct_add(uint8_t *dst, uint32_t stride_dst, const int16_t *src, uint32_t stride, const uint8_t *pred,
                  int width, uint32_t mode)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(dst && src && pred, "xmi_idct_add: null argument");
     XMI_ARG(width == 4 || width == 8 || width == 16 || width == 32, "xmi_idct_add: width %d not in {4,8,16,32}", width);
@@ -190,7 +190,7 @@ int xmi_idct_add(uint8_t *dst, uint32_t stride_dst, const int16_t *src, uint32_t
 int64_t xmi_tu_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *coef, int size, int stride,
                      int stride_rec, uint32_t qp, uint32_t mode, int slice_type)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(pix && pred && rec && coef, "xmi_tu_chain: null argument");
     XMI_ARG(size == 4 || size == 8 || size == 16 || size == 32, "xmi_tu_chain: size %d not in {4,8,16,32}", size);

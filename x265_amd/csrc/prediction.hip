@@ -143,7 +143,7 @@ std::mutex g_mu;   // the per-call forms share one staging area
 // One block through the kernel: window gathered on the host, uploaded as a tiny plane of its own.
 int percall(const char *who, bool chroma, const uint8_t *ref, uint8_t *pred, uint32_t ref_stride, uint32_t sx, uint32_t sy, int mvx, int mvy)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(ref && pred, "%s: null argument", who);
     XMI_ARG(sx == sy && (chroma ? (sx == 4 || sx == 8 || sx == 16 || sx == 32) : (sx == 8 || sx == 16 || sx == 32 || sx == 64)),

@@ -454,7 +454,7 @@ int xmi_sad_surface_dev(const xmi_sad_geom *g, const uint8_t *d_cur, const uint8
 int xmi_sad_surface(const xmi_sad_geom *g, const uint8_t *cur, const uint8_t *ref_origin, int pad,
                     uint16_t *sad8, uint16_t *sad16, uint32_t *sad32, uint32_t *sad64)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(g && cur && ref_origin && sad8 && sad16 && sad32 && sad64, "xmi_sad_surface: null argument");
     XMI_ARG(range_ok(g->range), "xmi_sad_surface: range %d not in {16,32,64,128}", g->range);

@@ -250,7 +250,7 @@ int xmi_sao_stats_dev(const xmi_sao_geom *g, const uint8_t *d_rec_y, const uint8
 int xmi_sao_stats_frame(const xmi_sao_geom *g, const uint8_t *rec_y, const uint8_t *rec_u, const uint8_t *rec_v, const uint8_t *org_y,
                   const uint8_t *org_u, const uint8_t *org_v, xmi_sao_stats *stats)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     rc = check_geom("xmi_sao_stats_frame", g);
     if (rc != XMI_OK) return rc;
@@ -291,7 +291,7 @@ int xmi_sao_apply_plane_dev(const uint8_t *d_src, int src_stride, uint8_t *d_dst
 
 int xmi_sao_apply_plane(uint8_t *plane, int stride, int width, int height, int ctu_size, const xmi_sao_ctu_param *params)
 {
-    int rc = xmi::require_device();
+    int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(plane && params && width > 0 && height > 0 && stride >= width && (ctu_size == 64 || ctu_size == 32), "xmi_sao_apply_plane: bad argument");
     std::lock_guard<std::mutex> lk(xmi::picture_call_mutex());

@@ -12,7 +12,9 @@
 namespace xmi {
 
 void set_error(const char *fmt, ...);
-int  require_device();          // XMI_OK or XMI_ERR_NO_DEVICE (initialises on first use)
+int  require_device();          // XMI_OK or XMI_ERR_*: binds on first use; the caller's current device must be the bound one
+int  enter_device();            // the same for host-pointer / handle entry points: makes the bound device current for the thread
+int  bound_device();            // -1 before the first binding
 hipStream_t as_stream(void *s);
 
 // per-device set-up of sad_surface.hip (LDS opt-in of its kernels); called when the library binds a device

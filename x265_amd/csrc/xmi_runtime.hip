@@ -49,33 +49,57 @@ static int init_locked(int device)
     return XMI_OK;
 }
 
+// Implicit binding (no xmi_init before the first call): the calling thread's current device - HIP's own default, device 0
+// unless the caller chose another one - so a host that only links the drop-in works on a box with several GPUs as any HIP
+// program does.
+static int bind_implicitly_locked()
+{
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+    return init_locked(cur);
+}
+
+// Entry points that take the caller's device pointers and stream: the library never switches such a caller's device behind
+// its back. A thread whose current device is another one than the bound one holds pointers of the wrong device and is told so.
 int require_device()
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_device >= 0) {
-        // The binding is per process and the library never switches a caller's device behind its back: a thread whose
-        // current device is another one (a torch caller on a different GPU, a fresh thread in a process bound to a
-        // device other than 0) is told so instead of being moved.
-        int cur = -1;
-        if (hipGetDevice(&cur) != hipSuccess) {
-            set_error("hipGetDevice failed");
-            return XMI_ERR_HIP;
-        }
-        if (cur != g_device) {
-            set_error("the calling thread's current device is %d but the library is bound to device %d: make it current "
-                      "(hipSetDevice / torch.cuda.set_device) before calling",
-                      cur, g_device);
-            return XMI_ERR_ARG;
-        }
-        return XMI_OK;
+    if (g_device < 0) return bind_implicitly_locked();
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) {
+        set_error("hipGetDevice failed");
+        return XMI_ERR_HIP;
     }
-    // implicit binding only where it cannot pick the wrong GPU
-    int n = 0;
-    if (hipGetDeviceCount(&n) == hipSuccess && n > 1) {
-        set_error("%d devices visible: call xmi_init(device) before any other entry point", n);
+    if (cur != g_device) {
+        set_error("the calling thread's current device is %d but the library is bound to device %d: make it current "
+                  "(hipSetDevice / torch.cuda.set_device) before calling",
+                  cur, g_device);
         return XMI_ERR_ARG;
     }
-    return init_locked(0);
+    return XMI_OK;
+}
+
+// Entry points that take host pointers or one of the library's handles (per-call primitives, frame session, analysis,
+// encoder): everything they touch on the GPU is the library's own, on the bound device, so the bound device is made current
+// for the calling thread - a fresh host thread starts on device 0 whatever the process was bound to, and the worker threads of
+// the handles do the same for themselves.
+int enter_device()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_device < 0) return bind_implicitly_locked();
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == g_device) return XMI_OK;
+    if (hipSetDevice(g_device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", g_device);
+        return XMI_ERR_HIP;
+    }
+    return XMI_OK;
+}
+
+int bound_device()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_device;
 }
 
 std::mutex &picture_call_mutex()

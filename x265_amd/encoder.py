@@ -91,18 +91,20 @@ class Encoder:
                                       "read_back": t[9] / 1e3 / n}}
 
 
-def scene_changed(enc, y_aligned, pictures_done, intra_period):
+def scene_changed(enc, y_aligned, pictures_done, intra_period, rec_y):
     """sceneChangeDetection (src/preProcess.cpp:104-152) with the library's SAD: 32x32 blocks of the picture about to be coded
-    against the previous picture's reconstruction; a block with SAD above 320 * 16 is a motion block, and 85 % motion blocks
-    make a scene change. As the reference computes it: its loops over the CTUs never move the two pointers, so it is the four
-    blocks of the first CTU, each counted once per CTU of the picture."""
+    against a reconstructed picture; a block with SAD above 320 * 16 is a motion block, and 85 % motion blocks make a scene
+    change. As the reference computes it: its loops over the CTUs never move the two pointers, so it is the four blocks of the
+    first CTU, each counted once per CTU of the picture; and `rec_y` is the reconstruction of the picture BEFORE the last one -
+    the function reads the slot h->pFrameRec after xEncodeFrame has exchanged the two pictures (src/encode.cpp:6087-6092), which
+    then holds the last picture's reference. A cut at picture c that falls into the first SCENE_CHANGE_INTERVAL pictures after
+    an I picture is therefore still seen at picture c + 1."""
     if pictures_done <= 0:
         return True
     if intra_period > 1 and pictures_done % intra_period == 0:
         return False
     from . import capi
     L = capi.load()
-    rec_y = enc.reconstruction()[0]
     ctus = (enc.W // 64) * (enc.H // 64)
     threshold = int(0.85 * (ctus * 4) + 0.5 + 1e-6)
     motion = 0
@@ -123,13 +125,17 @@ def encode_clip(frames, width, height, qp, intra_period=100, scene_change=False,
     enc = Encoder(width, height, qp, **kw)
     try:
         out, prev_intra, interval = [], False, 0
+        recs = []      # luma reconstructions of the last two pictures (only kept for the detection)
         for i, (y, u, v) in enumerate(frames):
             if y.shape != (enc.H, enc.W):
                 y, u, v = align_frame(y, u, v, enc.W, enc.H)
-            changed = scene_change and interval > 4 and scene_changed(enc, np.ascontiguousarray(y), i, intra_period)
+            # more than SCENE_CHANGE_INTERVAL = 4 P pictures since the last I picture: at least five pictures are coded
+            changed = scene_change and interval > 4 and scene_changed(enc, np.ascontiguousarray(y), i, intra_period, recs[-2])
             intra = (i % intra_period == 0 or changed) and not prev_intra
             interval = 0 if intra else interval + 1
             out.append(enc.encode(y, u, v, intra))
+            if scene_change:
+                recs = recs[-1:] + [enc.reconstruction()[0]]
             prev_intra = intra
         return b"".join(out)
     finally:
