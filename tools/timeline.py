@@ -32,23 +32,29 @@ for it in range(n_launch):     # sustained load, the last launch is analysed
                                      planes[1].data_ptr(), planes[2].data_ptr(), planes[3].data_ptr(), 0, nctu, s))
 torch.cuda.synchronize()
 print(f"{n_launch} launches back to back: {(time.perf_counter() - wall0) / n_launch * 1e6:.1f} us per launch (host clock)")
-buf = (C.c_uint64 * (6 * nctu))()
+nwg = nctu * (R // 32 if R >= 64 else 1)      # workgroups of a launch: one per CTU and slice of the dx range
+buf = (C.c_uint64 * (6 * nwg))()
 L.xmi_debug_timeline.argtypes = [C.c_void_p, C.c_int]
-assert L.xmi_debug_timeline(buf, nctu) == 0
-t = np.frombuffer(buf, np.uint64).reshape(nctu, 6).astype(np.int64)
+assert L.xmi_debug_timeline(buf, nwg) == 0
+t = np.frombuffer(buf, np.uint64).reshape(nwg, 6).astype(np.int64)
 dur, stg, loop, tail = t[:, 3] - t[:, 0], t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 r0 = t[:, 4].min()
 rs, re_ = t[:, 4] - r0, t[:, 5] - r0
-first = dur < np.median(dur)
-qsad_cycles = 8 * 136 * 64 * 16 // 4     # per SIMD for one workgroup: 8 wavefronts x 136 steps x 64 qsad x 16 cycles, over 4 SIMDs
-print(f"kernel span {re_.max() / 100:.1f} us; workgroups start within {rs.max() / 100:.2f} us")
+first = rs < 0.25 * re_.max()                 # workgroups that started with the launch; the others took a slot that became free
+steps = 136
+qsad_cycles = steps * 64 * 16                 # issue cycles of one wavefront's v_qsad_pk_u16_u8 over the main loop (one wavefront per SIMD and workgroup)
+print(f"kernel span {re_.max() / 100:.1f} us; {int(first.sum())} of {nwg} workgroups start within {rs[first].max() / 100:.2f} us")
 q = [0, 10, 25, 50, 75, 90, 100]
 print("start times, us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(rs, q)))
 print("end times,   us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(re_, q)))
 print("durations,   us, percentiles", q, ":", " ".join(f"{x / 100:.1f}" for x in np.percentile(re_ - rs, q)))
-for name, m in (("first workgroup of a CU", first), ("second workgroup of a CU", ~first)):
-    print(f"{name}: n {m.sum()}  ends at {re_[m].mean() / 100:.1f} us  core cycles: total {int(dur[m].mean())}  staging {int(stg[m].mean())}  "
-          f"main loop {int(loop[m].mean())}  dx=+R pass {int(tail[m].mean())}  core clock {float((dur[m] / ((t[m, 5] - t[m, 4]) * 10.0)).mean()):.3f} GHz")
-print(f"v_qsad_pk_u16_u8 issue bound of one workgroup's main loop: {qsad_cycles} cycles -> the first workgroup runs at "
-      f"{qsad_cycles / loop[first].mean():.1%} of it; both workgroups of a CU together need {int(dur[~first].mean())} cycles "
-      f"for 2 x {qsad_cycles} cycles of qsad issue ({2 * qsad_cycles / dur[~first].mean():.1%})")
+clk = dur / ((t[:, 5] - t[:, 4]) * 10.0)
+print(f"core clock inside the kernel (s_memtime / s_memrealtime over each workgroup): median {float(np.median(clk)):.3f} GHz, "
+      f"10th..90th percentile {float(np.percentile(clk, 10)):.3f}..{float(np.percentile(clk, 90)):.3f}")
+for name, m in (("workgroups of the first round", first), ("workgroups of the second round", ~first)):
+    if m.sum() == 0:
+        continue
+    print(f"{name}: n {m.sum()}  end at {re_[m].mean() / 100:.1f} us  core cycles: total {int(dur[m].mean())}  staging {int(stg[m].mean())}  "
+          f"main loop {int(loop[m].mean())}  dx=+R pass {int(tail[m].mean())}")
+print(f"two wavefronts share a SIMD: their v_qsad_pk_u16_u8 alone need 2 x {qsad_cycles} issue cycles per main loop; "
+      f"main loop of the first round {int(loop[first].mean())} cycles ({2 * qsad_cycles / loop[first].mean():.1%} of them SAD issue)")

@@ -29,7 +29,10 @@
 //
 // Measurement variants (never defined in the library build; tools/build_variant.sh compiles them into separate
 // libraries): XMI_EXP_NOSTORE / XMI_EXP_NOCOMPUTE leave out the stores / the SAD instructions to time the other half,
-// XMI_EXP_NOPEEL and XMI_EXP_NOSCHEDBAR undo two scheduling measures, XMI_EXP_TIMELINE records per-workgroup clocks.
+// XMI_EXP_HALFCOMPUTE leaves out half of the SAD instructions, XMI_EXP_NOPIPE runs full-range bands through the plain step
+// loop instead of the software pipeline, XMI_EXP_NOPEEL and XMI_EXP_NOSCHEDBAR undo two scheduling measures,
+// XMI_EXP_X4 / XMI_EXP_GROUPS0 / XMI_EXP_STORE_AUX=<bits> are the store-width, instruction-order and cache-policy
+// experiments, XMI_EXP_TIMELINE records per-workgroup clocks.
 #include "xmi_common.h"
 
 #include <type_traits>
@@ -59,6 +62,16 @@ constexpr int row_pitch(int R, int level) { return xmi::surface_row_pitch(R, lev
 
 __device__ __forceinline__ u64 pack64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+// Cache-policy bits of the surface stores in the pipelined loop: 2 = nt (non-temporal). The surface is written once and read
+// by a later kernel, if at all; streamed past the caches the launch is 3 % shorter (0.354 -> 0.343 ms at 1080p, R = 64, A/B in
+// one process per pair on two devices). With both halves of the kernel running the chip holds 2.04 GHz instead of the
+// 2.39 GHz it holds for either half alone (rocm-smi sclk and s_memtime / s_memrealtime inside the kernel), so what shortens
+// the launch is less energy per launch, not fewer cycles: scope bits (16 = sc1, 17 = sc0 sc1) gained 1 %, 16-byte stores 1 %,
+// the order of the SAD instructions nothing.
+#ifndef XMI_EXP_STORE_AUX
+#define XMI_EXP_STORE_AUX 2
+#endif
 __device__ __forceinline__ u32x2 as_u32x2(u64 v) { return __builtin_bit_cast(u32x2, v); }
 
 template <int CTRL>
@@ -167,6 +180,9 @@ __global__ void __launch_bounds__(8 * R / SPLIT, 2) sad_surface_kernel(const Sad
     char *o32 = reinterpret_cast<char *>(p.sad32 + row0 * ROW32);
     char *o64 = reinterpret_cast<char *>(p.sad64 + row0 * ROW64);
     const u32 off8 = (u32)(wave_g * 1024 + z * 16 + gl * 4) * 2u;   // child c adds c*512 bytes
+#ifdef XMI_EXP_X4
+    const u32 off8x = (u32)(wave_g * 2048 + (z * 4 + gl) * 16);
+#endif
     const u32 off16 = (u32)(wave_g * 256 + z * 16 + gl * 4) * 2u;
     const u32 off32 = (u32)(wave_g * 64 + q * 16 + gl * 4 + b) * 4u; // lane b stores the sum for dx = 4*gl + b
     const u32 off64 = (u32)(wave_g * 16 + gl * 4 + b) * 4u;
@@ -269,16 +285,182 @@ __global__ void __launch_bounds__(8 * R / SPLIT, 2) sad_surface_kernel(const Sad
             }
         }
     };
+    // The same group as a software pipeline, for full-range bands (ndy = 1 mod 8: every step from the eighth on completes a
+    // row, so no store is conditional). A step is four runs of 16 SAD instructions (256 issue cycles each); everything else
+    // is placed between the runs and is one step behind or ahead, so that a wavefront never waits for its own memory
+    // operations and its stores leave one or two at a time instead of seven in a burst at the step's end:
+    //   - the reference dwords of a run are read from LDS two runs earlier;
+    //   - the row completed by step s-1 (P0..P3) goes through the pyramid during step s: the 16x16 sum, the quad
+    //     reduce-scatter and the ds_swizzle after run 0, the ds_bpermute after run 1, the 64x64 total after run 2, with the
+    //     seven stores spread over the three gaps.
+    // sched_barrier keeps the compiler from pulling the pieces together again.
+    u64 P0 = 0, P1 = 0, P2 = 0, P3 = 0;          // the row completed by the previous step
+    u32 DA[5], DB[5];                            // the five dwords of the reference row that meet the upper / lower 8x8 children
+    u64 RA[4], RB[4];                            // the same as byte-shifted dword pairs, put together at the run that uses them first
+    auto load_row = [&](u32 (&d)[5], const int row) {
+        const u32 *rr = reinterpret_cast<const u32 *>(ref_lane + row * rls);
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = rr[k];
+    };
+    auto make_pairs = [&](u64 (&w)[4], const u32 (&d)[5]) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = pack64(d[k], d[k + 1]);
+    };
+    // A run's SAD instructions have no side effects, so nothing but data dependences would hold them in place: the empty
+    // asm statements (ordered among themselves and with the stores) take the run's operands in front of it and its results
+    // behind it, which ties the run between the memory operations written before and after it.
+    auto run16 = [&](auto phase_tag, const int u, const int cy, const int h, u64 (&w)[4]) {
+        constexpr int PHASE = decltype(phase_tag)::value;
+#ifndef XMI_EXP_NOCOMPUTE
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "+v"(w[k]));
+#ifdef XMI_EXP_GROUPS0      // experiment: the four instructions that share a reference operand issue back to back
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int yy = 0; yy < 4; yy++) {
+                const int y = h * 4 + yy;
+                if ((PHASE == 0 && y > u) || (PHASE == 2 && y < u)) continue;
+                const int j = (u - y) & 7;
+                const uint4 c = creg[cy * 8 + y];
+                u64 &a = acc[cy * 2 + (k >> 1)][j];
+                const u32 cd = k == 0 ? c.x : k == 1 ? c.y : k == 2 ? c.z : c.w;
+                a = __builtin_amdgcn_qsad_pk_u16_u8(w[k], cd, ((k & 1) == 0 && y == 0) ? 0ull : a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
+#pragma unroll
+        for (int yy = 0; yy < 4; yy++) {
+            const int y = h * 4 + yy;
+            if ((PHASE == 0 && y > u) || (PHASE == 2 && y < u)) continue;
+            const int j = (u - y) & 7;
+            const uint4 c = creg[cy * 8 + y];
+            const u64 a0 = (y == 0) ? 0ull : acc[cy * 2 + 0][j];
+            const u64 a1 = (y == 0) ? 0ull : acc[cy * 2 + 1][j];
+            acc[cy * 2 + 0][j] = __builtin_amdgcn_qsad_pk_u16_u8(w[1], c.y, __builtin_amdgcn_qsad_pk_u16_u8(w[0], c.x, a0));
+            acc[cy * 2 + 1][j] = __builtin_amdgcn_qsad_pk_u16_u8(w[3], c.w, __builtin_amdgcn_qsad_pk_u16_u8(w[2], c.z, a1));
+        }
+#endif
+#pragma unroll
+        for (int yy = 0; yy < 4; yy++) {
+            const int y = h * 4 + yy;
+            if ((PHASE == 0 && y > u) || (PHASE == 2 && y < u)) continue;
+            const int j = (u - y) & 7;
+            asm volatile("" : "+v"(acc[cy * 2 + 0][j]));
+            asm volatile("" : "+v"(acc[cy * 2 + 1][j]));
+        }
+#endif
+    };
+    // STORE: the previous step completed a row (dy index s - 8 of the band)
+    auto pipe_step = [&](auto phase_tag, auto store_tag, const int s, const int u) {
+        constexpr bool STORE = decltype(store_tag)::value;
+        const int soff = STORE ? __builtin_amdgcn_readfirstlane(s - 8) : 0;
+        u64 v16 = 0;
+        u32 r32 = 0, t64 = 0, swz = 0, bp = 0;
+        load_row(DB, 8 + s);
+        __builtin_amdgcn_sched_barrier(0);
+        make_pairs(RA, DA);
+        run16(phase_tag, u, 0, 0, RA);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STORE) {
+            v16 = P0 + P1 + P2 + P3;
+            r32 = quad_reduce_scatter((u32)v16, (u32)(v16 >> 32), b);
+            swz = (u32)__builtin_amdgcn_ds_swizzle((int)r32, kSwizzleXor16);
+#ifdef XMI_EXP_X4      // timing experiment only: the same bytes as two 16-byte stores per lane (not the documented layout)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ (u32)P0, (u32)(P0 >> 32), (u32)P1, (u32)(P1 >> 32) }, rs8, off8x, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+#elif !defined(XMI_EXP_NOSTORE)
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P0), rs8, off8, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P1), rs8, off8 + 512, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        run16(phase_tag, u, 0, 1, RA);
+        __builtin_amdgcn_sched_barrier(0);
+        load_row(DA, s + 1);
+        if constexpr (STORE) {
+            t64 = r32 + swz;
+            bp = (u32)__builtin_amdgcn_ds_bpermute((int)xor32_addr, (int)t64);
+#ifdef XMI_EXP_X4
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ (u32)P2, (u32)(P2 >> 32), (u32)P3, (u32)(P3 >> 32) }, rs8, off8x + 1024, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+#elif !defined(XMI_EXP_NOSTORE)
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P2), rs8, off8 + 1024, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P3), rs8, off8 + 1536, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        make_pairs(RB, DB);
+#ifndef XMI_EXP_HALFCOMPUTE
+        run16(phase_tag, u, 1, 0, RB);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STORE) {
+            t64 += bp;
+#ifdef XMI_EXP_NOSTORE
+            if (v16 == 0x1234567812345678ull && t64 == 77u)
+#endif
+            {
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v16), rs16, off16, soff * (ROW16 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(r32, rs32, off32, soff * (ROW32 * 4), XMI_EXP_STORE_AUX);
+                if (q == 0) __builtin_amdgcn_raw_buffer_store_b32(t64, rs64, off64, soff * (ROW64 * 4), XMI_EXP_STORE_AUX);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifndef XMI_EXP_HALFCOMPUTE
+        run16(phase_tag, u, 1, 1, RB);
+#endif
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("" : "+v"(acc[c][j]));
+        const int jd = (u + 1) & 7;
+        P0 = acc[0][jd], P1 = acc[1][jd], P2 = acc[2][jd], P3 = acc[3][jd];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Tag0 = std::integral_constant<int, 0>;
+    using Tag1 = std::integral_constant<int, 1>;
+    using Tag2 = std::integral_constant<int, 2>;
     const bool peel = (ndy & 7) == 1 && nsteps >= 24;
 #ifdef XMI_EXP_NOPEEL
-    for (int s0 = 0; s0 < nsteps; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
+    for (int s0 = 0; s0 < nsteps; s0 += 8) group(Tag1{}, s0);
 #else
     if (peel) {
-        group(std::integral_constant<int, 0>{}, 0);
-        for (int s0 = 8; s0 < nsteps - 8; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
-        group(std::integral_constant<int, 2>{}, nsteps - 8);
+#ifdef XMI_EXP_NOPIPE
+        group(Tag0{}, 0);
+        for (int s0 = 8; s0 < nsteps - 8; s0 += 8) group(Tag1{}, s0);
+        group(Tag2{}, nsteps - 8);
+#else
+        load_row(DA, 0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) pipe_step(Tag0{}, std::false_type{}, u, u);
+        for (int s0 = 8; s0 < nsteps - 8; s0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) pipe_step(Tag1{}, std::true_type{}, s0 + u, u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) pipe_step(Tag2{}, std::true_type{}, nsteps - 8 + u, u);
+        {   // the row completed by the last step
+            const int soff = __builtin_amdgcn_readfirstlane(nsteps - 8);
+            const u64 v16 = P0 + P1 + P2 + P3;
+            const u32 r32 = quad_reduce_scatter((u32)v16, (u32)(v16 >> 32), b);
+            u32 t64 = r32 + (u32)__builtin_amdgcn_ds_swizzle((int)r32, kSwizzleXor16);
+            t64 += (u32)__builtin_amdgcn_ds_bpermute((int)xor32_addr, (int)t64);
+#ifdef XMI_EXP_NOSTORE
+            if (v16 == 0x1234567812345678ull && t64 == 77u)
+#endif
+            {
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P0), rs8, off8, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P1), rs8, off8 + 512, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P2), rs8, off8 + 1024, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(P3), rs8, off8 + 1536, soff * (ROW8 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(as_u32x2(v16), rs16, off16, soff * (ROW16 * 2), XMI_EXP_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(r32, rs32, off32, soff * (ROW32 * 4), XMI_EXP_STORE_AUX);
+                if (q == 0) __builtin_amdgcn_raw_buffer_store_b32(t64, rs64, off64, soff * (ROW64 * 4), XMI_EXP_STORE_AUX);
+            }
+        }
+#endif
     } else {
-        for (int s0 = 0; s0 < nsteps; s0 += 8) group(std::integral_constant<int, 1>{}, s0);
+        for (int s0 = 0; s0 < nsteps; s0 += 8) group(Tag1{}, s0);
     }
 #endif
 
