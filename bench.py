@@ -36,6 +36,25 @@ UHD_FRAMES = 6          # pictures of the 3840x2160 encode legs
 SEGMENT_WORKERS = 2
 
 
+def host_core_slice(world, local):
+    """-> (cores this rank may use, host threads per encoder when eight encoders share them)"""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1, SEGMENT_WORKERS
+    limit = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)      # the GPU box exports its per-GPU core share this way
+    if world > 1:
+        per = max(1, len(cores) // world)
+        mine = cores[local * per:(local + 1) * per] or cores[-per:]
+        try:
+            os.sched_setaffinity(0, mine)
+            cores = mine
+        except OSError:
+            pass
+    n = len(cores) if world > 1 or not limit else min(len(cores), limit)
+    return n, max(1, n // 8)
+
+
 def measured_traffic(w, h, rng):
     """HBM bytes per launch from the committed PMC passes of this workload (x265_amd/measured_traffic.json), else None.
     Counters cannot be collected from inside this process; tools/profile_round.sh refreshes the file."""
@@ -146,14 +165,26 @@ def cpu_encoder_fps(frames=ENCODE_FRAMES, qp=32, width=1920, height=1080, seed=7
         one = run(exe, 1)
         if not one:
             return None
+        # The reference's encoder is timed as its command line runs: process start and reading the clip from the file included.
+        # This library's encoder (the `encode` block) is timed on pictures already in host memory. To compare like with like, the
+        # time this process needs to start a trivial child and to read the same file is measured here and taken off.
+        t0 = time.perf_counter()
+        subprocess.run(["/bin/true"], check=False)
+        with open(yuv, "rb") as f:
+            while f.read(1 << 24):
+                pass
+        overhead = time.perf_counter() - t0
         enc = {"fps": one[0], "frames": frames, "qp": qp, "threads": 1, "bytes": one[1],
-               "what": f"{width}x{height} synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included"}
+               "what": f"{width}x{height} synthetic IPPP, reference control flow and C++/SSE4 primitives, file I/O included",
+               "start_and_read_seconds": round(overhead, 3),
+               "fps_without_start_and_read": round(frames / max(1e-9, frames / one[0] - overhead), 3)}
         threads = min(16, cores)
         if os.path.exists(exe_mt) and threads > 1:
             many = run(exe_mt, threads)
             if many and many[1] == one[1]:
                 enc["fps_row_threads"] = many[0]
                 enc["row_threads"] = threads
+                enc["fps_row_threads_without_start_and_read"] = round(frames / max(1e-9, frames / many[0] - overhead), 3)
         return enc
 
 
@@ -184,7 +215,7 @@ def satd_rates(L, capi, torch, dev, stream, reps=10):
     return out
 
 
-def analysis_rate(L, qp=32, pictures=4, segments=True):
+def analysis_rate(L, qp=32, pictures=4, segments=True, workers=SEGMENT_WORKERS):
     """The encode-side half of the headline metric with this library's code only: P pictures per second of
     xmi_analysis_p_picture (mode decision + reconstruction of every CTU of a 1080p picture: the reference's xEncodeCUs for
     inter pictures, host decision logic + GPU pixel work). Outside the timed region, rank 0. The reference's own encoder on
@@ -200,7 +231,7 @@ def analysis_rate(L, qp=32, pictures=4, segments=True):
         if segments:
             by_level = {}
             for level in (1, 2):
-                seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L, speculate=level, workers=SEGMENT_WORKERS)
+                seg = bench_analysis.run_segments(1920, 1080, qp, 3, 8, lib=L, speculate=level, workers=workers)
                 by_level[level] = seg.get("analysis_fps", seg.get("error"))
             ok = {k: v for k, v in by_level.items() if isinstance(v, (int, float))}
             out["analysis_fps_8_segments"] = max(ok.values()) if ok else by_level[2]
@@ -210,7 +241,7 @@ def analysis_rate(L, qp=32, pictures=4, segments=True):
         return {"error": repr(e)}
 
 
-def encode_rate(L, qp=32, segments=True):
+def encode_rate(L, qp=32, segments=True, workers=SEGMENT_WORKERS):
     """The first half of the headline metric with this library's code only: encode fps of xmi_encoder_encode (analysis loop,
     in-loop filters, SAO, entropy coding; I and P pictures; the stream is the reference's, tests/test_encoder_gpu.py) on the
     clip the reference's encoder is timed on under cpu_baseline.encoder. Outside the timed region, rank 0."""
@@ -219,7 +250,7 @@ def encode_rate(L, qp=32, segments=True):
         import bench_encoder
         out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
         if segments:
-            out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=SEGMENT_WORKERS)
+            out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=workers)
             # the 3840x2160 configuration (coded 3840x2176), a short clip: to be read beside cpu_baseline.encoder_2160p
             uhd = bench_encoder.run(3840, 2160, UHD_FRAMES, qp)
             out["uhd"] = {k: uhd[k] for k in ("stream_matches_fixture", "what", "encode_fps", "pictures", "bytes", "md5", "i_picture_ms", "p_picture_ms", "p_stage_ms",
@@ -244,6 +275,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="diagnostic runs: leave out the satd and analysis blocks")
     ap.add_argument("--no-analysis", action="store_true", help="leave out the analysis block")
+    ap.add_argument("--uhd-segment-frames", type=int, default=0,
+                    help="with --gpus N > 1: also encode one 3840x2160 GOP segment of this many pictures per rank, all ranks at once "
+                         "(the sharded configuration; 16 is its published shape, 0 leaves the leg out)")
     ap.add_argument("--no-segments", action="store_true",
                     help="leave out the 8-segment leg of the analysis block (rocprofv3's kernel trace crashes inside hipLaunchKernel when "
                          "eight host threads launch at once)")
@@ -262,13 +296,18 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Host cores: the encode legs are host-bound (CTU-row fibers, entropy coding), so with several ranks on one host every rank
+    # takes its own slice of the cores this job may use - before anything here touches the GPU or starts a thread - and sizes
+    # the host-thread groups of its eight concurrent encoders to it. One rank keeps whatever it was given.
+    cores_per_rank, segment_workers = host_core_slice(world, local)
+
     import torch
     import torch.distributed as dist
     from x265_amd import capi
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
@@ -382,17 +421,28 @@ def main():
         devs = [f"cuda:{local}"]
     # encode leg of a multi-GPU run: every rank encodes its own GOP segments with the library's encoder at the same time
     # (8 concurrent segments per GPU, as in the single-GPU encode block); rank 0 reports the sum. No exchange inside.
-    enc_ranks = None
+    enc_ranks = uhd_ranks = None
     if world > 1 and not args.headline_only and not args.no_analysis:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_encoder
         dist.barrier()
         try:
-            mine = bench_encoder.run_segments(1920, 1080, 4, 32, 8, workers=SEGMENT_WORKERS)
+            mine = bench_encoder.run_segments(1920, 1080, 4, 32, 8, workers=segment_workers)
         except Exception as e:      # noqa: BLE001
             mine = {"error": repr(e)}
         enc_ranks = [None] * world
         dist.all_gather_object(enc_ranks, mine)
+        # the sharded 3840x2160 configuration: one GOP segment per rank and GPU (--uhd-segment-frames pictures each, the
+        # published shape is 16), all ranks at the same time, every rank with all the cores of its slice
+        uhd_ranks = None
+        if args.uhd_segment_frames > 0:
+            dist.barrier()
+            try:
+                one = bench_encoder.run_segments(3840, 2160, args.uhd_segment_frames, 32, 1, workers=None, seed0=9 + rank)
+            except Exception as e:      # noqa: BLE001
+                one = {"error": repr(e)}
+            uhd_ranks = [None] * world
+            dist.all_gather_object(uhd_ranks, one)
     if world > 1:              # all collectives are done: leave the group together, before rank 0's CPU-side legs
         dist.barrier()
         dist.destroy_process_group()
@@ -409,9 +459,15 @@ def main():
             "config": {"workload": f"{args.width}x{args.height} 8-bit luma (coded {w}x{h}, {nctu} CTUs), IPPP P-frame SAD pyramid, "
                                    f"search range {R} ({nmv1}x{nmv1} integer MVs), {args.frames} resident frames per GPU",
                        "cands_per_step": cands, "frames_per_s": round(args.steps * world / elapsed, 2),
-                       "parallelism": f"gop-segments x{world}", "rank_devices": devs, "rank_kernel_ms_avg": per_rank,
+                       "parallelism": f"gop-segments x{world}", "cores_per_rank": cores_per_rank, "workers": segment_workers,
+                       # what becomes of the surface: the library's encoder replays the reference's sparse diamond walk (about ten of
+                       # the 16 641 vectors per PU) and computes those SADs itself; the surface serves exhaustive searches
+                       "consumed_by_encoder": False, "rank_devices": devs, "rank_kernel_ms_avg": per_rank,
                        "gathered_records": int(allrec.shape[0]), "matching_cost_per_frame_mean": round(float(allrec[:, 5].mean()), 1)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # bound: the figure is bytes against the HBM peak. What holds the kernel below it, by the counters and clock probes under
+            # profiles/: store path (5.4 TB/s ceiling for streaming stores) and SAD issue rate are within 10 % of each other, and with
+            # both running the chip lowers its clock from 2.39 to 2.04 GHz (either half alone keeps 2.39).
+            "roofline": {"bound": "hbm", "limiter": "stores + SAD issue under a power-lowered clock (2.04 of 2.39 GHz)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(w, h, R),
                          "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kern_avg_ms, 4),
                          "kernel_ms_min": round(kern_ms[0], 4)},
@@ -429,8 +485,8 @@ def main():
         if not args.headline_only:
             out["satd"] = satd_rates(L, capi, torch, dev, stream)
             if not args.no_analysis:
-                out["analysis"] = analysis_rate(L, segments=not args.no_segments)
-                out["encode"] = encode_rate(L, segments=not args.no_segments)
+                out["analysis"] = analysis_rate(L, segments=not args.no_segments, workers=segment_workers)
+                out["encode"] = encode_rate(L, segments=not args.no_segments, workers=segment_workers)
                 if enc_ranks:
                     good = [r for r in enc_ranks if r and "error" not in r]
                     failed = {str(i): (r or {}).get("error", "no result") for i, r in enumerate(enc_ranks) if not r or "error" in r}
@@ -439,9 +495,29 @@ def main():
                     out["encode"]["all_ranks_8_segments"] = {"p_pictures_per_s": round(sum(r["p_pictures_per_s"] for r in good), 2),
                                                              "encode_fps": round(sum(r["encode_fps"] for r in good), 2), "ranks": len(good),
                                                              "per_rank_p_pictures_per_s": [r.get("p_pictures_per_s") if r else None for r in enc_ranks]}
+                if uhd_ranks:
+                    good = [r for r in uhd_ranks if r and "error" not in r]
+                    out["encode"]["all_ranks_2160p_one_segment_each"] = {
+                        "what": f"3840x2160, one GOP segment of {args.uhd_segment_frames} pictures per rank, all ranks at the same time",
+                        "encode_fps": round(sum(r["encode_fps"] for r in good), 2), "ranks": len(good),
+                        "per_rank_encode_fps": [r.get("encode_fps") if r else None for r in uhd_ranks],
+                        "errors": {str(i): (r or {}).get("error", "no result") for i, r in enumerate(uhd_ranks) if not r or "error" in r} or None}
         if not args.no_cpu_baseline:
             t = 1
             out["cpu_baseline"] = cpu_baseline(frames[t], pad_frame(frames[t - 1], PAD), R)
+            # vs_baseline stays null: the reference publishes no figure for this metric. Ratios against the CPU figures measured
+            # beside it on this box (reported baselines, not targets):
+            cb = out["cpu_baseline"] or {}
+            ratios = {}
+            if cb.get("value"):
+                ratios["sad_candidates_vs_one_core"] = round(value / world / cb["value"], 1)
+            enc, ref = out.get("encode") or {}, cb.get("encoder") or {}
+            if enc.get("encode_fps") and ref.get("fps_without_start_and_read"):
+                ratios["encode_fps_1080p_vs_reference_one_thread"] = round(enc["encode_fps"] / ref["fps_without_start_and_read"], 2)
+            if enc.get("encode_fps") and ref.get("fps_row_threads_without_start_and_read"):
+                ratios["encode_fps_1080p_vs_reference_row_threads"] = round(enc["encode_fps"] / ref["fps_row_threads_without_start_and_read"], 2)
+            if ratios:
+                out["vs_cpu_baseline"] = ratios
         print(json.dumps(out), flush=True)
 
 

@@ -55,6 +55,9 @@ def test_two_ranks_share_this_gpu_over_gloo():
     assert d["n_gpus"] == 2 and d["config"]["gathered_records"] == 12 and len(d["config"]["rank_kernel_ms_avg"]) == 2
     assert all("shared" in x for x in d["config"]["rank_devices"])
     assert d["config"]["matching_cost_per_frame_mean"] > 0
+    # every rank took its own slice of the host's cores and sized its encoders' thread groups to it
+    assert d["config"]["cores_per_rank"] >= 1 and d["config"]["workers"] == max(1, d["config"]["cores_per_rank"] // 8)
+    assert d["config"]["consumed_by_encoder"] is False
 
 
 def test_two_ranks_over_rccl_on_two_gpus():

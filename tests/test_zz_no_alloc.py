@@ -12,6 +12,12 @@ from x265_amd import capi
 pytestmark = pytest.mark.gpu
 
 
+def free_device_bytes():
+    """free bytes of the current device as the HIP runtime of this process reports them (hipMemGetInfo)"""
+    import torch
+    return torch.cuda.mem_get_info()[0]
+
+
 def random_maps(w, h, intra, seed):
     rng = np.random.default_rng(seed)
     lg = np.zeros((h // 4, w // 4), np.uint8)
@@ -40,9 +46,17 @@ def both(L, w, h, intra, seed):
     want_v, want_h = np.full(n, 9, np.uint8), np.full(n, 9, np.uint8)
     capi.check(L.xmi_deblock_strengths(w, h, intra, O.p(lg), O.p(cbf), O.p(mv), O.p(want_v), O.p(want_h)))
     got_v, got_h = np.full(n, 7, np.uint8), np.full(n, 7, np.uint8)
+    free_before = free_device_bytes()
     capi.check(L.xmi_deblock_strengths_static(w, h, intra, O.p(lg), O.p(cbf), None if intra else O.p(mv), O.p(got_v), O.p(got_h)))
+    assert free_device_bytes() == free_before, "the call changed the amount of free device memory"
     np.testing.assert_array_equal(got_v, want_v)
     np.testing.assert_array_equal(got_h, want_h)
+    # and against the CPU checker's restatement of the reference's per-unit loops
+    orc = O.load()
+    orc_v, orc_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    orc.orc_deblock_strengths(w, h, intra, O.p(lg), O.p(cbf), O.p(mv), O.p(orc_v), O.p(orc_h))
+    np.testing.assert_array_equal(got_v, orc_v)
+    np.testing.assert_array_equal(got_h, orc_h)
     assert set(np.unique(got_v)) <= {0, 1, 2} and (got_v != 0).any()
     return got_v, got_h
 

@@ -66,13 +66,13 @@ def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, specula
             "p_picture_us_per_round_trip": per[-1]["us_per_round_trip"] if p_ms else None}
 
 
-def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0):
+def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0, seed0=7):
     """`segments` independent GOP segments (each its own encoder, I picture first) encoded at the same time on one GPU, one
     host thread per segment (the C call releases the interpreter lock): whole-job pictures per second over all pictures,
     and over the P pictures alone (after a barrier behind the I pictures)"""
     import threading
     from x265_amd.encoder import Encoder
-    clips = [clip(w, h, n, seed=7 + s) for s in range(segments)]
+    clips = [clip(w, h, n, seed=seed0 + s) for s in range(segments)]
     encs = [Encoder(w, h, qp, spin_us=spin_us, workers=workers) for _ in range(segments)]
     errs, marks = [], {}
     gate = threading.Barrier(segments + 1)

@@ -22,6 +22,7 @@
 #include <string>
 #include <thread>
 
+#include <sched.h>
 #include <ucontext.h>
 
 namespace xmi {
@@ -870,11 +871,17 @@ void Row::fiber_main(unsigned lo, unsigned hi)
     swapcontext(&r->fiber, r->home);      // for good
 }
 
-// cores this process may use: the hardware's, or the CPU time its control group grants if that is less
+// cores this process may use: the hardware's, the ones its affinity mask names (a rank of a multi-GPU job that was given a
+// slice of the host), or the CPU time its control group grants - whichever is least
 int host_cores()
 {
     int n = (int)std::thread::hardware_concurrency();
     if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int allowed = CPU_COUNT(&set);
+        if (allowed >= 1 && allowed < n) n = allowed;
+    }
     std::ifstream f("/sys/fs/cgroup/cpu.max");
     long long quota = 0, period = 0;
     std::string q;
