@@ -513,6 +513,46 @@ int xmi_dequant_batch_dev(int n, int count, const int16_t *d_level, const uint8_
 int xmi_idct_add_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_pred,
                            const uint8_t *d_flags, uint8_t *d_rec, void *stream);
 
+/* ---- "RdoQ": rate-distortion optimised quantisation --------------------------------------------------
+ * What the reference holds under this name is compiled out (#if RDOQ, src/RdoQ.cpp:32) and consists of the bit-cost table
+ * builders estimateBit / estCBFBit / estSignificantCoeffGroupMapBit / estSignificantMapBit / estSignificantCoefficientsBit
+ * (src/RdoQ.cpp:67-305) over estBitsSbacStruct (inc/RdoQ.h:38-49); the level decision (My_xRateDistOptQuant, inc/RdoQ.h:55)
+ * is declared and never defined. So there is NO reference behaviour to match: the bit-exact quantiser of the reference is
+ * xQuant (xmi_quant_*), and these entry points are an extension that changes the levels - validated against the CPU
+ * checker's statement of the same algorithm, never part of a parity claim.
+ *   xmi_rdoq_tables          estBitsSbacStruct for one block size and component, costs in 1/32768 bit.
+ *   xmi_rdoq_est_bits        the table builders: from context states in the reference's layout (inc/x265.h:286-311). Host.
+ *   xmi_rdoq_initial_contexts the states a slice starts from (xCabacInit, src/bitstream.cpp:588). Host.
+ *   xmi_rdoq_lambda_of       the weight of a bit for one QP and size from the Lagrange multiplier the reference's decision
+ *                            loops use (0.578 * 2^((QP-12)/3) in P slices, 0.57 * ... in I slices, src/encode.cpp:5348, 5406). Host.
+ *   xmi_rdoq_quant_batch_dev xmi_quant_batch_dev with the decision: per coefficient the rounded level, one less or zero
+ *                            (cost = squared error + weight * bits of the reference's residual syntax, src/encode.cpp:2385-2553),
+ *                            4x4 groups dropped when their flag alone is cheaper, the last position moved back over levels of
+ *                            magnitude one, the empty block. d_tables: one table set; d_lambda: 52 entries, by QP; scan_idx
+ *                            0 diagonal / 1 horizontal / 2 vertical; d_flags is accepted and not read.
+ *   xmi_tu_chain_rdoq_batch_dev  xSubDct -> decision -> xDeQuant -> xIDctAdd for packed TUs (xmi_tu_chain_batch_dev with the
+ *                            decision in the quantiser's place); d_work: count * n * n int16 of scratch the caller owns. */
+typedef struct xmi_rdoq_tables {
+    int32_t sig_cg[2][2];            /* significantCoeffGroupBits[ctx][bin] */
+    int32_t sig[27][2];              /* significantBits[getSigCtxInc][bin] */
+    int32_t last_x[12], last_y[12];  /* lastXBits / lastYBits by group index */
+    int32_t one[16][2];              /* greaterOneBits[4 * context set + c1][bin] */
+    int32_t abs[4][2];               /* levelAbsBits[context set][bin] */
+    int32_t cbf[2];                  /* blockCbpBits of the component's first context */
+} xmi_rdoq_tables;
+typedef struct xmi_rdoq_lambda {
+    uint32_t mantissa;               /* rate cost = (mantissa * bits) >> shift, in squared sixteenths of a level */
+    int32_t shift;
+} xmi_rdoq_lambda;
+int xmi_rdoq_est_bits(const uint8_t *ctx, int log2_size, int is_luma, xmi_rdoq_tables *out);
+int xmi_rdoq_initial_contexts(int slice_type, int qp, uint8_t ctx[256]);
+int xmi_rdoq_lambda_of(double lambda, int qp, int log2_size, xmi_rdoq_lambda *out);
+int xmi_rdoq_quant_batch_dev(int n, int count, const int16_t *d_coef, const uint8_t *d_qp, const uint8_t *d_flags, const xmi_rdoq_tables *d_tables,
+                             const xmi_rdoq_lambda *d_lambda, int scan_idx, int is_luma, int16_t *d_level, uint32_t *d_sum, void *stream);
+int xmi_tu_chain_rdoq_batch_dev(int n, int count, const uint8_t *d_pix, const uint8_t *d_pred, const uint8_t *d_qp, const uint8_t *d_flags,
+                                const xmi_rdoq_tables *d_tables, const xmi_rdoq_lambda *d_lambda, int scan_idx, int is_luma, int16_t *d_work,
+                                int16_t *d_level, uint8_t *d_rec, uint32_t *d_sum, void *stream);
+
 /* ---- per-call drop-ins (HOST pointers, strided, synchronous) ---------------------------------
  * Same argument meaning as the reference primitives; each call stages its operands to the GPU,
  * runs the batch kernel with count = 1 and copies the result back. Correct and slow: they exist so

@@ -220,6 +220,23 @@ typedef struct {
 void orc_sao_apply_plane(const uint8_t *src, int src_stride, uint8_t *dst, int dst_stride, int width, int height, int ctu_size,
                          const orc_sao_ctu_param *params);
 
+/* A9 "RdoQ": rate-distortion optimised quantisation (x265_rdoq.c). PARITY UNPINNED BY CONSTRUCTION: the reference holds
+ * only bit-cost table builders (src/RdoQ.cpp:67-305, inc/RdoQ.h:38-49) and no level decision. orc_rdoq_est_bits restates
+ * those builders; orc_rdoq_quant is this build's own decision priced with their tables (see the file header). */
+typedef struct orc_rdoq_tables {
+    int32_t sig_cg[2][2];     /* significantCoeffGroupBits */
+    int32_t sig[27][2];       /* significantBits, indexed by getSigCtxInc */
+    int32_t last_x[12], last_y[12]; /* lastXBits / lastYBits by group index */
+    int32_t one[16][2];       /* greaterOneBits, 4 * context set + c1 */
+    int32_t abs[4][2];        /* levelAbsBits by context set */
+    int32_t cbf[2];           /* blockCbpBits of the component's first context */
+} orc_rdoq_tables;
+void orc_rdoq_est_bits(const uint8_t *ctx, int log2_size, int is_luma, orc_rdoq_tables *t);
+void orc_rdoq_lambda(double lambda, unsigned qp, int log2_size, uint32_t *mant, int32_t *shift);
+/* coef -> level (both with `stride`), returns sum |level|; scan_idx 0 diagonal, 1 horizontal, 2 vertical */
+uint32_t orc_rdoq_quant(int16_t *level, const int16_t *coef, int stride, int n, unsigned qp, int is_luma, int scan_idx,
+                        const orc_rdoq_tables *t, uint32_t lam_m, int32_t lam_s);
+
 #ifdef __cplusplus
 }
 #endif

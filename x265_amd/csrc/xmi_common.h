@@ -21,6 +21,8 @@ hipStream_t as_stream(void *s);
 int sad_surface_prepare_device();
 // per-device set-up of deblock.hip (address of its statically allocated staging array on `device`, which is current)
 int deblock_prepare_device(int device);
+// per-device set-up of rdoq.hip (coefficient scan tables in device memory)
+int rdoq_prepare_device();
 
 // scratch device buffer owned by the library, grown on demand (used by the host-pointer entry points)
 void *scratch(int slot, size_t bytes);

@@ -45,6 +45,8 @@ static int init_locked(int device)
     if (rc != XMI_OK) return rc;
     rc = deblock_prepare_device(device);
     if (rc != XMI_OK) return rc;
+    rc = rdoq_prepare_device();
+    if (rc != XMI_OK) return rc;
     g_device = device;
     return XMI_OK;
 }
