@@ -471,6 +471,11 @@ void xmi_encoder_destroy(xmi_encoder *e);
 int xmi_encoder_configure(xmi_encoder *e, int lanes, int spin_us);
 int xmi_encoder_speculate(xmi_encoder *e, int level);      /* xmi_analysis_speculate for the encoder's analysis loop */
 int xmi_encoder_workers(xmi_encoder *e, int workers);      /* xmi_analysis_workers for the encoder's analysis loop */
+/* Extension without a counterpart in the reference (its RdoQ.cpp is compiled out): from the next picture on, the transform units
+ * of P pictures (luma and chroma) take their levels from the decision of xmi_rdoq_quant_batch_dev instead of xQuant - tables
+ * from the contexts the slice starts with, the decision loop's own Lagrange multiplier, diagonal scan. The stream stays a valid
+ * stream whose picture hash matches the encoder's reconstruction, and is no longer the reference's. Off by default. */
+int xmi_encoder_rdoq(xmi_encoder *e, int on);
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
                            size_t capacity);
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);

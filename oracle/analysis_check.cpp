@@ -2,6 +2,7 @@
 // the same source libx265_amd.so is built from) bound to a CPU evaluator made of the oracle's primitives, so that the
 // decision logic can be held against traces of the reference's encoder without a GPU (tests/test_analysis_cpu.py). Built
 // into oracle/libx265_analysis_check.so by `make -C oracle analysis_check`. Nothing in the product links or loads this.
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -29,9 +30,34 @@ public:
     std::vector<int16_t> lane_words[8];
 
     int w = 0, h = 0;
+    // the level decision of x265_rdoq.c in the transform chains of P pictures, as xmi_encoder_rdoq switches it on in the library
+    bool rdoq = false, rdoq_active = false;
+    orc_rdoq_tables rdoq_tables[4][2];
+    uint32_t rdoq_m[4][2];
+    int32_t rdoq_s[4][2];
 
-    int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int) override
+    uint8_t coder_ctx[256];
+    bool have_coder_ctx = false;
+    void coder_contexts(const uint8_t *ctx) override
     {
+        have_coder_ctx = ctx != nullptr;
+        if (ctx) std::memcpy(coder_ctx, ctx, 256);
+    }
+
+    int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int qp) override
+    {
+        rdoq_active = rdoq && ref[0];
+        if (rdoq_active) {
+            uint8_t ctx[256];
+            if (have_coder_ctx) std::memcpy(ctx, coder_ctx, 256);
+            else xmi::analysis::init_contexts(1, qp, ctx);
+            const double lambda = 0.578 * std::pow(2.0, (qp - 12) / 3.0);
+            for (int lg = 2; lg <= 5; lg++)
+                for (int comp = 0; comp < 2; comp++) {
+                    orc_rdoq_est_bits(ctx, lg, comp == 0, &rdoq_tables[lg - 2][comp]);
+                    orc_rdoq_lambda(lambda, (unsigned)(comp ? xmi::analysis::chroma_qp(qp) : qp), lg, &rdoq_m[lg - 2][comp], &rdoq_s[lg - 2][comp]);
+                }
+        }
         const int pc = pad / 2;
         p.w = w, p.h = h;
         p.src_y = src[0], p.src_u = src[1], p.src_v = src[2];
@@ -255,8 +281,26 @@ private:
         }
     }
 
+    // xSubDctQuantRec of one inter unit (rows `stride` apart, reconstruction rows 80 apart): the reference's quantiser, or the
+    // level decision in its place
+    uint32_t unit_chain(const uint8_t *pix, const uint8_t *pred, uint8_t *rec, int16_t *lev, int n, int stride, int qp) const
+    {
+        if (!rdoq_active) return orc_tu_chain(pix, pred, rec, lev, n, stride, 80, (unsigned)qp, ORC_MODE_INVALID, ORC_SLICE_P);
+        const int lg = n == 4 ? 2 : n == 8 ? 3 : n == 16 ? 4 : 5, comp = stride == 64 ? 0 : 1;
+        int16_t work[32 * 64];
+        orc_sub_dct(work, pix, stride, pred, stride, n, ORC_MODE_INVALID);
+        const uint32_t sum = orc_rdoq_quant(lev, work, stride, n, (unsigned)qp, comp == 0, 0, &rdoq_tables[lg - 2][comp], rdoq_m[lg - 2][comp], rdoq_s[lg - 2][comp]);
+        if (sum) {
+            orc_dequant(work, lev, stride, (unsigned)qp, n, n);
+            orc_idct_add(rec, 80, work, stride, pred, n, ORC_MODE_INVALID);
+        } else {
+            for (int r = 0; r < n; r++) std::memcpy(rec + r * 80, pred + r * stride, (size_t)n);
+        }
+        return sum;
+    }
+
     // transform chain(s) of a size x size block held with 64-sample rows; results packed with `size`-sample rows
-    static uint32_t chains(const uint8_t *pix, const uint8_t *pred, int size, int qp, uint32_t sum[4], uint8_t *rec_out, int16_t *lev_out, int stride)
+    uint32_t chains(const uint8_t *pix, const uint8_t *pred, int size, int qp, uint32_t sum[4], uint8_t *rec_out, int16_t *lev_out, int stride) const
     {
         uint8_t rec[64 * 80];
         int16_t lev[64 * 64];
@@ -268,10 +312,10 @@ private:
             for (int j = 0; j < 2; j++)
                 for (int i = 0; i < 2; i++) {
                     const int o = j * hsz * stride + i * hsz, orec = j * hsz * 80 + i * hsz;
-                    sum[j * 2 + i] = orc_tu_chain(pix + o, pred + o, rec + orec, lev + o, hsz, stride, 80, (unsigned)qp, ORC_MODE_INVALID, ORC_SLICE_P);
+                    sum[j * 2 + i] = unit_chain(pix + o, pred + o, rec + orec, lev + o, hsz, stride, qp);
                 }
         } else {
-            sum[0] = orc_tu_chain(pix, pred, rec, lev, size, stride, 80, (unsigned)qp, ORC_MODE_INVALID, ORC_SLICE_P);
+            sum[0] = unit_chain(pix, pred, rec, lev, size, stride, qp);
         }
         for (int r = 0; r < size; r++) {
             std::memcpy(rec_out + r * size, rec + r * 80, (size_t)size);
@@ -486,6 +530,11 @@ int orc_encoder_configure(void *h, int lanes, int spin_us)
 {
     static_cast<EncHandle *>(h)->enc.analyser().lanes = lanes;
     static_cast<EncHandle *>(h)->enc.analyser().spin_us = spin_us;
+    return 0;
+}
+int orc_encoder_rdoq(void *h, int on)
+{
+    static_cast<EncHandle *>(h)->ev.rdoq = on != 0;
     return 0;
 }
 int orc_encoder_speculate(void *h, int level)

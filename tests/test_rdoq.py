@@ -262,3 +262,75 @@ def test_errors():
     assert L.xmi_rdoq_quant_batch_dev(8, 1, 8, 8, None, 8, 8, 3, 1, 8, 8, None) == -1
     assert L.xmi_rdoq_quant_batch_dev(8, 0, 8, 8, None, 8, 8, 0, 1, 8, 8, None) == 0      # an empty batch
     assert L.xmi_rdoq_est_bits(None, 3, 1, None) == -1
+
+
+# ------------------------------------------------------------------------------------------------- in the encoder
+def harness_stream(w, h, frames, qp, rdoq):
+    """the product's host code on the CPU checker's primitives (oracle/libx265_analysis_check.so), level decision on or off"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from gen_yuv import frame
+    from x265_amd.encoder import align_frame
+    lib = C.CDLL(os.path.join(root, "oracle", "libx265_analysis_check.so"))
+    lib.orc_encoder_create.restype = C.c_void_p
+    lib.orc_encoder_create.argtypes = [C.c_int] * 4
+    lib.orc_encoder_destroy.argtypes = [C.c_void_p]
+    lib.orc_encoder_rdoq.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_encoder_encode.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_size_t]
+    W, H = (w + 63) // 64 * 64, (h + 63) // 64 * 64
+    enc = lib.orc_encoder_create(W, H, qp, 0)
+    assert lib.orc_encoder_rdoq(enc, int(rdoq)) == 0
+    rng = np.random.default_rng(1234)
+    out = np.zeros(W * H * 3 + 4096, np.uint8)
+    aus = []
+    for t in range(frames):
+        y, u, v = align_frame(*frame(w, h, t, rng), W, H)
+        n = lib.orc_encoder_encode(enc, y.ctypes.data, u.ctypes.data, v.ctypes.data, 2 if t == 0 else 1, out.ctypes.data, out.size)
+        assert n > 0, n
+        aus.append(bytes(out[:n]))
+    lib.orc_encoder_destroy(enc)
+    return aus
+
+
+def test_encoder_with_the_decision_on_the_cpu_harness():
+    """The P pictures change (the decision weighs squared error against bits at the decision loop's own Lagrange multiplier, where
+    the reference's quantiser rounds with a fixed dead zone: on this noisy clip it spends fewer bits at QP 37 and more at QP 22),
+    the I picture is untouched, and the stream stays what the plain encoder writes when the switch is off"""
+    plain, rd = harness_stream(416, 240, 4, 37, False), harness_stream(416, 240, 4, 37, True)
+    assert plain[0] == rd[0]
+    assert all(a != b for a, b in zip(plain[1:], rd[1:]))
+    assert sum(map(len, rd[1:])) < sum(map(len, plain[1:]))
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_md5.json")))["416x240_f8_q27"]
+    assert hashlib.md5(b"".join(harness_stream(416, 240, 8, 27, False))).hexdigest() == gold["md5"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,frames,qp", [(416, 240, 4, 27), (416, 240, 3, 22), (1920, 1080, 3, 32)])
+def test_library_encoder_with_the_decision_equals_the_cpu_harness(w, h, frames, qp):
+    """xmi_encoder_rdoq: the library's stream is the one its host code writes on the CPU checker's primitives with the checker's
+    statement of the decision, access unit by access unit; the picture hash in every access unit is the hash of the
+    reconstruction the encoder holds (a decoder of the stream would have to arrive at the same picture)."""
+    import hashlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_yuv import frame
+    from x265_amd.encoder import Encoder
+    want = harness_stream(w, h, frames, qp, True)
+    rng = np.random.default_rng(1234)
+    enc = Encoder(w, h, qp, rdoq=True)
+    try:
+        for t in range(frames):
+            au = enc.encode(*frame(w, h, t, rng), t == 0)
+            assert len(au) == len(want[t]) and au == want[t], f"picture {t}"
+            rec = enc.reconstruction()
+            k = au.rfind(b"\x00\x00\x01\x50\x01\x84\x31\x00")
+            payload = au[k + 8:].replace(b"\x00\x00\x03", b"\x00\x00")
+            assert payload[:48] == b"".join(hashlib.md5(p.tobytes()).digest() for p in rec)
+    finally:
+        enc.close()

@@ -19,7 +19,9 @@
 #include <atomic>
 #include <thread>
 #include <chrono>
+#include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -28,6 +30,7 @@
 #include "intra_device.h"
 #include "me_search_device.h"
 #include "tu_valu_device.h"
+#include "rdoq_device.h"
 
 using namespace xmi::analysis;
 
@@ -76,6 +79,7 @@ struct RoundParams {
     const uint8_t *ref_c[2];      // sample (0,0) of the padded chroma reference planes
     int width, stride, rows, stride_c;
     int qp, qpc;
+    const RdoqSet *rdoq;          // tables of the level decision that takes the quantiser's place, or null (the reference's quantiser)
     uint8_t *out;                 // result area
     unsigned *counter;            // workgroups finished since the handle was made (device memory)
     unsigned target;              // value of the counter when this round is complete
@@ -127,7 +131,8 @@ __constant__ int8_t k_dst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 8
 // most units of a P picture quantise to nothing (the result area is host memory: every store crosses the bus).
 template <int N, bool INTRA = false, bool DST = false, bool LAZY = false>
 __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, const uint8_t *pred, int pred_stride, int qp, int16_t *level,
-                           uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd, uint8_t *rec_copy = nullptr, int copy_stride = 0)
+                           uint8_t *rec, uint8_t *pred_out, int out_stride, uint32_t &sum, uint32_t &ssd, uint8_t *rec_copy = nullptr, int copy_stride = 0,
+                           const RdoqSet *rq = nullptr, int comp = 0)
 {
     constexpr int LD = Cfg<N>::LD, LG = Cfg<N>::LOG2, TPT = Cfg<N>::TPT;
     const int tid = threadIdx.x;
@@ -165,13 +170,73 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
     uint32_t local = 0;
     uint2 held = make_uint2(0u, 0u);      // (a unit has at most 1024 samples: one step per thread)
     static_assert(N <= 32, "one quantiser step per thread");
+    // The level decision in the quantiser's place (rq != null; rdoq_device.h): rounded levels in scan order by all threads, the
+    // decision on one of them, then the loop below takes its magnitudes from the decided levels. Scratch is what the chain
+    // does not need at this point: the search window (costs, levels, tables), the forward matrix (the scan) and L.b (groups).
+    int best_last = -1;
+    const int16_t *r_lvl = reinterpret_cast<const int16_t *>(L.win + 4096);
+    if (rq) {
+        constexpr int SETS = (N / 4) * (N / 4);
+        uint32_t *pos_b = reinterpret_cast<uint32_t *>(L.win);
+        int16_t *lvl = reinterpret_cast<int16_t *>(L.win + 4096);
+        xmi_rdoq_tables *tab = reinterpret_cast<xmi_rdoq_tables *>(L.win + 4096 + 2048);
+        static_assert(4096 + 2048 + sizeof(xmi_rdoq_tables) <= sizeof L.win, "decision scratch fits the search window");
+        uint16_t *scan = reinterpret_cast<uint16_t *>(M);
+        unsigned char *gb = reinterpret_cast<unsigned char *>(L.b);
+        long long *cg_d = reinterpret_cast<long long *>(gb);
+        int *cg_b = reinterpret_cast<int *>(gb + 512);
+        uint8_t *cg_flag = gb + 768, *scan_cg = gb + 832;
+        unsigned long long *s_d = reinterpret_cast<unsigned long long *>(gb + 896);      // [0] nothing coded, [1] behind the last rounded level
+        int *s_int = reinterpret_cast<int *>(gb + 912);                                  // [0] last rounded level, [1] the decision
+        const int eshift = qbits - 4;
+        for (int i2 = tid; i2 < (int)(sizeof(xmi_rdoq_tables) / 4); i2 += 256) reinterpret_cast<int *>(tab)[i2] = reinterpret_cast<const int *>(&rq->tables[LG - 2][comp])[i2];
+        for (int i2 = tid; i2 < SETS; i2 += 256) cg_flag[i2] = 0, scan_cg[i2] = g_rdoq_scan_cg[0][LG - 2][i2];
+        if (tid == 0) s_d[0] = s_d[1] = 0, s_int[0] = -1, s_int[1] = -1;
+        __syncthreads();
+        int top_l = -1;
+        for (int i2 = tid; i2 < N * N; i2 += 256) {
+            const int pos = g_rdoq_scan[0][LG - 2][i2];
+            scan[i2] = (uint16_t)pos;
+            const uint32_t v = (uint32_t)(abs((int)L.a[(pos >> LG) * LD + (pos & (N - 1))]) * q);
+            uint32_t mx = (uint32_t)(((unsigned long long)v + (1u << (qbits - 1))) >> qbits);
+            if (mx > 32767u) mx = 32767u;
+            lvl[i2] = (int16_t)mx;
+            if (mx) top_l = i2;
+        }
+        atomicMax(&s_int[0], top_l);
+        __syncthreads();
+        const int top = s_int[0];
+        if (top >= 0) {
+            unsigned long long all0 = 0, beyond = 0;
+            for (int i2 = tid; i2 < N * N; i2 += 256) {
+                const int pos = scan[i2];
+                const long long e = (long long)(uint32_t)(abs((int)L.a[(pos >> LG) * LD + (pos & (N - 1))]) * q) >> eshift;
+                all0 += (unsigned long long)(e * e);
+                if (i2 > top) beyond += (unsigned long long)(e * e);
+            }
+            atomicAdd(&s_d[0], all0);
+            atomicAdd(&s_d[1], beyond);
+            __syncthreads();
+            if (tid == 0)
+                s_int[1] = rdoq_decide<N>([&](int i2) { const int pos = scan[i2]; return (uint32_t)(abs((int)L.a[(pos >> LG) * LD + (pos & (N - 1))]) * q); }, scan, scan_cg,
+                                          lvl, pos_b, cg_d, cg_b, cg_flag, *tab, top, (long long)s_d[0], (long long)s_d[1], qbits,
+                                          rq->lambda[LG - 2][comp].mantissa, rq->lambda[LG - 2][comp].shift, 0, comp == 0);
+            __syncthreads();
+            best_last = s_int[1];
+        }
+        __syncthreads();      // the group arrays in L.b are done with: the loop below fills it
+    }
     for (int e = tid * 4; e < N * N; e += 1024) {
         const int k = e / N, i = e % N;
         int lv[4];
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int c = L.a[k * LD + i + t];
-            const int mag = (abs(c) * q + qrnd) >> qbits;
+            int mag = (abs(c) * q + qrnd) >> qbits;
+            if (rq) {
+                const int at = g_rdoq_inv[0][LG - 2][k * N + i + t];
+                mag = at <= best_last ? r_lvl[at] : 0;
+            }
             local += (uint32_t)mag;
             lv[t] = clip16(c < 0 ? -mag : mag);
             L.b[(i + t) * LD + k] = (int16_t)clip16((lv[t] * dscale + (1 << (dshift - 1))) >> dshift);
@@ -348,7 +413,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
     const size_t o = (size_t)uy * N + ux;
     uint32_t sum, ssd;
     chain_unit<UN, false, false, true>(L, src + (size_t)uy * p.width + ux, p.width, pr + (size_t)uy * p.stride + ux, p.stride, p.qp, level + o, rec + o,
-                   pred_out ? pred_out + o : nullptr, N, sum, ssd);
+                   pred_out ? pred_out + o : nullptr, N, sum, ssd, nullptr, 0, p.rdoq, 0);
     if (tid == 0) {
         (path ? head->sum_me : head->sum_merge)[u] = sum;
         (path ? head->ssd_me : head->ssd_merge)[u] = ssd;
@@ -413,7 +478,7 @@ __device__ void chroma_job(const RoundParams &p, RoundLds &L, const ChromaJob &j
     }
     uint32_t sum, ssd;
     chain_unit<N, false, false, true>(L, p.src[1 + j.plane] + (size_t)j.y * (p.width / 2) + j.x, p.width / 2, pred_lds, N, p.qpc,
-                  reinterpret_cast<int16_t *>(p.out + j.out_level), rec, nullptr, j.rec_stride, sum, ssd);
+                  reinterpret_cast<int16_t *>(p.out + j.out_level), rec, nullptr, j.rec_stride, sum, ssd, nullptr, 0, p.rdoq, 1);
     if (tid == 0) *reinterpret_cast<uint32_t *>(p.out + j.out_sum) = sum;
 }
 
@@ -1095,6 +1160,8 @@ public:
     size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, off_done = 0, intra_scratch = 0;
     hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
+    bool rdoq = false, rdoq_active = false;      // the level decision (rdoq.hip) in the P pictures' transform chains: asked for / in force for the bound picture
+    RdoqSet h_rdoq, *d_rdoq = nullptr;
     // P rounds: hand the answers out when the merge paths of the asking CUs and the chroma jobs are through (rows then poll
     // for the rest when they get to it) - for the polling configurations, where latency counts; with sleeping waiters (many
     // encoders on one GPU, the host cores are what is short) the coordinator waits for the whole round
@@ -1117,6 +1184,7 @@ public:
             d_src[i] = d_ref[i] = nullptr;
         }
         if (d_planes) (void)hipFree(d_planes), d_planes = nullptr;
+        if (d_rdoq) (void)hipFree(d_rdoq), d_rdoq = nullptr;
         for (int i = 0; i < 3; i++) {
             if (d_rec[i]) (void)hipFree(d_rec[i]);
             if (d_sao[i]) (void)hipFree(d_sao[i]);
@@ -1161,6 +1229,17 @@ public:
         XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_planes), 16 * plane));
         XMI_HIP(hipStreamCreate(&st));
         XMI_HIP(hipMemsetAsync(d_planes, 0, 16 * plane, st));
+        XMI_HIP(hipMalloc(reinterpret_cast<void **>(&d_rdoq), sizeof(RdoqSet)));
+        {      // the scan tables of the level decision, once per process (one device per process)
+            static std::mutex mu;
+            static bool uploaded = false;
+            std::lock_guard<std::mutex> lk(mu);
+            if (!uploaded) {
+                const int rc = rdoq_upload_scans();
+                if (rc != XMI_OK) return rc;
+                uploaded = true;
+            }
+        }
         XMI_HIP(hipStreamSynchronize(st));
         return set_lanes(nlanes);
     }
@@ -1308,8 +1387,33 @@ public:
             if (rc != XMI_OK) return rc;
         }
         cur_qp = qp, cur_qpc = qpc;
+        rdoq_active = false;
+        if (rdoq && ref[0]) {      // the level decision serves the transform units of P pictures
+            // tables from the states the coder ended the previous picture with (the contexts the slice starts with when there is
+            // none), the Lagrange multiplier of the decision loop (src/encode.cpp:5406)
+            uint8_t ctx[256];
+            if (have_coder_ctx) std::memcpy(ctx, coder_ctx, 256);
+            else xmi::analysis::init_contexts(1, qp, ctx);
+            const double lambda = 0.578 * std::pow(2.0, (qp - 12) / 3.0);
+            for (int lg = 2; lg <= 5; lg++)
+                for (int comp = 0; comp < 2; comp++) {
+                    int rc = xmi_rdoq_est_bits(ctx, lg, comp == 0, &h_rdoq.tables[lg - 2][comp]);
+                    if (rc == XMI_OK) rc = xmi_rdoq_lambda_of(lambda, comp ? qpc : qp, lg, &h_rdoq.lambda[lg - 2][comp]);
+                    if (rc != XMI_OK) return rc;
+                }
+            XMI_HIP(hipMemcpyAsync(d_rdoq, &h_rdoq, sizeof h_rdoq, hipMemcpyHostToDevice, st));
+            rdoq_active = true;
+        }
         XMI_HIP(hipStreamSynchronize(st));
         return XMI_OK;
+    }
+
+    uint8_t coder_ctx[256];
+    bool have_coder_ctx = false;
+    void coder_contexts(const uint8_t *ctx) override
+    {
+        have_coder_ctx = ctx != nullptr;
+        if (ctx) std::memcpy(coder_ctx, ctx, 256);
     }
 
     int bind_pictures(const uint8_t *const src[3], const uint8_t *const ref[3], int pad, int qp) override
@@ -1697,6 +1801,7 @@ private:
         p.ref_c[0] = d_ref[1] + (size_t)kPadC * stride_c + kPadC, p.ref_c[1] = d_ref[2] + (size_t)kPadC * stride_c + kPadC;
         p.width = w, p.stride = stride, p.rows = rows, p.stride_c = stride_c;
         p.qp = cur_qp, p.qpc = cur_qpc;
+        p.rdoq = rdoq_active ? d_rdoq : nullptr;
         p.out = R.g_out;
         const unsigned ngroups = (unsigned)(nluma + nc);
         R.issued += ngroups;
@@ -1943,6 +2048,13 @@ int xmi_encoder_workers(xmi_encoder *e, int workers)
     XMI_ARG(e, "xmi_encoder_workers: null handle");
     XMI_ARG(workers >= 0 && workers <= 1024, "xmi_encoder_workers: %d threads", workers);
     e->enc.analyser().workers = workers;
+    return XMI_OK;
+}
+
+int xmi_encoder_rdoq(xmi_encoder *e, int on)
+{
+    XMI_ARG(e, "xmi_encoder_rdoq: null handle");
+    e->ev.rdoq = on != 0;
     return XMI_OK;
 }
 

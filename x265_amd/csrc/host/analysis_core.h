@@ -159,6 +159,10 @@ public:
         (void)src, (void)ref, (void)pad, (void)qp;
         return -1;
     }
+    // Context states the entropy coder ended the previous picture with (256 bytes), handed over before bind_pictures(): what an
+    // evaluator that prices levels (the level decision that may take the quantiser's place) builds its bit-cost tables from.
+    // Null before the first picture.
+    virtual void coder_contexts(const uint8_t *ctx) { (void)ctx; }
     // the requests of an I picture; same calling rules as evaluate()
     virtual int evaluate_intra(int lane, const IntraBatch &batch)
     {

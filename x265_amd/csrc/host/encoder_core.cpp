@@ -538,6 +538,7 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     const auto t0 = clock::now();
     const uint8_t *srcp[3] = { src_y, src_u, src_v }, *refp[3] = { nullptr, nullptr, nullptr };
     if (!intra) refp[0] = ref_[0].data(), refp[1] = ref_[1].data(), refp[2] = ref_[2].data();
+    ev.coder_contexts(have_ctx_ ? last_ctx_ : nullptr);
     int rc = ev.bind_pictures(srcp, refp, kPad, qp_);
     if (rc) return rc < 0 ? rc : -rc;
     rc = intra ? an_.i_picture(qp_, strong_, ev, res_) : an_.p_picture(qp_, ev, res_);
@@ -646,6 +647,8 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
             if (x == 1 && y != rows_ - 1) std::memcpy(saved, cabac.ctx, 256);
         }
     const int n_entry = rows_ - 1;
+    std::memcpy(last_ctx_, cabac.ctx, 256);
+    have_ctx_ = true;
     cabac.flush();
     sb.trailing_bits();
     bytes0[n_entry + 1] = sb.flush();

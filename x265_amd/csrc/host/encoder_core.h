@@ -77,6 +77,8 @@ private:
     std::vector<uint8_t> rec_[3];            // reconstruction of the current picture, packed
     std::vector<uint8_t> ref_[3];            // padded previous reconstruction (PAD_YSIZE 80 / PAD_CSIZE 40)
     bool have_ref_ = false;
+    bool have_ctx_ = false;
+    uint8_t last_ctx_[256] = {};             // the coder's context states at the end of the last picture written
     int poc_ = -1;
     std::vector<syntax::SaoUnit> sao_[3];
     bool sao_on_[2] = { true, true };
