@@ -18,9 +18,9 @@ if [ -d $S ]; then
   grep '^{' $S/bench_kernels.jsonl > $dst/secondary_kernels.jsonl
   cp $S/pmc_summary.txt $dst/secondary_pmc_summary.txt
 fi
-python3 - "$P" <<'PY'
+python3 - "$P" "$dst" <<'PY'
 import json, re, sys
-p = sys.argv[1]
+p, dst = sys.argv[1], sys.argv[2]
 def mean(path, name):
     txt = open(path).read()
     m = re.search(r"sad_surface_kernel<64[^>]*>\s*\n\s*" + name + r"\s+mean\s+([0-9.]+)", txt)
@@ -28,7 +28,9 @@ def mean(path, name):
 w, f = mean(p + "/pmc_write.txt", "WRITE_SIZE"), mean(p + "/pmc_fetch.txt", "FETCH_SIZE")
 path = "x265_amd/measured_traffic.json"
 d = json.load(open(path))
-d["1920x1088_R64"].update(write_size_kb=w, fetch_size_kb=f, bytes_per_launch=int(round((w + 2 * f) * 1024)))
+src = d["1920x1088_R64"].get("source", "")
+src = re.sub(r"^profiles/\w+/", dst.rstrip("/") + "/", src)
+d["1920x1088_R64"].update(write_size_kb=w, fetch_size_kb=f, bytes_per_launch=int(round((w + 2 * f) * 1024)), source=src)
 json.dump(d, open(path, "w"), indent=1)
 print("traffic per launch:", d["1920x1088_R64"]["bytes_per_launch"])
 PY

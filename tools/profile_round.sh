@@ -8,7 +8,7 @@ repo=$PWD
 out=$repo/gpurun_out/profile_$tag
 mkdir -p $out
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $repo/bench.py --no-cpu-baseline --no-segments > $out/bench_stats_run.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python3 $repo/bench.py --no-cpu-baseline > $out/bench_stats_run.log 2>&1 || exit 1
 cp $out/stats/bench_kernel_stats.csv $out/kernel_stats.csv
 pass() { # name counters...
   n=$1; shift
