@@ -249,6 +249,7 @@ def encode_rate(L, qp=32, segments=True, workers=SEGMENT_WORKERS):
     try:
         import bench_encoder
         out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
+        out["two_step"] = bench_encoder.run_two_step(1920, 1080, ENCODE_FRAMES, qp)
         if segments:
             out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=workers)
             # the 3840x2160 configuration (coded 3840x2176), a short clip: to be read beside cpu_baseline.encoder_2160p

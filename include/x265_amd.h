@@ -461,6 +461,14 @@ int xmi_analysis_p_picture(xmi_analysis *a, const uint8_t *src_y, const uint8_t 
  *                        at 16 384 CABAC commands per CTU, inc/x265.h:416, long before that.) After a failed call the handle
  *                        holds no reference picture: the next picture must be an I picture, and since the statistics
  *                        carried from picture to picture may have advanced, streams no longer equal the reference's.
+ * xmi_encoder_submit / xmi_encoder_collect: xmi_encoder_encode in two steps, for callers that can take the access unit of
+ *                        picture n after handing in picture n + 1 (no counterpart in the reference, whose xIEncFrame returns the
+ *                        picture's bytes). submit does everything up to the slice data and the reference picture of the next
+ *                        call, and leaves the picture hash - MD5 over the final reconstruction, a serial pass of 2.6 ms for a
+ *                        1920x1088 luma plane - to two threads of its own; collect waits for them, appends the hash unit and
+ *                        returns the oldest waiting access unit (same bytes as xmi_encoder_encode's). Two pictures may wait
+ *                        at most; a third submit, an xmi_encoder_encode while one waits, and a collect without one fail with
+ *                        XMI_ERR_ARG; a collect whose buffer is too small fails and the picture keeps waiting.
  * xmi_encoder_reconstruction: the last picture's reconstruction after the in-loop filters, packed planes.
  * xmi_encoder_timing   : of the last picture, out = { ns analysis, ns deblocking + SAO statistics, ns SAO decision + offsets, ns
  *                        writing, GPU round trips, CU / PU requests, and of the round trips: ns writing job tables, ns in the
@@ -478,6 +486,8 @@ int xmi_encoder_workers(xmi_encoder *e, int workers);      /* xmi_analysis_worke
 int xmi_encoder_rdoq(xmi_encoder *e, int on);
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out,
                            size_t capacity);
+int xmi_encoder_submit(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type);
+int64_t xmi_encoder_collect(xmi_encoder *e, uint8_t *out, size_t capacity);
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v);
 int xmi_encoder_timing(xmi_encoder *e, uint64_t out[10]);
 

@@ -549,6 +549,13 @@ int orc_encoder_encode(void *hv, const uint8_t *y, const uint8_t *u, const uint8
     EncHandle &H = *static_cast<EncHandle *>(hv);
     return H.enc.encode(y, u, v, slice_type, H.ev, H.ops, out, cap);
 }
+// the same in two steps (Encoder::submit / collect)
+int orc_encoder_submit(void *hv, const uint8_t *y, const uint8_t *u, const uint8_t *v, int slice_type)
+{
+    EncHandle &H = *static_cast<EncHandle *>(hv);
+    return H.enc.submit(y, u, v, slice_type, H.ev, H.ops);
+}
+int orc_encoder_collect(void *hv, uint8_t *out, size_t cap) { return static_cast<EncHandle *>(hv)->enc.collect(out, cap); }
 // the last picture's decisions: arrays as orc_analysis_p_picture hands them out, plus the mode map and the rate counters
 void orc_encoder_analysis(void *hv, uint16_t *info0, uint8_t *info1, uint8_t *mode, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint8_t *rec_y,
                           uint8_t *rec_u, uint8_t *rec_v, uint8_t *ctx_out, uint64_t *frac)

@@ -174,6 +174,35 @@ def test_early_answers_at_1080p_write_the_recorded_stream():
         assert len(stream) == GOLD[key]["bytes"] and hashlib.md5(stream).hexdigest() == GOLD[key]["md5"], (lanes, spin)
 
 
+def test_two_step_encode_writes_the_recorded_stream():
+    """xmi_encoder_submit / xmi_encoder_collect with one picture in flight (the hash of picture t beside the analysis of
+    t + 1): the recorded 64-picture 1920x1080 stream and a 416x240 one; the limits of the queue are errors."""
+    from x265_amd.capi import XmiError
+    from x265_amd.encoder import Encoder
+    for key in ("1920x1080_f64_q32", "416x240_f8_q32"):
+        size, f, q = key.split("_")
+        w, h = (int(v) for v in size.split("x"))
+        pics = clip(w, h, int(f[1:]))
+        enc = Encoder(w, h, int(q[1:]), lanes=2, spin_us=200)
+        try:
+            with pytest.raises(XmiError):
+                enc.collect()
+            stream = b""
+            for i, (y, u, v) in enumerate(pics):
+                enc.submit(y, u, v, i == 0)
+                if i == 1:
+                    with pytest.raises(XmiError):
+                        enc.submit(y, u, v, False)      # two pictures wait
+                    with pytest.raises(XmiError):
+                        enc.encode(y, u, v, False)
+                if i:
+                    stream += enc.collect()
+            stream += enc.collect()
+        finally:
+            enc.close()
+        assert len(stream) == GOLD[key]["bytes"] and hashlib.md5(stream).hexdigest() == GOLD[key]["md5"], key
+
+
 def test_picture_hash_matches_the_reconstruction():
     """the SEI carries the MD5 of each reconstructed plane (src/encode.cpp:6012-6053): the writer's digest against hashlib"""
     from x265_amd.encoder import Encoder

@@ -141,3 +141,50 @@ def test_small_output_buffer_is_refused_and_nothing_is_written_beyond_it():
     n = lib.orc_encoder_encode(enc, pics[0][0].ctypes.data, pics[0][1].ctypes.data, pics[0][2].ctypes.data, 2, big.ctypes.data, big.size)
     assert n > cap
     lib.orc_encoder_destroy(enc)
+
+
+def test_two_step_encode_gives_the_same_access_units():
+    """submit / collect with one picture in flight: the access units equal encode()'s; the limits of the queue are errors and
+    a collect into a buffer that is too small leaves the picture waiting."""
+    from x265_amd.encoder import align_frame
+    lib = checker()
+    w, h, qp = 416, 240, 32
+    W, H = 448, 256
+    rng = np.random.default_rng(1234)
+    pics = [align_frame(*frame(w, h, t, rng), W, H) for t in range(4)]
+    lib.orc_encoder_submit.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    lib.orc_encoder_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    out = np.zeros(W * H * 3 + 8192, np.uint8)
+
+    def args(t):
+        return [p.ctypes.data for p in pics[t]] + [2 if t == 0 else 1]
+
+    enc = lib.orc_encoder_create(W, H, qp, 0)
+    lib.orc_encoder_configure(enc, 1, 0)
+    plain = []
+    for t in range(4):
+        n = lib.orc_encoder_encode(enc, *args(t), out.ctypes.data, out.size)
+        assert n > 0
+        plain.append(bytes(out[:n]))
+    lib.orc_encoder_destroy(enc)
+
+    enc = lib.orc_encoder_create(W, H, qp, 0)
+    lib.orc_encoder_configure(enc, 1, 0)
+    assert lib.orc_encoder_collect(enc, out.ctypes.data, out.size) == -104       # nothing waits
+    got = []
+    assert lib.orc_encoder_submit(enc, *args(0)) == 0
+    assert lib.orc_encoder_submit(enc, *args(1)) == 0
+    assert lib.orc_encoder_submit(enc, *args(2)) == -103                         # two wait already
+    assert lib.orc_encoder_encode(enc, *args(2), out.ctypes.data, out.size) == -103
+    assert lib.orc_encoder_collect(enc, out.ctypes.data, 100) == -102            # too small: the picture keeps waiting
+    for t in (2, 3):
+        n = lib.orc_encoder_collect(enc, out.ctypes.data, out.size)
+        assert n > 0
+        got.append(bytes(out[:n]))
+        assert lib.orc_encoder_submit(enc, *args(t)) == 0
+    for _ in range(2):
+        n = lib.orc_encoder_collect(enc, out.ctypes.data, out.size)
+        assert n > 0
+        got.append(bytes(out[:n]))
+    lib.orc_encoder_destroy(enc)
+    assert got == plain

@@ -66,6 +66,34 @@ def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, specula
             "p_picture_us_per_round_trip": per[-1]["us_per_round_trip"] if p_ms else None}
 
 
+def run_two_step(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200):
+    """the same stream with one picture in flight: picture t + 1 is handed in (xmi_encoder_submit) before the access unit of
+    picture t is taken (xmi_encoder_collect), so the picture hash of t - a serial MD5 pass - runs beside the analysis of t + 1"""
+    import hashlib
+    from x265_amd.encoder import Encoder
+    pics = clip(w, h, n)
+    warm = Encoder(w, h, qp)
+    warm.encode(*pics[0], True)
+    warm.close()
+    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us)
+    try:
+        stream = b""
+        t0 = time.perf_counter()
+        for i, (y, u, v) in enumerate(pics):
+            enc.submit(y, u, v, i == 0)
+            if i:
+                stream += enc.collect()
+        stream += enc.collect()
+        wall = time.perf_counter() - t0
+    finally:
+        enc.close()
+    want = recorded_stream(w, h, n, qp)
+    md5 = hashlib.md5(stream).hexdigest()
+    return {"stream_matches_fixture": None if want is None else bool((want["md5"], want["bytes"]) == (md5, len(stream))),
+            "what": "the same clip through xmi_encoder_submit / xmi_encoder_collect, one picture in flight: an access unit is taken after the next picture was handed in",
+            "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": md5}
+
+
 def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0, seed0=7):
     """`segments` independent GOP segments (each its own encoder, I picture first) encoded at the same time on one GPU, one
     host thread per segment (the C call releases the interpreter lock): whole-job pictures per second over all pictures,
@@ -111,6 +139,9 @@ def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0
 
 def main():
     a = sys.argv[1:]
+    if a and a[0] == "two_step":      # two_step W H FRAMES QP
+        print(json.dumps(run_two_step(*(int(v) for v in a[1:5]))))
+        return
     if a and a[0] == "segments":      # segments N PICTURES WORKERS SPIN_US
         n, pics, workers, spin = (int(v) for v in a[1:5])
         print(json.dumps(run_segments(1920, 1080, pics, 32, n, workers or None, spin)))

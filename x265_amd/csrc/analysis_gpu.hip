@@ -20,6 +20,7 @@
 #include <thread>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -75,7 +76,8 @@ struct RoundParams {
     int nluma, nchroma;           // workgroups of the luma part, chroma jobs
     int n64;                      // 64x64 CUs, which are the first jobs of the table
     const uint8_t *src[3];        // source planes, rows width / width/2 apart
-    const uint8_t *planes;        // 16 quarter-pel luma planes of the padded reference
+    const uint8_t *planes;        // 16 quarter-pel luma planes of the padded reference: rows `stride` bytes apart, phases `phase_pitch`
+    unsigned phase_pitch, row_bytes;      // row_bytes: bytes of a row
     const uint8_t *ref_c[2];      // sample (0,0) of the padded chroma reference planes
     int width, stride, rows, stride_c;
     int qp, qpc;
@@ -108,7 +110,7 @@ struct __align__(16) RoundLds {
 
 __device__ __forceinline__ const uint8_t *plane_block(const RoundParams &p, int x0, int y0, int mvx, int mvy)
 {
-    const size_t plane = (size_t)((mvy & 3) * 4 + (mvx & 3)) * (size_t)p.stride * p.rows;
+    const size_t plane = (size_t)((mvy & 3) * 4 + (mvx & 3)) * (size_t)p.phase_pitch;
     return p.planes + plane + (size_t)(kPad + y0 + (mvy >> 2)) * p.stride + kPad + x0 + (mvx >> 2);
 }
 
@@ -388,7 +390,7 @@ __device__ void luma_job(const RoundParams &p, RoundLds &L, const LumaJob &j, in
         rq.mv_min_ipel[0] = j.mv_min_ipel[0], rq.mv_min_ipel[1] = j.mv_min_ipel[1];
         rq.mv_max_ipel[0] = j.mv_max_ipel[0], rq.mv_max_ipel[1] = j.mv_max_ipel[1];
         rq.sqrt_lambda = j.sqrt_lambda;
-        MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+        MeParams mp = { p.src[0], p.planes, nullptr, &L.me, p.width, p.stride, p.rows, kPad, 1, kMeRange, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, p.phase_pitch, p.row_bytes };
         if constexpr (kLazy) {      // the whole workgroup shares the block
             if (known) {
                 search<N, false, false, 4>(mp, rq, 0, tid, L.win, L.red36);
@@ -1160,6 +1162,7 @@ public:
     size_t jobs_bytes = 0, out_bytes = 0, off_groups = 0, off_cjobs = 0, off_done = 0, intra_scratch = 0;
     hipStream_t st = nullptr;                              // picture set-up
     int cur_qp = 0, cur_qpc = 0;
+    bool planes_by_row = std::getenv("XMI_EXP_PLANES_CLASSIC") == nullptr;      // layout of d_planes (interp_planes_launch)
     bool rdoq = false, rdoq_active = false;      // the level decision (rdoq.hip) in the P pictures' transform chains: asked for / in force for the bound picture
     RdoqSet h_rdoq, *d_rdoq = nullptr;
     // P rounds: hand the answers out when the merge paths of the asking CUs and the chroma jobs are through (rows then poll
@@ -1383,7 +1386,7 @@ public:
             XMI_HIP(hipMemcpyAsync(d_ref[0], ref[0], (size_t)stride * rows, hipMemcpyHostToDevice, st));
             XMI_HIP(hipMemcpyAsync(d_ref[1], ref[1], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
             XMI_HIP(hipMemcpyAsync(d_ref[2], ref[2], (size_t)stride_c * rows_c, hipMemcpyHostToDevice, st));
-            int rc = xmi_interp_planes_dev(d_ref[0], stride, rows, stride, d_planes, st);
+            int rc = xmi::interp_planes_launch(d_ref[0], stride, rows, stride, d_planes, planes_by_row, st);
             if (rc != XMI_OK) return rc;
         }
         cur_qp = qp, cur_qpc = qpc;
@@ -1799,7 +1802,11 @@ private:
         for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
         p.planes = d_planes;
         p.ref_c[0] = d_ref[1] + (size_t)kPadC * stride_c + kPadC, p.ref_c[1] = d_ref[2] + (size_t)kPadC * stride_c + kPadC;
-        p.width = w, p.stride = stride, p.rows = rows, p.stride_c = stride_c;
+        // the 16 phases of a row lie next to each other: the candidates of a sub-pel stage - up to nine planes - then share
+        // their pages and memory rows instead of lying megabytes apart
+        p.width = w, p.rows = rows, p.stride_c = stride_c;
+        p.stride = planes_by_row ? 16 * stride : stride;
+        p.phase_pitch = planes_by_row ? (unsigned)stride : (unsigned)((size_t)stride * rows), p.row_bytes = (unsigned)stride;
         p.qp = cur_qp, p.qpc = cur_qpc;
         p.rdoq = rdoq_active ? d_rdoq : nullptr;
         p.out = R.g_out;
@@ -2066,23 +2073,54 @@ int xmi_encoder_speculate(xmi_encoder *e, int level)
     return XMI_OK;
 }
 
+namespace {
+void mark_lanes(xmi_encoder *e)
+{
+    for (int i = 0; i < e->ev.lanes; i++) {
+        const GpuEvaluator::LaneRes &l = e->ev.lane[i];
+        e->lane_mark[i][0] = l.t_prepare, e->lane_mark[i][1] = l.t_launch, e->lane_mark[i][2] = l.t_wait, e->lane_mark[i][3] = l.t_collect;
+    }
+}
+// the encoder's own error codes as messages and XMI_ERR_* values
+int64_t encoder_error(xmi_encoder *e, const char *who, int n, size_t capacity)
+{
+    if (n == -100) xmi::set_error("%s: the output buffer must hold at least 4096 bytes", who);
+    else if (n == -101) xmi::set_error("%s: a P picture needs a picture before it (the first picture, or the one after a failed call, is an I picture)", who);
+    else if (n == -102) xmi::set_error("%s: access unit exceeds capacity (%zu bytes; slice data is limited to 3 * width * height + 4096 bytes)", who, capacity);
+    else if (n == -103) xmi::set_error("%s: pictures are waiting for xmi_encoder_collect (two at most; none for xmi_encoder_encode)", who);
+    else if (n == -104) xmi::set_error("%s: no picture is waiting", who);
+    else if (e->ev.first_error()[0]) xmi::set_error("%s: %s", who, e->ev.first_error());
+    return n <= -100 && n >= -104 ? XMI_ERR_ARG : (n == XMI_ERR_ARG || n == XMI_ERR_NO_DEVICE ? n : XMI_ERR_HIP);
+}
+}  // namespace
+
 int64_t xmi_encoder_encode(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, uint8_t *out, size_t capacity)
 {
     int rc = xmi::enter_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(e && src_y && src_u && src_v && out, "xmi_encoder_encode: null argument");
     XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_encode: slice type %d", slice_type);
-    for (int i = 0; i < e->ev.lanes; i++) {
-        const GpuEvaluator::LaneRes &l = e->ev.lane[i];
-        e->lane_mark[i][0] = l.t_prepare, e->lane_mark[i][1] = l.t_launch, e->lane_mark[i][2] = l.t_wait, e->lane_mark[i][3] = l.t_collect;
-    }
+    mark_lanes(e);
     const int n = e->enc.encode(src_y, src_u, src_v, slice_type, e->ev, e->ev, out, capacity);
-    if (n > 0) return n;
-    if (n == -100) xmi::set_error("xmi_encoder_encode: the output buffer must hold at least 4096 bytes");
-    else if (n == -101) xmi::set_error("xmi_encoder_encode: a P picture needs a picture before it (the first picture, or the one after a failed call, is an I picture)");
-    else if (n == -102) xmi::set_error("xmi_encoder_encode: access unit exceeds capacity (%zu bytes; slice data is limited to 3 * width * height + 4096 bytes)", capacity);
-    else if (e->ev.first_error()[0]) xmi::set_error("xmi_encoder_encode: %s", e->ev.first_error());
-    return n == -100 || n == -101 || n == -102 ? XMI_ERR_ARG : (n == XMI_ERR_ARG || n == XMI_ERR_NO_DEVICE ? n : XMI_ERR_HIP);
+    return n > 0 ? n : encoder_error(e, "xmi_encoder_encode", n, capacity);
+}
+
+int xmi_encoder_submit(xmi_encoder *e, const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type)
+{
+    int rc = xmi::enter_device();
+    if (rc != XMI_OK) return rc;
+    XMI_ARG(e && src_y && src_u && src_v, "xmi_encoder_submit: null argument");
+    XMI_ARG(slice_type == XMI_SLICE_P || slice_type == XMI_SLICE_I, "xmi_encoder_submit: slice type %d", slice_type);
+    mark_lanes(e);
+    const int n = e->enc.submit(src_y, src_u, src_v, slice_type, e->ev, e->ev);
+    return n == 0 ? XMI_OK : (int)encoder_error(e, "xmi_encoder_submit", n, 0);
+}
+
+int64_t xmi_encoder_collect(xmi_encoder *e, uint8_t *out, size_t capacity)
+{
+    XMI_ARG(e && out, "xmi_encoder_collect: null argument");
+    const int n = e->enc.collect(out, capacity);
+    return n > 0 ? n : encoder_error(e, "xmi_encoder_collect", n, capacity);
 }
 
 int xmi_encoder_reconstruction(xmi_encoder *e, uint8_t *y, uint8_t *u, uint8_t *v)

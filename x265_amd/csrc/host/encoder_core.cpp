@@ -65,6 +65,17 @@ Encoder::Encoder(int width, int height, int qp, int strong_intra_smoothing)
     stats_.assign((size_t)rows_ * cols_ * 3, SaoStats());
 }
 
+Encoder::~Encoder()
+{
+    for (Pending &q : pend_) q.join();
+}
+
+void Encoder::Pending::join()
+{
+    if (hash_y.joinable()) hash_y.join();
+    if (hash_c.joinable()) hash_c.join();
+}
+
 namespace {
 
 // The syntax of one CTU (xEncWriteCU, src/encode.cpp:4547-4924) from the picture-level decision arrays. The reference reads
@@ -482,13 +493,38 @@ void Encoder::sao_decide(int slice_type, const SaoStats *stats)
 int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, analysis::Evaluator &ev, FrameOps &ops, uint8_t *out,
                     size_t cap)
 {
+    if (slice_type != 2 && !have_ref_) return -101;
+    if (cap < 4096) return -100;               // parameter sets, slice header and the picture hash need a few hundred bytes at most
+    if (pending_) return -103;
+    int rc = submit(src_y, src_u, src_v, slice_type, ev, ops);
+    if (rc) return rc;
+    const auto t = std::chrono::steady_clock::now();
+    rc = collect(out, cap);
+    stage_ns[3] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count();
+    if (rc < 0) {      // the access unit does not fit: the picture is given up and the sequence cannot go on
+        pend_[first_].join();
+        first_ ^= 1, pending_--;
+        have_ref_ = false;
+    }
+    return rc;
+}
+
+int Encoder::submit(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, analysis::Evaluator &ev, FrameOps &ops)
+{
     using clock = std::chrono::steady_clock;
     auto ns = [](clock::time_point a, clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
     const bool intra = slice_type == 2;
     if (!intra && !have_ref_) return -101;
+    if (pending_ == 2) return -103;
     const size_t ny = (size_t)w_ * h_;
-    if (cap < 4096) return -100;               // parameter sets, slice header and the picture hash need a few hundred bytes at most
-    // What the handle carries from picture to picture is committed when the access unit is complete; an error on the way leaves
+    Pending &slot = pend_[(first_ + pending_) & 1], &other = pend_[(first_ + pending_ + 1) & 1];
+    // parameter sets, slice header, entry points (4 bytes each at most), slice data (at most the substream buffer), hash unit;
+    // two readable bytes in front for the writer's look-back
+    slot.au.resize(2 + ny * 3 + 4096 + 4096 + 8 * (size_t)rows_ + 256);
+    slot.au[0] = slot.au[1] = 0xff;
+    uint8_t *const out = slot.au.data() + 2;
+    const size_t cap = slot.au.size() - 2;
+    // What the handle carries from picture to picture is committed when the slice is complete; an error on the way leaves
     // the handle without a reference picture (its analysis statistics may have advanced: the sequence cannot go on).
     struct Commit {
         Encoder &e;
@@ -574,6 +610,7 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
             }
             pp[comp] = params;
         }
+        other.join(), slot.join();      // the hash of the picture before reads rec_
         uint8_t *outp[3] = { rec_[0].data(), rec_[1].data(), rec_[2].data() };
         rc = ops.sao_apply(w_, h_, pp, outp);
         if (rc) return rc < 0 ? rc : -rc;
@@ -583,21 +620,19 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     // The picture hash of the final reconstruction (src/encode.cpp:6012-6053) follows the slice in the access unit and does not
     // depend on it: MD5 runs at about 0.8 GB/s and cannot be split within a plane, so luma and the two chroma planes are
     // hashed on two threads while this one writes the slice.
-    sub_.resize(ny * 3 + 4096);      // (before the threads start: nothing below this line throws while they are joinable)
-    uint8_t digest[3][16];
-    struct Joiner {
-        std::thread &t;
-        ~Joiner()
-        {
-            if (t.joinable()) t.join();
-        }
-    };
-    std::thread hash_y([&] { bitstream::md5_plane(rec_[0].data(), (size_t)w_, (size_t)w_, (size_t)h_, digest[0]); });
-    std::thread hash_c([&] {
-        bitstream::md5_plane(rec_[1].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[1]);
-        bitstream::md5_plane(rec_[2].data(), (size_t)wc, (size_t)wc, (size_t)hc, digest[2]);
-    });
-    Joiner join_y{ hash_y }, join_c{ hash_c };
+    // They are joined by collect(), by the next picture before it replaces rec_, or by the destructor.
+    sub_.resize(ny * 3 + 4096);
+    slot.join();
+    {
+        Pending *const q = &slot;
+        const uint8_t *const py = rec_[0].data(), *const pu = rec_[1].data(), *const pv = rec_[2].data();
+        const size_t w = (size_t)w_, h = (size_t)h_;
+        slot.hash_y = std::thread([=] { bitstream::md5_plane(py, w, w, h, q->digest[0]); });
+        slot.hash_c = std::thread([=] {
+            bitstream::md5_plane(pu, w / 2, w / 2, h / 2, q->digest[1]);
+            bitstream::md5_plane(pv, w / 2, w / 2, h / 2, q->digest[2]);
+        });
+    }
 
     // ---- slice header, then the slice data: one substream per CTU row (xCompressCU, src/encode.cpp:5594-5750) ----
     bitstream::write_slice_header(bs, slice_type, poc, sao_on_[0], sao_on_[1], qp_);
@@ -665,9 +700,12 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     cabac.out = &bs;
     cabac.flush();      // the reference flushes the coder a second time, into the access unit (src/encode.cpp:5749)
     bs.trailing_bits();
-    // slice data beyond the substream buffer (more than 3 bytes per luma sample), or an access unit beyond the caller's buffer:
-    // nothing was written past either end; the call fails. 64 bytes cover the picture-hash unit that follows, escapes included.
-    if (sb.overflowed() || bs.overflowed() || bs.room() < 64 + 8) return -102;
+    // slice data beyond the substream buffer (more than 3 bytes per luma sample): nothing was written past its end; the call
+    // fails. 64 bytes cover the picture-hash unit that follows, escapes included.
+    if (sb.overflowed() || bs.overflowed() || bs.room() < 64 + 8) {
+        slot.join();
+        return -102;
+    }
 
     // ---- the reconstruction becomes the reference of the next picture ----
     for (int c = 0; c < 3; c++) {
@@ -675,22 +713,38 @@ int Encoder::encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
         for (int i = 0; i < ph; i++) std::memcpy(&ref_[c][(size_t)(pad + i) * stride + pad], &rec_[c][(size_t)i * pw], (size_t)pw);
     }
 
-    // ---- picture hash SEI ----
-    hash_y.join(), hash_c.join();
-    bs.flush();
-    start_code(0x50);
-    bs.put(0x01, 8), bs.put(0x84, 8), bs.put(0x31, 8), bs.put(0x00, 8);
-    for (int c = 0; c < 3; c++)
-        for (int j = 0; j < 16; j++) bs.put(digest[c][j], 8);
-    bs.trailing_bits();
-    bs.flush();
-    int len = bs.flush();
-    if (out[len - 1] == 0) out[len++] = 0x03;
-    if (bs.overflowed()) return -102;
+    slot.bs = bs, slot.sei_done = false, slot.len = 0;
+    pending_++;
     commit.ok = true;
     const auto t4 = clock::now();
     stage_ns[0] = ns(t0, t1), stage_ns[1] = ns(t1, t2), stage_ns[2] = ns(t2, t3), stage_ns[3] = ns(t3, t4);
-    return len;
+    return 0;
+}
+
+int Encoder::collect(uint8_t *out, size_t cap)
+{
+    if (!pending_) return -104;
+    Pending &slot = pend_[first_];
+    if (!slot.sei_done) {
+        // ---- picture hash SEI ----
+        slot.join();
+        BitWriter &bs = slot.bs;
+        bs.flush();
+        bs.raw_byte(0), bs.raw_byte(0), bs.raw_byte(1), bs.raw_byte(0x50);
+        bs.put(0x01, 8), bs.put(0x84, 8), bs.put(0x31, 8), bs.put(0x00, 8);
+        for (int c = 0; c < 3; c++)
+            for (int j = 0; j < 16; j++) bs.put(slot.digest[c][j], 8);
+        bs.trailing_bits();
+        bs.flush();
+        int len = bs.flush();
+        uint8_t *au = slot.au.data() + 2;
+        if (au[len - 1] == 0) au[len++] = 0x03;
+        slot.len = len, slot.sei_done = true;
+    }
+    if ((size_t)slot.len > cap) return -102;      // stays pending: a larger buffer can still take it
+    std::memcpy(out, slot.au.data() + 2, (size_t)slot.len);
+    first_ ^= 1, pending_--;
+    return slot.len;
 }
 
 }  // namespace encoder

@@ -8,9 +8,11 @@
 // to the GPU; the test harness under oracle/ binds them to the CPU checker.
 #pragma once
 #include <cstdint>
+#include <thread>
 #include <vector>
 
 #include "analysis_core.h"
+#include "bitstream.h"
 #include "syntax.h"
 
 namespace xmi {
@@ -48,13 +50,26 @@ public:
 class Encoder {
 public:
     Encoder(int width, int height, int qp, int strong_intra_smoothing);      // coded size, multiples of 64
+    ~Encoder();
+    Encoder(const Encoder &) = delete;
+    Encoder &operator=(const Encoder &) = delete;
     analysis::Analyser &analyser() { return an_; }
 
     // One picture (xEncodeFrame): src_* are the source planes at coded size (packed), slice_type 1 = P, 2 = I. The access
     // unit - parameter sets in front of an I picture, slice, picture-hash SEI - is written to out (capacity cap); returns its
-    // size, or a negative error of the evaluator / frame operations (-100: out too small, -101: P picture without reference).
+    // size, or a negative error of the evaluator / frame operations (-100: out smaller than 4096 bytes, -101: P picture without
+    // reference, -102: the access unit does not fit, -103: pictures submitted and not collected).
     int encode(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, analysis::Evaluator &ev, FrameOps &ops, uint8_t *out,
                size_t cap);
+    // The same in two steps, for callers that accept the access unit of picture n after they have handed in picture n + 1:
+    // submit() does everything up to the slice data and the reference picture of the next call and leaves the picture hash
+    // (MD5 of the final reconstruction: a serial pass, 2.6 ms for a 1920x1088 luma plane) to two threads; collect() waits for
+    // them, appends the hash unit and hands out the oldest access unit. At most two pictures may be waiting (-103);
+    // collect() without one is -104, and with a buffer that is too small -102 (the picture keeps waiting).
+    // encode() = submit() + collect().
+    int submit(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, analysis::Evaluator &ev, FrameOps &ops);
+    int collect(uint8_t *out, size_t cap);
+    int waiting() const { return pending_; }
 
     // the last picture's final reconstruction (after deblocking and SAO), packed planes
     const std::vector<uint8_t> &rec_y() const { return rec_[0]; }
@@ -86,6 +101,16 @@ private:
     std::vector<SaoStats> stats_;
     std::vector<SaoCtuParam> sao_params_;
     std::vector<uint8_t> sub_;               // slice data under construction
+    struct Pending {                         // an access unit that lacks its picture hash
+        std::vector<uint8_t> au;             // two bytes the writer may look back over, then the access unit
+        bitstream::BitWriter bs;             // where it goes on
+        std::thread hash_y, hash_c;
+        uint8_t digest[3][16];
+        int len = 0;
+        bool sei_done = false;
+        void join();
+    } pend_[2];
+    int first_ = 0, pending_ = 0;            // the oldest waiting picture's slot, pictures waiting
 };
 
 }  // namespace encoder

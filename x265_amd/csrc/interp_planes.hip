@@ -72,14 +72,15 @@ __device__ __forceinline__ void store4(uint8_t *dst, u32 v, int x, int cols, boo
 }
 
 // buffer: `rows` x `stride` bytes; samples within 4 of the buffer edge are left untouched in planes 1..15
-__global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t *planes, int stride, int rows, int cols)
+// Output: sample (y, x) of phase ph at planes[ph * phase_pitch + y * row_pitch + x] - whole planes one after the other
+// (phase_pitch = rows * stride, row_pitch = stride) or the 16 phases of a row next to each other (phase_pitch = stride,
+// row_pitch = 16 * stride).
+__global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t *planes, int stride, int rows, int cols, size_t row_pitch, size_t phase_pitch)
 {
     __shared__ __align__(16) uint8_t s_ref[RH][RW];          // window rows y0-3 .., columns x0-4 ..
     __shared__ __align__(16) int16_t s_h[3][RH][TW];         // horizontal sums for xf = 1..3 (unbiased, fit 16 bits)
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = 4 + blockIdx.y * TH;       // first output sample of the tile (columns 0..3 are not written)
-    const size_t plane_bytes = (size_t)rows * stride;
-
     // window: rows y0-3 .., columns x0-4 .. x0+131 (one column more on the left than the filters need, so that it starts
     // on a dword of the buffer); whole dwords when the buffer allows it, clamped bytes at the right edge otherwise. The
     // columns left of the buffer (first tile of a row) only feed the four outputs that are not written.
@@ -183,22 +184,30 @@ __global__ void __launch_bounds__(256) interp_kernel(const uint8_t *ref, uint8_t
         out[8 + xf] = pack_hv(std::integral_constant<int, 2>{});
         out[12 + xf] = pack_hv(std::integral_constant<int, 3>{});
     }
-    const size_t at = (size_t)y * stride + x;
+    const size_t at = (size_t)y * row_pitch + x;
     const bool aligned = (at & 3) == 0;
 #pragma unroll
-    for (int ph = 0; ph < 16; ph++) store4(planes + ph * plane_bytes + at, out[ph], x, cols, aligned);
+    for (int ph = 0; ph < 16; ph++) store4(planes + ph * phase_pitch + at, out[ph], x, cols, aligned);
 }
 
 }  // namespace
 
-extern "C" int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, void *stream)
+namespace xmi {
+int interp_planes_launch(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, bool phases_by_row, void *stream)
 {
     int rc = xmi::require_device();
     if (rc != XMI_OK) return rc;
     XMI_ARG(d_ref_base && d_planes, "xmi_interp_planes_dev: null argument");
     XMI_ARG(rows >= 16 && cols >= 16 && stride >= cols, "xmi_interp_planes_dev: bad geometry %d x %d, stride %d", cols, rows, stride);
     dim3 grid((cols - 4 + TW - 1) / TW, (rows - 8 + TH - 1) / TH);
-    hipLaunchKernelGGL(interp_kernel, grid, dim3(256), 0, xmi::as_stream(stream), d_ref_base, d_planes, stride, rows, cols);
+    const size_t row_pitch = phases_by_row ? (size_t)16 * stride : (size_t)stride, phase_pitch = phases_by_row ? (size_t)stride : (size_t)rows * stride;
+    hipLaunchKernelGGL(interp_kernel, grid, dim3(256), 0, xmi::as_stream(stream), d_ref_base, d_planes, stride, rows, cols, row_pitch, phase_pitch);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
+}
+}  // namespace xmi
+
+extern "C" int xmi_interp_planes_dev(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, void *stream)
+{
+    return xmi::interp_planes_launch(d_ref_base, stride, rows, cols, d_planes, false, stream);
 }

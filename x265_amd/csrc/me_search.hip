@@ -133,7 +133,7 @@ extern "C" int xmi_me_search_batch_dev(const uint8_t *d_cur, int cur_stride, con
     if (n == 0) return XMI_OK;
     rc = check_common("xmi_me_search_batch_dev", d_cur, cur_stride, d_planes, stride, rows, pad, d_req, me_range, d_res);
     if (rc != XMI_OK) return rc;
-    MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0 };
+    MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, (u32)((size_t)rows * stride), (u32)stride };
     hipLaunchKernelGGL(me_search_kernel<false>, dim3(((n + 3) / 4 + 7) / 8 * 8 + ((n + 15) / 16 + 7) / 8 * 8), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;
@@ -156,7 +156,7 @@ extern "C" int xmi_me_search_surface_batch_dev(const uint8_t *d_cur, int cur_str
             "xmi_me_search_surface_batch_dev: surface geometry %dx%d range %d is not one xmi_sad_surface_dev produces", g->width,
             g->height, g->range);
     MeParams p = { d_cur, d_planes, d_req, d_res, cur_stride, stride, rows, pad, n, me_range, d_sad8, d_sad16, d_sad32, d_sad64,
-                   g->range, g->width / 64, (g->width / 64) * (g->height / 64) };
+                   g->range, g->width / 64, (g->width / 64) * (g->height / 64), (u32)((size_t)rows * stride), (u32)stride };
     hipLaunchKernelGGL(me_search_kernel<true>, dim3(((n + 3) / 4 + 7) / 8 * 8 + ((n + 15) / 16 + 7) / 8 * 8), dim3(256), 0, xmi::as_stream(stream), p);
     XMI_HIP(hipGetLastError());
     return XMI_OK;

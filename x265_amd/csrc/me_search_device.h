@@ -13,14 +13,15 @@ struct __attribute__((aligned(4))) dword_pair { u32 x, y; };      // an 8-byte a
 
 struct MeParams {
     const uint8_t *cur;
-    const uint8_t *planes;   // 16 planes, each rows*stride bytes; pixel (0,0) of the frame at (pad, pad)
+    const uint8_t *planes;   // 16 phase planes; sample (y, x) of phase ph at planes[ph * phase_pitch + y * stride + x]; pixel (0,0) of the frame at (pad, pad)
     const xmi_me_request *req;
     xmi_me_result *res;
-    int cur_stride, stride, rows, pad, n, me_range;
+    int cur_stride, stride, rows, pad, n, me_range;      // stride: bytes between rows of a plane
     // resident SAD surface of the same picture pair (SURF kernels only)
     const uint16_t *sad8, *sad16;
     const u32 *sad32, *sad64;
     int surf_range, surf_wc, surf_nctu;
+    u32 phase_pitch, row_bytes;                          // bytes between phases; bytes of a row that may be read
 };
 
 __device__ __forceinline__ u32 mv_bits(int v)
@@ -85,7 +86,6 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
     constexpr int KC = J == 1 ? 9 : J == 4 ? (WAVES == 4 ? 9 : 4) : 1;
     const int lane = PACK ? (wave_lane & 15) : wave_lane;
     const bool live = DW >= GT || lane < DW;
-    const size_t plane_bytes = (size_t)p.rows * p.stride;
     u32 cur[J];
     // the lane's dwords: d = lane + GT j -> row lane / DPR + j * (GT / DPR), column dword lane % DPR
     constexpr int JR = GT / DPR > 0 ? GT / DPR : 1;  // rows between a lane's dwords
@@ -147,7 +147,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
                 if (k0 + k < COUNT) out[k0 + k] = part[k];
         }
     };
-    const u32 ref_off = (u32)((p.pad + rq.y0) * p.stride + p.pad + rq.x0), plane_u32 = (u32)plane_bytes;
+    const u32 ref_off = (u32)((p.pad + rq.y0) * p.stride + p.pad + rq.x0), plane_u32 = p.phase_pitch;
     auto qpel = [&](int mx, int my) { return ref_off + (u32)((my & 3) * 4 + (mx & 3)) * plane_u32 + (u32)((my >> 2) * p.stride + (mx >> 2)); };
     auto ipel = [&](int x, int y) { return ref_off + (u32)(y * p.stride + x); };
     // ---- reference window in LDS for the diamond walk (kernels without a SAD surface) ----
@@ -169,7 +169,7 @@ __device__ __forceinline__ void search(const MeParams &p, const xmi_me_request &
         for (int e = lane; e < WH * WPD; e += GL) {
             const int r = e / WPD, c = e - r * WPD, y = gy0 + r, x = gxb + 4 * c;
             u32 v = 0;
-            if (y >= 0 && y < p.rows && x >= 0 && x + 4 <= p.stride) v = *reinterpret_cast<const u32 *>(p.planes + (size_t)y * p.stride + x);
+            if (y >= 0 && y < p.rows && x >= 0 && x + 4 <= (int)p.row_bytes) v = *reinterpret_cast<const u32 *>(p.planes + (size_t)y * p.stride + x);
             reinterpret_cast<u32 *>(s_win)[e] = v;
         }
         group_barrier();

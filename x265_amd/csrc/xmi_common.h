@@ -16,6 +16,9 @@ int  require_device();          // XMI_OK or XMI_ERR_*: binds on first use; the 
 int  enter_device();            // the same for host-pointer / handle entry points: makes the bound device current for the thread
 int  bound_device();            // -1 before the first binding
 hipStream_t as_stream(void *s);
+// xmi_interp_planes_dev with a choice of layout: whole planes one after the other (the documented layout of the entry point) or,
+// phases_by_row, the 16 phases of a row next to each other - sample (y, x) of phase ph at d_planes[(y * 16 + ph) * stride + x]
+int interp_planes_launch(const uint8_t *d_ref_base, int stride, int rows, int cols, uint8_t *d_planes, bool phases_by_row, void *stream);
 
 // per-device set-up of sad_surface.hip (LDS opt-in of its kernels); called when the library binds a device
 int sad_surface_prepare_device();

@@ -80,6 +80,26 @@ class Encoder:
             raise XmiError(f"xmi_encoder_encode returned {n}: {self.lib.xmi_last_error().decode()}")
         return bytes(self.out[:n])
 
+    def submit(self, y, u, v, intra):
+        """first step of encode(): everything but the picture hash; collect() hands out the access units in order"""
+        if y.shape != (self.H, self.W):
+            y, u, v = align_frame(y, u, v, self.W, self.H)
+        else:
+            y, u, v = (np.ascontiguousarray(p) for p in (y, u, v))
+        self.lib.xmi_encoder_submit.argtypes = [C.c_void_p] * 4 + [C.c_int]
+        rc = self.lib.xmi_encoder_submit(self.handle, y.ctypes.data, u.ctypes.data, v.ctypes.data, SLICE_I if intra else SLICE_P)
+        if rc != 0:
+            raise XmiError(f"xmi_encoder_submit returned {rc}: {self.lib.xmi_last_error().decode()}")
+
+    def collect(self):
+        """-> the bytes of the oldest access unit that waits"""
+        self.lib.xmi_encoder_collect.restype = C.c_int64
+        self.lib.xmi_encoder_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        n = self.lib.xmi_encoder_collect(self.handle, self.out.ctypes.data, self.out.size)
+        if n <= 0:
+            raise XmiError(f"xmi_encoder_collect returned {n}: {self.lib.xmi_last_error().decode()}")
+        return bytes(self.out[:n])
+
     def reconstruction(self):
         y = np.zeros((self.H, self.W), np.uint8)
         u, v = np.zeros((self.H // 2, self.W // 2), np.uint8), np.zeros((self.H // 2, self.W // 2), np.uint8)
