@@ -256,6 +256,8 @@ def encode_rate(L, qp=32, segments=True, workers=SEGMENT_WORKERS):
             uhd = bench_encoder.run(3840, 2160, UHD_FRAMES, qp)
             out["uhd"] = {k: uhd[k] for k in ("stream_matches_fixture", "what", "encode_fps", "pictures", "bytes", "md5", "i_picture_ms", "p_picture_ms", "p_stage_ms",
                                               "round_trips_per_p_picture") if k in uhd}
+            two = bench_encoder.run_two_step(3840, 2160, UHD_FRAMES, qp)
+            out["uhd"]["two_step"] = {k: two[k] for k in ("stream_matches_fixture", "encode_fps")}
         return out
     except Exception as e:      # noqa: BLE001 - reported, the headline measurement above stands on its own
         return {"error": repr(e)}

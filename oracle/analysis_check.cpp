@@ -22,10 +22,18 @@ struct Pictures {
     int w, h, ref_stride_y, ref_stride_c;
 };
 
+// the checker's transform, prediction and chain functions keep static work buffers (oracle/x265_oracle.c): one lock for every
+// handle of the process
+std::mutex &oracle_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+
 class CpuEvaluator : public Evaluator {
 public:
     Pictures p;
-    std::mutex mu;
+    std::mutex &mu = oracle_mutex();
     std::vector<uint8_t> lane_bytes[8];
     std::vector<int16_t> lane_words[8];
 
@@ -530,6 +538,11 @@ int orc_encoder_configure(void *h, int lanes, int spin_us)
 {
     static_cast<EncHandle *>(h)->enc.analyser().lanes = lanes;
     static_cast<EncHandle *>(h)->enc.analyser().spin_us = spin_us;
+    return 0;
+}
+int orc_encoder_workers(void *h, int workers)
+{
+    static_cast<EncHandle *>(h)->enc.analyser().workers = workers;
     return 0;
 }
 int orc_encoder_rdoq(void *h, int on)

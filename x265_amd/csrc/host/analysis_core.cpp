@@ -24,6 +24,18 @@
 
 #include <sched.h>
 #include <ucontext.h>
+#if defined(__SANITIZE_THREAD__)
+// ThreadSanitizer follows hand-made context switches only when told: its fiber interface (sanitizer/tsan_interface.h)
+extern "C" {
+void *__tsan_get_current_fiber(void);
+void *__tsan_create_fiber(unsigned flags);
+void __tsan_destroy_fiber(void *fiber);
+void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+}
+#define XMI_TSAN_FIBER(stmt) stmt
+#else
+#define XMI_TSAN_FIBER(stmt)
+#endif
 
 namespace xmi {
 namespace analysis {
@@ -274,6 +286,7 @@ struct Row {
     // has cores to poll on, and a row that waits - for answers, for the row above - hands its thread to the next one.
     enum Wait { kReady, kAnswers, kRowAbove };
     ucontext_t fiber, *home = nullptr;
+    void *san_fiber = nullptr, *san_home = nullptr;      // the sanitizer's handles of the two contexts (ThreadSanitizer builds only)
     std::unique_ptr<char[]> stack;
     Wait wait = kReady;
     bool started = false, done = false;
@@ -285,6 +298,7 @@ struct Row {
     void block(Wait why)      // back to the worker until the reason has gone
     {
         wait = why;
+        XMI_TSAN_FIBER(__tsan_switch_to_fiber(san_home, 0));
         swapcontext(&fiber, home);
         wait = kReady;
     }
@@ -860,6 +874,7 @@ void Row::make_fiber()
     fiber.uc_link = nullptr;
     const uintptr_t a = reinterpret_cast<uintptr_t>(this);
     makecontext(&fiber, reinterpret_cast<void (*)()>(&Row::fiber_main), 2, (unsigned)(a & 0xffffffffu), (unsigned)(a >> 32));
+    XMI_TSAN_FIBER(san_fiber = __tsan_create_fiber(0));
     started = true;
 }
 
@@ -868,6 +883,7 @@ void Row::fiber_main(unsigned lo, unsigned hi)
     Row *r = reinterpret_cast<Row *>((uintptr_t)lo | ((uintptr_t)hi << 32));
     r->run();
     r->done = true;
+    XMI_TSAN_FIBER(__tsan_switch_to_fiber(r->san_home, 0));
     swapcontext(&r->fiber, r->home);      // for good
 }
 
@@ -1443,9 +1459,14 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                 if (r->done || !r->runnable()) continue;
                 r->home = &home;
                 if (!r->started) r->make_fiber();
+                XMI_TSAN_FIBER(r->san_home = __tsan_get_current_fiber());
+                XMI_TSAN_FIBER(__tsan_switch_to_fiber(r->san_fiber, 0));
                 swapcontext(&home, &r->fiber);
                 ran = true;
-                if (r->done) left--;
+                if (r->done) {
+                    left--;
+                    XMI_TSAN_FIBER(__tsan_destroy_fiber(r->san_fiber));
+                }
             }
             if (!ran && left && !poll_until(S.spin_us, any)) {
                 std::unique_lock<std::mutex> lk(S.m);

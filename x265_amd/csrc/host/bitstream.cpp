@@ -326,12 +326,16 @@ struct Md5 {
     void transform(const uint8_t *p)
     {
         static const int shift[4][4] = { { 7, 12, 17, 22 }, { 5, 9, 14, 20 }, { 4, 11, 16, 23 }, { 6, 10, 15, 21 } };
-        static uint32_t k[64];
-        static bool have = false;
-        if (!have) {
-            for (int i = 0; i < 64; i++) k[i] = (uint32_t)(int64_t)std::floor(std::fabs(std::sin((double)(i + 1))) * 4294967296.0);
-            have = true;
-        }
+        // (a function-local static object: its construction is thread safe, and two planes are hashed at the same time)
+        struct Sines {
+            uint32_t v[64];
+            Sines()
+            {
+                for (int i = 0; i < 64; i++) v[i] = (uint32_t)(int64_t)std::floor(std::fabs(std::sin((double)(i + 1))) * 4294967296.0);
+            }
+        };
+        static const Sines sines;
+        const uint32_t *const k = sines.v;
         uint32_t m[16];
         for (int i = 0; i < 16; i++) m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
         uint32_t A = a, B = b, C = c, D = d;
