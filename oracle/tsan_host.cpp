@@ -3,7 +3,7 @@
 // The host side of the encoder (x265_amd/csrc/host/*.cpp: CTU rows as fibers of worker threads, coordinators, lock-free
 // hand-over, hashing threads) under ThreadSanitizer, bound to the CPU evaluator of analysis_check.cpp: several encoder handles
 // encode the same small clip at the same time from threads of their own - what one GPU does for a rank's GOP segments - in
-// the one- and two-step form, with one and two coordinators. Every stream must equal the first; the sanitizer reports data
+// the one- and two-step form, with one and two coordinators, sleeping and polling waiters. Every stream must equal the first; the sanitizer reports data
 // races on the way (oracle/Makefile target tsan builds everything with -fsanitize=thread; TSAN_OPTIONS=halt_on_error=1).
 #include <cstdint>
 #include <cstdio>
@@ -48,10 +48,10 @@ std::vector<Picture> clip()
     return pics;
 }
 
-std::vector<uint8_t> encode(const std::vector<Picture> &pics, int lanes, int workers, bool two_step)
+std::vector<uint8_t> encode(const std::vector<Picture> &pics, int lanes, int workers, bool two_step, int spin_us)
 {
     void *e = orc_encoder_create(W, H, 32, 0);
-    orc_encoder_configure(e, lanes, 0);
+    orc_encoder_configure(e, lanes, spin_us);
     orc_encoder_workers(e, workers);
     std::vector<uint8_t> out((size_t)W * H * 3 + 8192), stream;
     auto take = [&](int n) {
@@ -76,11 +76,11 @@ std::vector<uint8_t> encode(const std::vector<Picture> &pics, int lanes, int wor
 int main()
 {
     const std::vector<Picture> pics = clip();
-    const std::vector<uint8_t> first = encode(pics, 1, 1, false);
+    const std::vector<uint8_t> first = encode(pics, 1, 1, false, 0);
     constexpr int N = 6;
     std::vector<std::vector<uint8_t>> got(N);
     std::vector<std::thread> th;
-    for (int i = 0; i < N; i++) th.emplace_back([&, i] { got[i] = encode(pics, 1 + (i & 1), 1 + i % 3, (i & 2) != 0); });
+    for (int i = 0; i < N; i++) th.emplace_back([&, i] { got[i] = encode(pics, 1 + (i & 1), 1 + i % 3, (i & 2) != 0, i >= 3 ? 40 : 0); });
     for (std::thread &t : th) t.join();
     for (int i = 0; i < N; i++)
         if (got[i] != first) {
