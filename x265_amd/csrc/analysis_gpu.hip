@@ -683,6 +683,7 @@ struct __align__(16) IntraLds {
     uint8_t area[2][64], outer[2][40], qref[2][20];
     int qmode[4];
     double qcost[36];                 // quads: cost of every mode of the PU in hand
+    uint32_t qpred[36 * 4];           // quads: the four predicted samples of every (mode, row) of the PU in hand
 };
 
 // sample at (xx, yy) relative to the origin of an 8x8 area: from its 33 outer samples, or from the area itself
@@ -940,6 +941,7 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
             int hd[4] = { 0, 0, 0, 0 };
             if (mode < 35) {
                 int d[4];
+                uint32_t pv = 0;
                 const uint8_t *tl = ref + 8;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -953,7 +955,9 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
                         if (t & (1u << 21)) v = min(255, max(0, v + (((int)tl[(int)(int8_t)(t >> 24)] - (int)tl[0]) >> 1)));
                     }
                     d[x] = (int)L.r.pix[(oy + row) * 8 + ox + x] - v;
+                    pv |= (uint32_t)v << (8 * x);
                 }
+                L.qpred[mode * 4 + row] = pv;      // the winner's rows are the PU's prediction
                 const int a0 = d[0] + d[1], a1 = d[0] - d[1], a2 = d[2] + d[3], a3 = d[2] - d[3];
                 hd[0] = a0 + a2, hd[1] = a1 + a3, hd[2] = a0 - a2, hd[3] = a1 - a3;
             }
@@ -979,16 +983,17 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
         __syncthreads();
         XMI_QSTAMP(q3);
         if (wave == 0) {
-            // first minimum in mode order: lane m holds mode m's cost and looks at every other one (broadcast reads)
-            const double mine = lane < 35 ? L.qcost[lane] : 1.7976931348623157e308;
-            bool first = lane < 35;
+            // first minimum in mode order: lane m holds mode m's cost; butterfly over (cost, mode) pairs
+            double best_c = lane < 35 ? L.qcost[lane] : 1.7976931348623157e308;
+            int mode = lane;
 #pragma unroll
-            for (int o = 0; o < 35; o++) {
-                const double oc = L.qcost[o];
-                first = first && !(oc < mine || (oc == mine && o < lane));
+            for (int o = 32; o > 0; o >>= 1) {
+                const double oc = __shfl_xor(best_c, o);
+                const int om = __shfl_xor(mode, o);
+                if (oc < best_c || (oc == best_c && om < mode)) best_c = oc, mode = om;
             }
-            const int mode = __ffsll((long long)__ballot(first)) - 1;
-            if (lane < 16) L.r.pred[lane] = (uint8_t)pred_sample<4>(ref, mode, lane / 4, lane % 4, dc, true);
+            mode = __builtin_amdgcn_readfirstlane(mode);
+            if (lane < 4) reinterpret_cast<uint32_t *>(L.r.pred)[lane] = L.qpred[mode * 4 + lane];
             __builtin_amdgcn_wave_barrier();
             XMI_QSTAMP(q4);
             uint32_t sum, ssd;
