@@ -94,14 +94,14 @@ def run_two_step(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200):
             "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": md5}
 
 
-def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0, seed0=7):
+def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0, seed0=7, speculate=None):
     """`segments` independent GOP segments (each its own encoder, I picture first) encoded at the same time on one GPU, one
     host thread per segment (the C call releases the interpreter lock): whole-job pictures per second over all pictures,
     and over the P pictures alone (after a barrier behind the I pictures)"""
     import threading
     from x265_amd.encoder import Encoder
     clips = [clip(w, h, n, seed=seed0 + s) for s in range(segments)]
-    encs = [Encoder(w, h, qp, spin_us=spin_us, workers=workers) for _ in range(segments)]
+    encs = [Encoder(w, h, qp, spin_us=spin_us, workers=workers, speculate=speculate) for _ in range(segments)]
     errs, marks = [], {}
     gate = threading.Barrier(segments + 1)
 
@@ -133,7 +133,7 @@ def run_segments(w=1920, h=1080, n=4, qp=32, segments=8, workers=None, spin_us=0
         e.close()
     if errs:
         return {"error": errs[0]}
-    return {"segments": segments, "pictures_per_segment": n, "workers": workers, "spin_us": spin_us, "encode_fps": round(segments * n / (t1 - t0), 2),
+    return {"segments": segments, "pictures_per_segment": n, "workers": workers, "spin_us": spin_us, "speculate": speculate, "encode_fps": round(segments * n / (t1 - t0), 2),
             "p_pictures_per_s": round(segments * (n - 1) / (t1 - marks["i_done"]), 2), "i_pictures_s": round(marks["i_done"] - t0, 3)}
 
 
@@ -142,9 +142,9 @@ def main():
     if a and a[0] == "two_step":      # two_step W H FRAMES QP
         print(json.dumps(run_two_step(*(int(v) for v in a[1:5]))))
         return
-    if a and a[0] == "segments":      # segments N PICTURES WORKERS SPIN_US
+    if a and a[0] == "segments":      # segments N PICTURES WORKERS SPIN_US [SPECULATE]
         n, pics, workers, spin = (int(v) for v in a[1:5])
-        print(json.dumps(run_segments(1920, 1080, pics, 32, n, workers or None, spin)))
+        print(json.dumps(run_segments(1920, 1080, pics, 32, n, workers or None, spin, speculate=int(a[5]) if len(a) > 5 else None)))
         return
     w, h, n, qp = (int(v) for v in a[:4]) if len(a) >= 4 else (1920, 1080, 8, 32)
     lanes, spin = (int(a[4]), int(a[5])) if len(a) >= 6 else (2, 200)
