@@ -334,3 +334,42 @@ def test_library_encoder_with_the_decision_equals_the_cpu_harness(w, h, frames, 
             assert payload[:48] == b"".join(hashlib.md5(p.tobytes()).digest() for p in rec)
     finally:
         enc.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp", [22, 27, 32, 37])
+def test_1080p_qp_sweep_with_the_decision(qp):
+    """1920x1080 at every QP of the published sweep with the decision on: the P pictures differ from the plain quantiser's, every
+    access unit's picture hash is the hash of the encoder's reconstruction, and switching the decision off again on a new
+    handle gives back the recorded stream of the reference (tests/golden/encoder_md5.json)."""
+    import hashlib
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from gen_yuv import frame
+    from x265_amd.encoder import Encoder
+    gold = json.load(open(os.path.join(root, "tests", "golden", "encoder_md5.json")))
+    key = next(k for k in sorted(gold) if k.startswith("1920x1080_f") and k.endswith(f"_q{qp}") and "f64" not in k)
+    frames = int(key.split("_")[1][1:])
+    streams = {}
+    for on in (True, False):
+        rng = np.random.default_rng(7)
+        enc = Encoder(1920, 1080, qp, rdoq=on)
+        out = []
+        try:
+            for t in range(frames):
+                au = enc.encode(*frame(1920, 1080, t, rng), t == 0)
+                rec = enc.reconstruction()
+                k = au.rfind(b"\x00\x00\x01\x50\x01\x84\x31\x00")
+                payload = au[k + 8:].replace(b"\x00\x00\x03", b"\x00\x00")
+                assert payload[:48] == b"".join(hashlib.md5(p.tobytes()).digest() for p in rec), (on, t)
+                out.append(au)
+        finally:
+            enc.close()
+        streams[on] = out
+    plain = b"".join(streams[False])
+    assert len(plain) == gold[key]["bytes"] and hashlib.md5(plain).hexdigest() == gold[key]["md5"]
+    assert streams[True][0] == streams[False][0]                  # the I picture keeps the reference's quantiser
+    assert streams[True][1:] != streams[False][1:]                # the P pictures take the decision's levels
