@@ -246,7 +246,10 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
         held = make_uint2((uint32_t)(lv[0] & 0xffff) | ((uint32_t)lv[1] << 16), (uint32_t)(lv[2] & 0xffff) | ((uint32_t)lv[3] << 16));
         if (!LAZY) *reinterpret_cast<uint2 *>(level + (size_t)k * out_stride + i) = held;
     }
-    __syncthreads();
+    // (the barrier also tells every thread whether the unit has a level at all: without one its reconstruction is its
+    // prediction, and the prediction stays here - the result area is host memory, and the writes to it are what rounds of
+    // several handles queue for)
+    const bool any_level = __syncthreads_or(local != 0) != 0;
     XMI_CSTAMP(c3);
     if (live) stage<N, true>(Mt, L.b, L.a, 7, tid);
     __syncthreads();
@@ -267,7 +270,7 @@ __device__ void chain_unit(RoundLds &L, const uint8_t *pix, int pix_stride, cons
         }
         *reinterpret_cast<uint32_t *>(rec + (size_t)i * out_stride + j) = r4;
         if (rec_copy) *reinterpret_cast<uint32_t *>(rec_copy + i * copy_stride + j) = r4;
-        if (pred_out) *reinterpret_cast<uint32_t *>(pred_out + (size_t)i * out_stride + j) = pr4;
+        if (pred_out && any_level) *reinterpret_cast<uint32_t *>(pred_out + (size_t)i * out_stride + j) = pr4;
     }
     // the two sums of the unit: one value per wavefront into LDS (256 atomics on one word take longer than the transform)
     local = wave_sum(local);

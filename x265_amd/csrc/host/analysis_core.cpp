@@ -635,7 +635,17 @@ uint32_t Row::decide(int px, int py, int size, int depth)
             cab[depth] = work;
             bmv = mg[k];
             if (skip) {
-                std::memcpy(best_rec[li], q.pred_merge, (size_t)size * size);
+                // the prediction: per transform unit, the evaluator's copy of it where the unit has levels and the
+                // reconstruction - the same samples - where it has none
+                if (size == 64) {
+                    for (int u = 0; u < 4; u++) {
+                        const uint8_t *from = q.sum_merge[u] ? q.pred_merge : q.rec_merge;
+                        const size_t o = (size_t)(u >> 1) * 32 * 64 + (u & 1) * 32;
+                        for (int r = 0; r < 32; r++) std::memcpy(best_rec[li] + o + (size_t)r * 64, from + o + (size_t)r * 64, 32);
+                    }
+                } else {
+                    std::memcpy(best_rec[li], q.sum_merge[0] ? q.pred_merge : q.rec_merge, (size_t)size * size);
+                }
                 std::memset(best_coef[li], 0, (size_t)size * size * 2);
                 best_cbf[li] = 0;
             } else {

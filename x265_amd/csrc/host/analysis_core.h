@@ -37,7 +37,7 @@ struct CuEval {
     uint32_t ssd_skip;                // SSD(source, prediction of best_merge)
     uint32_t ssd_merge;               // SSD(source, reconstruction of best_merge)
     uint32_t sum_merge[4];            // sum |level| per transform unit; the levels of a unit are defined only where it is not zero
-    const uint8_t *pred_merge, *rec_merge;
+    const uint8_t *pred_merge, *rec_merge;      // pred_merge: defined only in the units whose sum_merge is not zero (elsewhere rec_merge is the prediction)
     const int16_t *level_merge;
     Mv mv_me;
     uint32_t ssd_me, sum_me[4];
