@@ -35,9 +35,10 @@ __global__ void __launch_bounds__(256) echo(unsigned *counter, unsigned target, 
 int main()
 {
     const int rounds = 4000;
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 6; mode++) {
         const int hold_us = mode == 0 ? 0 : 20;
-        const unsigned write_kb = mode == 2 ? 8 : mode == 3 ? 32 : 0;      // per workgroup, with a 256-byte read in front
+        const unsigned write_kb = mode == 2 || mode == 5 ? 8 : mode == 3 ? 32 : 0;      // per workgroup
+        const bool do_read = mode == 2 || mode == 3 || mode == 4;                  // a 256-byte record read in front
         for (int nthreads : { 1, 2, 4, 8, 16 }) {
             std::vector<std::thread> th;
             std::atomic<int> ready{ 0 };
@@ -49,10 +50,8 @@ int main()
                     unsigned *done = nullptr, *counter = nullptr, *h_in = nullptr;
                     uint4 *h_out = nullptr;
                     (void)hipHostMalloc((void **)&done, 256, hipHostMallocMapped | hipHostMallocCoherent);
-                    if (write_kb) {
-                        (void)hipHostMalloc((void **)&h_in, 64 * 256, hipHostMallocMapped | hipHostMallocCoherent);
-                        (void)hipHostMalloc((void **)&h_out, (size_t)64 * write_kb * 1024, hipHostMallocMapped | hipHostMallocCoherent);
-                    }
+                    if (do_read) (void)hipHostMalloc((void **)&h_in, 64 * 256, hipHostMallocMapped | hipHostMallocCoherent);
+                    if (write_kb) (void)hipHostMalloc((void **)&h_out, (size_t)64 * write_kb * 1024, hipHostMallocMapped | hipHostMallocCoherent);
                     (void)hipMalloc((void **)&counter, 256);
                     (void)hipMemset(counter, 0, 256);
                     *done = 0;
@@ -87,8 +86,8 @@ int main()
             const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             double mean = 0;
             for (double l : lat) mean += l / nthreads;
-            std::printf("kernel of %2d workgroups holding %2d us, %2u KiB to host memory each, %2d threads: %7.0f round trips/s in all, %6.2f us each\n", blocks, hold_us,
-                        write_kb, nthreads, nthreads * rounds / wall, mean);
+            std::printf("kernel of %2d workgroups holding %2d us, %s%2u KiB to host memory each, %2d threads: %7.0f round trips/s in all, %6.2f us each\n", blocks, hold_us,
+                        do_read ? "a record from and " : "", write_kb, nthreads, nthreads * rounds / wall, mean);
         }
     }
     return 0;
