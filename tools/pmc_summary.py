@@ -10,7 +10,7 @@ files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
 acc = defaultdict(lambda: defaultdict(list))
 for f in files:
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0][:60]
+        k = row["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "").split("(")[0][:60]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in acc.items():
     print(k)
