@@ -257,6 +257,10 @@ def encode_rate(L, qp=32, segments=True, workers=SEGMENT_WORKERS):
         import bench_encoder
         out = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp)
         out["two_step"] = bench_encoder.run_two_step(1920, 1080, ENCODE_FRAMES, qp)
+        # the reference's build without its CHECK_SEI option (no picture-hash unit; src/CMakeLists.txt:37): another stream, pinned
+        # by tests/golden/encoder_md5_nosei.json at other clip lengths
+        nh = bench_encoder.run(1920, 1080, ENCODE_FRAMES, qp, picture_hash=False)
+        out["without_picture_hash"] = {k: nh[k] for k in ("encode_fps", "bytes", "p_picture_ms", "p_stage_ms")}
         if segments:
             out["segments_8"] = bench_encoder.run_segments(1920, 1080, 4, qp, 8, workers=workers)
             # the 3840x2160 configuration (coded 3840x2176), a short clip: to be read beside cpu_baseline.encoder_2160p

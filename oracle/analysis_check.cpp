@@ -545,6 +545,11 @@ int orc_encoder_workers(void *h, int workers)
     static_cast<EncHandle *>(h)->enc.analyser().workers = workers;
     return 0;
 }
+int orc_encoder_picture_hash(void *h, int on)
+{
+    static_cast<EncHandle *>(h)->enc.picture_hash(on != 0);
+    return 0;
+}
 int orc_encoder_rdoq(void *h, int on)
 {
     static_cast<EncHandle *>(h)->ev.rdoq = on != 0;

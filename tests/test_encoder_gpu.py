@@ -203,6 +203,30 @@ def test_two_step_encode_writes_the_recorded_stream():
         assert len(stream) == GOLD[key]["bytes"] and hashlib.md5(stream).hexdigest() == GOLD[key]["md5"], key
 
 
+def test_without_the_picture_hash_the_stream_is_the_one_of_the_reference_built_without_it():
+    """xmi_encoder_picture_hash(e, 0): the reference's CHECK_SEI build option off (src/CMakeLists.txt:37); streams recorded from
+    oracle/_ref/x265_refsse_nosei (tests/golden/encoder_md5_nosei.json), one- and two-step"""
+    from x265_amd.encoder import Encoder
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "encoder_md5_nosei.json")))
+    for key in sorted(gold):
+        size, f, q = key.split("_")
+        w, h = (int(v) for v in size.split("x"))
+        pics = clip(w, h, int(f[1:]))
+        for two_step in (False, True):
+            enc = Encoder(w, h, int(q[1:]), picture_hash=False)
+            try:
+                stream = b""
+                for i, (y, u, v) in enumerate(pics):
+                    if two_step:
+                        enc.submit(y, u, v, i == 0)
+                        stream += enc.collect()
+                    else:
+                        stream += enc.encode(y, u, v, i == 0)
+            finally:
+                enc.close()
+            assert len(stream) == gold[key]["bytes"] and hashlib.md5(stream).hexdigest() == gold[key]["md5"], (key, two_step)
+
+
 def test_picture_hash_matches_the_reconstruction():
     """the SEI carries the MD5 of each reconstructed plane (src/encode.cpp:6012-6053): the writer's digest against hashlib"""
     from x265_amd.encoder import Encoder

@@ -31,13 +31,16 @@ def checker():
     return lib
 
 
-def encode(lib, w, h, frames, qp, lanes=1, speculate=1):
+def encode(lib, w, h, frames, qp, lanes=1, speculate=1, picture_hash=True):
     from x265_amd.encoder import align_frame
     W, H = (w + 63) // 64 * 64, (h + 63) // 64 * 64
     enc = lib.orc_encoder_create(W, H, qp, 0)
     lib.orc_encoder_configure(enc, lanes, 0)
     lib.orc_encoder_speculate.argtypes = [C.c_void_p, C.c_int]
     assert lib.orc_encoder_speculate(enc, speculate) == 0      # 2, the library's setting, costs the CPU harness several times the pixel work
+    if not picture_hash:
+        lib.orc_encoder_picture_hash.argtypes = [C.c_void_p, C.c_int]
+        assert lib.orc_encoder_picture_hash(enc, 0) == 0
     rng = np.random.default_rng(1234)
     out = np.zeros(W * H * 3 + 4096, np.uint8)
     stream, raw = b"", b""
@@ -188,3 +191,19 @@ def test_two_step_encode_gives_the_same_access_units():
         got.append(bytes(out[:n]))
     lib.orc_encoder_destroy(enc)
     assert got == plain
+
+
+def test_host_encoder_without_the_picture_hash_writes_the_stream_of_the_reference_built_without_it():
+    """the reference's CHECK_SEI build option off (src/CMakeLists.txt:37): tests/golden/encoder_md5_nosei.json, written by
+    oracle/_ref/x265_refsse_nosei (tools/enc_parity.py --nosei)"""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "encoder_md5_nosei.json")))
+    lib = checker()
+    for key in ("416x240_f8_q32", "416x240_f3_q22"):
+        size, f, q = key.split("_")
+        w, h = (int(v) for v in size.split("x"))
+        stream, raw = encode(lib, w, h, int(f[1:]), int(q[1:]), picture_hash=False)
+        assert hashlib.md5(raw).hexdigest() == gold[key]["input_md5"]
+        assert len(stream) == gold[key]["bytes"] and hashlib.md5(stream).hexdigest() == gold[key]["md5"], key

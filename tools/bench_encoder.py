@@ -28,13 +28,13 @@ def recorded_stream(w, h, n, qp):
         return None
 
 
-def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, speculate=None):
+def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, speculate=None, picture_hash=True):
     """one picture stream: the clip of the CPU baseline (tools/gen_yuv.py, seed 7 at 1080p), picture 0 intra; wall clock of the
     encode calls (pictures resident in host memory; the call uploads them)"""
     import hashlib
     from x265_amd.encoder import Encoder
     pics = clip(w, h, n)
-    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us, speculate=speculate)
+    enc = Encoder(w, h, qp, lanes=lanes, spin_us=spin_us, speculate=speculate, picture_hash=picture_hash)
     try:
         warm = Encoder(w, h, qp)        # first call of a process: code objects, buffers - on an instance of its own, so that the
         warm.encode(*pics[0], True)     # timed instance starts from a new encoder's state, as the reference's run does
@@ -55,7 +55,7 @@ def run(w=1920, h=1080, n=6, qp=32, lanes=2, spin_us=200, verbose=False, specula
         enc.close()
     p_ms = [p["ms"] for p in per[1:]]
     md5 = hashlib.md5(stream).hexdigest()
-    want = recorded_stream(w, h, n, qp)
+    want = recorded_stream(w, h, n, qp) if picture_hash else None
     return {"stream_matches_fixture": None if want is None else bool((want["md5"], want["bytes"]) == (md5, len(stream))),
             "what": f"{w}x{h} synthetic IPPP, {n} pictures, QP {qp}: this library's encoder (xmi_encoder_encode), one picture stream",
             "encode_fps": round(n / wall, 2), "pictures": n, "bytes": len(stream), "md5": md5,

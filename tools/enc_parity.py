@@ -2,6 +2,8 @@
 """Run the encoder integration harness variants and compare bitstreams.
   enc_parity.py --write            (development container) record refsse md5s into tests/golden/encoder_md5.json
   enc_parity.py --add              the same for the configurations the file does not hold yet; the others stay as they are
+  enc_parity.py --nosei            record the streams of the reference built without its CHECK_SEI option (x265_refsse_nosei:
+                                   no picture-hash unit) into tests/golden/encoder_md5_nosei.json
   enc_parity.py VARIANT...         print md5/size/time per variant for every recorded config"""
 import hashlib
 import json
@@ -30,7 +32,23 @@ def run(variant, yuv, w, h, f, q, out, scene_change=0):
     return hashlib.md5(open(out, "rb").read()).hexdigest(), os.path.getsize(out), time.time() - t
 
 
+def write_nosei():
+    gold = {}
+    with tempfile.TemporaryDirectory() as d:
+        for w, h, f, q in ((416, 240, 8, 32), (416, 240, 3, 22), (1920, 1080, 4, 32)):
+            yuv = os.path.join(d, "in.yuv")
+            subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_yuv.py"), str(w), str(h), str(f), str(SEED[w]), yuv])
+            m, n, t = run("refsse_nosei", yuv, w, h, f, q, os.path.join(d, "o.265"))
+            print(f"{w}x{h}_f{f}_q{q} refsse_nosei {m} {n} B {t:.2f} s")
+            gold[f"{w}x{h}_f{f}_q{q}"] = {"md5": m, "bytes": n, "input_md5": hashlib.md5(open(yuv, "rb").read()).hexdigest()}
+    path = os.path.join(ROOT, "tests", "golden", "encoder_md5_nosei.json")
+    json.dump(gold, open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
+
+
 def main():
+    if "--nosei" in sys.argv:
+        return write_nosei()
     add = "--add" in sys.argv
     write = "--write" in sys.argv or add
     variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["refsse", "oracle"]

@@ -2073,6 +2073,13 @@ int xmi_encoder_rdoq(xmi_encoder *e, int on)
     return XMI_OK;
 }
 
+int xmi_encoder_picture_hash(xmi_encoder *e, int on)
+{
+    XMI_ARG(e, "xmi_encoder_picture_hash: null handle");
+    e->enc.picture_hash(on != 0);
+    return XMI_OK;
+}
+
 int xmi_encoder_speculate(xmi_encoder *e, int level)
 {
     XMI_ARG(e, "xmi_encoder_speculate: null handle");

@@ -623,7 +623,8 @@ int Encoder::submit(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *s
     // They are joined by collect(), by the next picture before it replaces rec_, or by the destructor.
     sub_.resize(ny * 3 + 4096);
     slot.join();
-    {
+    slot.hashed = hash_on_;
+    if (hash_on_) {
         Pending *const q = &slot;
         const uint8_t *const py = rec_[0].data(), *const pu = rec_[1].data(), *const pv = rec_[2].data();
         const size_t w = (size_t)w_, h = (size_t)h_;
@@ -730,12 +731,14 @@ int Encoder::collect(uint8_t *out, size_t cap)
         slot.join();
         BitWriter &bs = slot.bs;
         bs.flush();
-        bs.raw_byte(0), bs.raw_byte(0), bs.raw_byte(1), bs.raw_byte(0x50);
-        bs.put(0x01, 8), bs.put(0x84, 8), bs.put(0x31, 8), bs.put(0x00, 8);
-        for (int c = 0; c < 3; c++)
-            for (int j = 0; j < 16; j++) bs.put(slot.digest[c][j], 8);
-        bs.trailing_bits();
-        bs.flush();
+        if (slot.hashed) {
+            bs.raw_byte(0), bs.raw_byte(0), bs.raw_byte(1), bs.raw_byte(0x50);
+            bs.put(0x01, 8), bs.put(0x84, 8), bs.put(0x31, 8), bs.put(0x00, 8);
+            for (int c = 0; c < 3; c++)
+                for (int j = 0; j < 16; j++) bs.put(slot.digest[c][j], 8);
+            bs.trailing_bits();
+            bs.flush();
+        }
         int len = bs.flush();
         uint8_t *au = slot.au.data() + 2;
         if (au[len - 1] == 0) au[len++] = 0x03;

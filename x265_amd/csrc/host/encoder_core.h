@@ -70,6 +70,9 @@ public:
     int submit(const uint8_t *src_y, const uint8_t *src_u, const uint8_t *src_v, int slice_type, analysis::Evaluator &ev, FrameOps &ops);
     int collect(uint8_t *out, size_t cap);
     int waiting() const { return pending_; }
+    // The picture-hash unit behind every slice is the reference's default build (CMake option CHECK_SEI, src/CMakeLists.txt:37,
+    // on); off = its build without it: no hashing, no such unit. From the next picture submitted on.
+    void picture_hash(bool on) { hash_on_ = on; }
 
     // the last picture's final reconstruction (after deblocking and SAO), packed planes
     const std::vector<uint8_t> &rec_y() const { return rec_[0]; }
@@ -93,6 +96,7 @@ private:
     std::vector<uint8_t> ref_[3];            // padded previous reconstruction (PAD_YSIZE 80 / PAD_CSIZE 40)
     bool have_ref_ = false;
     bool have_ctx_ = false;
+    bool hash_on_ = true;
     uint8_t last_ctx_[256] = {};             // the coder's context states at the end of the last picture written
     int poc_ = -1;
     std::vector<syntax::SaoUnit> sao_[3];
@@ -108,6 +112,7 @@ private:
         uint8_t digest[3][16];
         int len = 0;
         bool sei_done = false;
+        bool hashed = true;                  // the picture was submitted with the picture hash on
         void join();
     } pend_[2];
     int first_ = 0, pending_ = 0;            // the oldest waiting picture's slot, pictures waiting

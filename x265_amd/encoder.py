@@ -30,7 +30,7 @@ def align_frame(y, u, v, width, height):
 class Encoder:
     """one encoder instance; pictures are (y, u, v) uint8 arrays of the display size given to the constructor"""
 
-    def __init__(self, width, height, qp, strong_intra_smoothing=False, lanes=None, spin_us=0, speculate=None, workers=None, rdoq=False):
+    def __init__(self, width, height, qp, strong_intra_smoothing=False, lanes=None, spin_us=0, speculate=None, workers=None, rdoq=False, picture_hash=True):
         self.lib = load()
         self.width, self.height = width, height
         self.W, self.H = (width + 63) // 64 * 64, (height + 63) // 64 * 64
@@ -61,6 +61,10 @@ class Encoder:
         if rdoq:
             self.lib.xmi_encoder_rdoq.argtypes = [C.c_void_p, C.c_int]
             if self.lib.xmi_encoder_rdoq(self.handle, 1) != 0:
+                raise XmiError(self.lib.xmi_last_error().decode())
+        if not picture_hash:
+            self.lib.xmi_encoder_picture_hash.argtypes = [C.c_void_p, C.c_int]
+            if self.lib.xmi_encoder_picture_hash(self.handle, 0) != 0:
                 raise XmiError(self.lib.xmi_last_error().decode())
         self.out = np.zeros(self.W * self.H * 3 + 4096, np.uint8)
 
