@@ -267,6 +267,20 @@ struct Row {
     uint8_t quad_rec[16];           // the PU of them that is being decided, packed
     int16_t quad_level[16];
     IntraChromaQuadEval cquad;
+    // I pictures: the chroma PUs of a decided CTU are a chain of requests of their own - nothing in it depends on a cost, and
+    // nothing the luma decisions of the next CTU read depends on it (the estimation contexts pass through luma syntax only) -,
+    // so its links travel with the luma requests of the CTU to the right. What the chain reads of its CTU is kept here.
+    int ic_ctu = -1;                // CTU whose chroma chain is under way, or -1
+    int ic_idx = 0;                 // next unit of it in coding order (4x4 units, 256 = through)
+    bool ic_begun = false;          // neighbouring samples gathered (the row above has come far enough)
+    int ic_dx = 0, ic_dy = 0, ic_size_y = 0;
+    uint8_t ic_info1[16 * 16], ic_mode[16 * 16];
+    bool chroma_link_fill();        // the next request of the chain into ichroma / cquad; false when it cannot go yet
+    void chroma_link_take();
+    void chroma_chain_arm(int xp);
+    void chroma_chain_drain();
+    void wait_row_above(int ctus, bool whole);
+    void luma_done(int xp);
     IntraEval *req_in[4] = {};
     int n_req_in = 0;
     bool req_ichroma = false, req_quad = false, req_cquad = false;
@@ -282,6 +296,7 @@ struct Row {
     int n_req_cu = 0;
     bool req_chroma = false;     // ... that is part of the call its lane is making right now
     std::atomic<int> need{ -1 };     // CTUs of the row above this row waits for, or -1 (changed under the mutex, polled without)
+    bool need_whole = true;          // ... complete (I pictures: with their chroma), or their luma alone
     // A row runs as a fiber of a worker thread (rows y, y + workers, ... share one): a picture has more CTU rows than a host
     // has cores to poll on, and a row that waits - for answers, for the row above - hands its thread to the next one.
     enum Wait { kReady, kAnswers, kRowAbove };
@@ -327,14 +342,12 @@ struct Row {
     }
     void fill_intra(IntraEval &q, int px, int py, int size);
     double decide_intra(int px, int py, int size, int depth);
-    void intra_chroma_pass();
 
     void collect_cus(int px, int py, int size, std::vector<int> &list);
     void run();
     void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
     void evaluate_intra(IntraEval *const *list, int n, bool with_quad);
-    void evaluate_intra_chroma(bool quad);
     void fill_quad(int px, int py);
     void post_and_wait();
     static void fiber_main(unsigned lo, unsigned hi);
@@ -366,7 +379,9 @@ struct Shared {
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
     bool defer_chroma = true;       // a CTU's chroma requests travel with the next CTU's first luma request
     std::deque<Lane> lanes;
-    std::vector<int> done;          // CTUs finished per row
+    std::vector<int> done;          // CTUs finished per row (under the mutex)
+    std::vector<int> done_luma;     // I pictures: CTUs whose luma is decided (their chroma may still be under way)
+    std::unique_ptr<std::atomic<int>[]> done_seen;      // `done`, for a look without the mutex
     std::deque<Row> rows;
     std::vector<Ctx> saved;         // contexts after CTU 1 of a row: where the row below starts (cabacRdoSaved, src/encode.cpp:5481)
     Ctx start;                      // contexts of the slice start
@@ -863,15 +878,52 @@ void Row::ctu_done(int xp)
     Shared &S = *sh;
     std::lock_guard<std::mutex> lk(S.m);
     S.done[y] = xp + 1;
+    S.done_seen[y].store(xp + 1, std::memory_order_release);
+    if (S.done_luma[y] < xp + 1) S.done_luma[y] = xp + 1;
     if (y + 1 < S.nrows) {
         Row &below = S.rows[y + 1];
         const int wanted = below.need.load(std::memory_order_relaxed);
-        if (wanted >= 0 && S.done[y] >= wanted) {
+        if (wanted >= 0 && (below.need_whole ? S.done[y] : S.done_luma[y]) >= wanted) {
             S.lanes[0].running++;      // on the waiter's behalf, before it can ask for anything
             below.need.store(-1, std::memory_order_release);
             if (S.sleepers.load(std::memory_order_relaxed) > 0) S.cv_rows.notify_all();
         }
     }
+}
+
+// I pictures: the luma of CTU xp is decided and in the picture's arrays
+void Row::luma_done(int xp)
+{
+    Shared &S = *sh;
+    std::lock_guard<std::mutex> lk(S.m);
+    S.done_luma[y] = xp + 1;
+    if (y + 1 < S.nrows) {
+        Row &below = S.rows[y + 1];
+        const int wanted = below.need.load(std::memory_order_relaxed);
+        if (wanted >= 0 && !below.need_whole && S.done_luma[y] >= wanted) {
+            S.lanes[0].running++;
+            below.need.store(-1, std::memory_order_release);
+            if (S.sleepers.load(std::memory_order_relaxed) > 0) S.cv_rows.notify_all();
+        }
+    }
+}
+
+// until the row above has finished `ctus` CTUs (whole: with their chroma)
+void Row::wait_row_above(int ctus, bool whole)
+{
+    Shared &S = *sh;
+    std::unique_lock<std::mutex> lk(S.m);
+    if ((whole ? S.done[y - 1] : S.done_luma[y - 1]) >= ctus) return;
+    need_whole = whole;
+    need.store(ctus, std::memory_order_relaxed);
+    release_answers();
+    Lane &ln = S.lanes[0];
+    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_all();
+    lk.unlock();
+    const auto t0 = std::chrono::steady_clock::now();
+    block(kRowAbove);
+    t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
+    if (S.error) throw Abort();
 }
 
 void Row::make_fiber()
@@ -999,18 +1051,11 @@ void Row::evaluate_intra(IntraEval *const *list, int n, bool with_quad)
     n_req_in = n, n_req_cu = 0;
     req_chroma = req_ichroma = req_cquad = false;
     req_quad = with_quad;
+    const bool link = ic_ctu >= 0 && chroma_link_fill();
     post_and_wait();
     n_req_in = 0;
     req_quad = false;
-}
-
-void Row::evaluate_intra_chroma(bool quad)
-{
-    n_req_in = n_req_cu = 0;
-    req_chroma = req_quad = false;
-    req_ichroma = !quad, req_cquad = quad;
-    post_and_wait();
-    req_ichroma = req_cquad = false;
+    if (link) chroma_link_take();
 }
 
 // request for the four 4x4 PUs of the 8x8 block at (px, py) of the CTU, nothing of which is decided yet
@@ -1163,14 +1208,49 @@ double Row::decide_intra(int px, int py, int size, int depth)
 
 // xEncodeChromaCU (src/encode.cpp:4234-4418): the PUs of the decided CTU in coding order. Luma PUs of 16x16 and more have one
 // chroma PU each; the chroma of the 8x8 luma blocks of a 16x16 block - four 4x4 chroma PUs - goes out as one request.
-void Row::intra_chroma_pass()
+// The chain of CTU xp starts when the luma of the CTU is in the picture's arrays.
+void Row::chroma_chain_arm(int xp)
 {
+    ic_ctu = xp, ic_idx = 0, ic_begun = false;
+    for (int r = 0; r < 16; r++) {
+        std::memcpy(&ic_info1[r * 16], &I1(r, 0), 16);
+        std::memcpy(&ic_mode[r * 16], &M(r, 0), 16);
+    }
+}
+
+bool Row::chroma_link_fill()
+{
+    Shared &S = *sh;
+    const PictureResult &out = *S.out;
+    const int xp = ic_ctu;
+    if (!ic_begun) {
+        // the unfiltered chroma above (as far as the CTU above and to the right) and to the left of the CTU
+        const int wanted = xp + 2 < S.cols ? xp + 2 : S.cols;
+        if (y > 0 && S.done_seen[y - 1].load(std::memory_order_acquire) < wanted) return false;
+        const int wc = S.w / 2;
+        std::memset(top_u, 0x80, sizeof top_u), std::memset(top_v, 0x80, sizeof top_v);
+        std::memset(left_u, 0x80, sizeof left_u), std::memset(left_v, 0x80, sizeof left_v);
+        if (y > 0) {
+            for (int i = 0; i <= 64; i++) {
+                const int gx = xp * 32 - 1 + i;
+                if (gx >= 0 && gx < wc) top_u[i] = out.rec_u[(size_t)(y * 32 - 1) * wc + gx], top_v[i] = out.rec_v[(size_t)(y * 32 - 1) * wc + gx];
+            }
+        }
+        if (xp > 0) {
+            for (int r = 0; r < 32; r++) {
+                left_u[r] = out.rec_u[(size_t)(y * 32 + r) * wc + xp * 32 - 1];
+                left_v[r] = out.rec_v[(size_t)(y * 32 + r) * wc + xp * 32 - 1];
+            }
+        }
+        ic_begun = true;
+    }
+    auto info = [&](int dy, int dx) { return ic_info1[dy * 16 + dx]; };
     auto unit_valids = [&](int dy, int dx) {
-        int valids = I1(dy, dx) & 0x1f;
-        if ((I1(dy, dx) >> kOffSize) == 0) {      // the chroma block of four 4x4 luma PUs: below-left from the PU below, top-right from the PU to the right
+        int valids = info(dy, dx) & 0x1f;
+        if ((info(dy, dx) >> kOffSize) == 0) {      // the chroma block of four 4x4 luma PUs: below-left from the PU below, top-right from the PU to the right
             valids &= ~0x11;
-            valids |= I1(dy + 1, dx) & 0x01;
-            valids |= I1(dy, dx + 1) & 0x10;
+            valids |= info(dy + 1, dx) & 0x01;
+            valids |= info(dy, dx + 1) & 0x10;
         }
         return valids;
     };
@@ -1184,46 +1264,86 @@ void Row::intra_chroma_pass()
             rv[2 * size + i] = (uint8_t)sample_c(top_v, left_v, rec_v, cy - 1, cx - 1 + i);
         }
     };
-    for (int idx = 0; idx != 256;) {
-        const int dx = interleave4(idx), dy = interleave4(idx >> 1);
-        const int size_y = 1 << (2 + (I1(dy, dx) >> kOffSize));
-        const int cx = dx * 2, cy = dy * 2;
-        if (size_y >= 16 || !sh->speculate) {
-            const int size = size_y == 4 ? 4 : size_y >> 1;
-            IntraChromaEval &c = ichroma;
-            c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy, c.size = size;
-            c.valids = (uint8_t)unit_valids(dy, dx), c.luma_mode = M(dy, dx);
-            c.qpc = chroma_qp(qp);
-            gather(c.ref_u, c.ref_v, cx, cy, size);
-            evaluate_intra_chroma(false);
-            block_in(rec_u + cy * 32 + cx, 32, c.rec_u, size, size, size);
-            block_in(rec_v + cy * 32 + cx, 32, c.rec_v, size, size, size);
-            block_in(coef_u + cy * 32 + cx, 64, c.level_u, size * 2, size, size * 2);
-            block_in(coef_v + cy * 32 + cx, 64, c.level_v, size * 2, size, size * 2);
-            const int cbf_c = (c.sum_v ? 2 : 0) | (c.sum_u ? 1 : 0);
-            I0(dy, dx) |= (uint16_t)((c.best_idx << 13) | (cbf_c << kOffCbfC));
-            idx += size_y < 8 ? 4 : size_y * size_y / 16;
-            continue;
-        }
-        // a 16x16 luma block of smaller PUs (idx is a multiple of 16): the 8x8 area of its chroma
-        IntraChromaQuadEval &c = cquad;
-        c.x0 = ctu_x * 32 + cx, c.y0 = y * 32 + cy;
+    const int dx = ic_dx = interleave4(ic_idx), dy = ic_dy = interleave4(ic_idx >> 1);
+    const int size_y = ic_size_y = 1 << (2 + (info(dy, dx) >> kOffSize));
+    const int cx = dx * 2, cy = dy * 2;
+    if (size_y >= 16 || !S.speculate) {
+        const int size = size_y == 4 ? 4 : size_y >> 1;
+        IntraChromaEval &c = ichroma;
+        c.x0 = xp * 32 + cx, c.y0 = y * 32 + cy, c.size = size;
+        c.valids = (uint8_t)unit_valids(dy, dx), c.luma_mode = ic_mode[dy * 16 + dx];
         c.qpc = chroma_qp(qp);
-        for (int k = 0; k < 4; k++) {
-            const int uy = dy + (k >> 1) * 2, ux = dx + (k & 1) * 2;
-            c.valids[k] = (uint8_t)unit_valids(uy, ux), c.luma_mode[k] = M(uy, ux);
-        }
-        gather(c.ref_u, c.ref_v, cx, cy, 8);
-        evaluate_intra_chroma(true);
+        gather(c.ref_u, c.ref_v, cx, cy, size);
+        req_ichroma = true;
+        return true;
+    }
+    // a 16x16 luma block of smaller PUs (the unit index is a multiple of 16): the 8x8 area of its chroma
+    IntraChromaQuadEval &c = cquad;
+    c.x0 = xp * 32 + cx, c.y0 = y * 32 + cy;
+    c.qpc = chroma_qp(qp);
+    for (int k = 0; k < 4; k++) {
+        const int uy = dy + (k >> 1) * 2, ux = dx + (k & 1) * 2;
+        c.valids[k] = (uint8_t)unit_valids(uy, ux), c.luma_mode[k] = ic_mode[uy * 16 + ux];
+    }
+    gather(c.ref_u, c.ref_v, cx, cy, 8);
+    req_cquad = true;
+    return true;
+}
+
+void Row::chroma_link_take()
+{
+    Shared &S = *sh;
+    PictureResult &out = *S.out;
+    const int xp = ic_ctu, w4 = S.w / 4, dx = ic_dx, dy = ic_dy, cx = dx * 2, cy = dy * 2, size_y = ic_size_y;
+    auto flags = [&](int r, int c) -> uint16_t & { return out.info0[(size_t)(y * 16 + r) * w4 + xp * 16 + c]; };
+    if (req_ichroma) {
+        req_ichroma = false;
+        const IntraChromaEval &c = ichroma;
+        const int size = c.size;
+        block_in(rec_u + cy * 32 + cx, 32, c.rec_u, size, size, size);
+        block_in(rec_v + cy * 32 + cx, 32, c.rec_v, size, size, size);
+        block_in(coef_u + cy * 32 + cx, 64, c.level_u, size * 2, size, size * 2);
+        block_in(coef_v + cy * 32 + cx, 64, c.level_v, size * 2, size, size * 2);
+        const int cbf_c = (c.sum_v ? 2 : 0) | (c.sum_u ? 1 : 0);
+        flags(dy, dx) |= (uint16_t)((c.best_idx << 13) | (cbf_c << kOffCbfC));
+        ic_idx += size_y < 8 ? 4 : size_y * size_y / 16;
+    } else {
+        req_cquad = false;
+        const IntraChromaQuadEval &c = cquad;
         block_in(rec_u + cy * 32 + cx, 32, c.rec_u, 8, 8, 8);
         block_in(rec_v + cy * 32 + cx, 32, c.rec_v, 8, 8, 8);
         block_in(coef_u + cy * 32 + cx, 64, c.level_u, 16, 8, 16);
         block_in(coef_v + cy * 32 + cx, 64, c.level_v, 16, 8, 16);
         for (int k = 0; k < 4; k++) {
             const int cbf_c = (c.sum_v[k] ? 2 : 0) | (c.sum_u[k] ? 1 : 0);
-            I0(dy + (k >> 1) * 2, dx + (k & 1) * 2) |= (uint16_t)((c.best_idx[k] << 13) | (cbf_c << kOffCbfC));
+            flags(dy + (k >> 1) * 2, dx + (k & 1) * 2) |= (uint16_t)((c.best_idx[k] << 13) | (cbf_c << kOffCbfC));
         }
-        idx += 16;
+        ic_idx += 16;
+    }
+    if (ic_idx == 256) {      // the CTU is complete
+        const int wc = S.w / 2;
+        block_in(&out.rec_u[(size_t)(y * 32) * wc + xp * 32], wc, rec_u, 32, 32, 32);
+        block_in(&out.rec_v[(size_t)(y * 32) * wc + xp * 32], wc, rec_v, 32, 32, 32);
+        block_in(&out.coef_u[(size_t)(y * 32) * wc + xp * 32], S.w, coef_u, 64, 32, 64);
+        block_in(&out.coef_v[(size_t)(y * 32) * wc + xp * 32], S.w, coef_v, 64, 32, 64);
+        ic_ctu = -1;
+        ctu_done(xp);
+    }
+}
+
+// what is left of the chain, one request after the other
+void Row::chroma_chain_drain()
+{
+    while (ic_ctu >= 0) {
+        if (!ic_begun && y > 0) wait_row_above(ic_ctu + 2 < sh->cols ? ic_ctu + 2 : sh->cols, true);
+        n_req_in = n_req_cu = 0;
+        req_chroma = req_quad = req_ichroma = req_cquad = false;
+        if (!chroma_link_fill()) {      // (cannot happen after the wait)
+            sh->error = -3;
+            throw Abort();
+        }
+        post_and_wait();
+        chroma_link_take();
     }
 }
 
@@ -1247,21 +1367,7 @@ void Row::run()
             std::memset(tree_ok, 0, sizeof tree_ok);
             in_ok[0] = in_ok[1] = in_ok[2] = in_ok[3] = false;
             quad_ok = false;
-            if (y > 0) {   // top-right neighbour done (or the whole row above)
-                const int need = x + 2 < cols ? x + 2 : cols;
-                std::unique_lock<std::mutex> lk(S.m);
-                if (S.done[y - 1] < need) {
-                    this->need.store(need, std::memory_order_relaxed);
-                    release_answers();
-                    Lane &ln = S.lanes[0];
-                    if (ln.running.fetch_sub(1) == 1) ln.cv_main.notify_all();
-                    lk.unlock();
-                    const auto t0 = std::chrono::steady_clock::now();
-                    block(kRowAbove);
-                    t_resume += std::chrono::steady_clock::now() - t0;      // waiting for the row above is not work
-                    if (S.error) throw Abort();
-                }
-            }
+            if (y > 0) wait_row_above(x + 2 < cols ? x + 2 : cols, !S.intra);      // top-right neighbour done (or the whole row above)
 #ifdef XMI_EXP_HOST_TIMING
             const uint64_t tp0 = tick();
 #endif
@@ -1299,29 +1405,18 @@ void Row::run()
 #endif
             if (S.intra) {
                 // the unfiltered reconstruction above and to the left of the CTU, as far as the picture has it
-                const int wc = S.w / 2;
-                std::memset(top_y, 0x80, sizeof top_y), std::memset(top_u, 0x80, sizeof top_u), std::memset(top_v, 0x80, sizeof top_v);
-                std::memset(left_y, 0x80, sizeof left_y), std::memset(left_u, 0x80, sizeof left_u), std::memset(left_v, 0x80, sizeof left_v);
+                std::memset(top_y, 0x80, sizeof top_y);
+                std::memset(left_y, 0x80, sizeof left_y);
                 if (y > 0) {
                     for (int i = 0; i <= 128; i++) {
                         const int gx = x * 64 - 1 + i;
                         if (gx >= 0 && gx < S.w) top_y[i] = out.rec_y[(size_t)(y * 64 - 1) * S.w + gx];
                     }
-                    for (int i = 0; i <= 64; i++) {
-                        const int gx = x * 32 - 1 + i;
-                        if (gx >= 0 && gx < wc) top_u[i] = out.rec_u[(size_t)(y * 32 - 1) * wc + gx], top_v[i] = out.rec_v[(size_t)(y * 32 - 1) * wc + gx];
-                    }
                 }
-                if (x > 0) {
+                if (x > 0)
                     for (int r = 0; r < 64; r++) left_y[r] = out.rec_y[(size_t)(y * 64 + r) * S.w + x * 64 - 1];
-                    for (int r = 0; r < 32; r++) {
-                        left_u[r] = out.rec_u[(size_t)(y * 32 + r) * wc + x * 32 - 1];
-                        left_v[r] = out.rec_v[(size_t)(y * 32 + r) * wc + x * 32 - 1];
-                    }
-                }
                 std::memset(mvd, 0, sizeof mvd), std::memset(mvp_idx, 0, sizeof mvp_idx);
                 out.rd_cost[(size_t)y * cols + x] = (uint32_t)decide_intra(0, 0, 64, 0);
-                intra_chroma_pass();
             } else {
                 out.rd_cost[(size_t)y * cols + x] = decide(0, 0, 64, 0);
                 chroma_prepare();
@@ -1349,11 +1444,11 @@ void Row::run()
                 S.saved[y] = cab[0];
             }
             if (S.intra) {
-                block_in(&out.rec_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_u, 32, 32, 32);
-                block_in(&out.rec_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w / 2, rec_v, 32, 32, 32);
-                block_in(&out.coef_u[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_u, 64, 32, 64);
-                block_in(&out.coef_v[(size_t)(y * 32) * (S.w / 2) + x * 32], S.w, coef_v, 64, 32, 64);
-                ctu_done(x);
+                // the chroma chain of the CTU before this one has had the luma requests of this CTU to travel with
+                luma_done(x);
+                chroma_chain_drain();
+                chroma_chain_arm(x);
+                if (x + 1 == cols || !S.defer_chroma) chroma_chain_drain();
             } else if (x + 1 < cols && S.defer_chroma) {
                 chroma_waiting = x;                 // with the next CTU's first request
 #ifdef XMI_EXP_HOST_TIMING
@@ -1433,6 +1528,9 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     S.an = this, S.out = &out;
     S.w = w_, S.h = h_, S.cols = cols_, S.nrows = rows_, S.qp = qp;
     S.done.assign(rows_, 0);
+    S.done_luma.assign(rows_, 0);
+    S.done_seen.reset(new std::atomic<int>[rows_]);
+    for (int y = 0; y < rows_; y++) S.done_seen[y].store(0, std::memory_order_relaxed);
     S.saved.resize(rows_);
     S.intra = intra, S.strong = strong;
     init_contexts(intra ? 2 : 1, qp, S.start.m);
