@@ -11,6 +11,7 @@
 // The inner product runs on v_dot2c_i32_i16 over LDS-resident int16 rows with an odd dword pitch.
 #include "tu_valu_device.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -587,7 +588,10 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
     __shared__ __align__(16) v4i s_frag[2][4][64];     // [dct | dst][natural, negated, columns permuted, rows permuted][lane]
     __shared__ __align__(16) int s_bias[2][12];        // [dct | dst]: F2 input by row % 4, I2 input by row % 4, I1 input by column % 4
     __shared__ int2 s_qtab[52];                        // per qp: { quant scale | qbits << 16, dequant scale << qp/6 }
-    __shared__ __align__(16) int16_t s_lvl[4][1024];   // per wavefront: levels of a tile, TU (a, b) at (8a + b) * 16
+    // per wavefront: levels of a tile, TU (a, b) at lv_at(a, b). A store instruction of the quantiser writes one level row of
+    // the eight TUs (a, 0 .. 7) per lane half: 16 int16 apart they would meet in pairs on a bank (stores: dword address mod 32),
+    // so TUs 4 .. 7 of a row sit four dwords further on; a row takes 72 dwords, which spreads the 16-byte reads of the way out.
+    __shared__ __align__(16) int16_t s_lvl[4][8 * 144];
     __shared__ uint32_t s_sum[4][64];                  // per wavefront: sum of |level| of the 64 TUs, memory order
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -629,6 +633,7 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
     __syncthreads();
 
     auto pix_off = [](int row, int col) { return ((col >> 2) * 8 + (row >> 2)) * 16 + (row & 3) * 4 + (col & 3); };
+    auto lv_at = [](int a, int b) { return a * 144 + b * 16 + (b >> 2) * 8; };
     const int ntiles = p.count / S;
     int16_t *lv = s_lvl[wave];
     uint32_t *sm = s_sum[wave];
@@ -659,6 +664,13 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
     };
     if (t0 < ntiles) fetch(t0);
     claim();
+    // The operands of a transform: the single stages keep them in registers from tile to tile until a tile asks for the other
+    // transform; the chain, which has no registers to spare for that, reads them per pass.
+    constexpr bool KEEP = MODE != MODE_CHAIN;
+    int have_type = -1;
+    v4i m_nat = { 0, 0, 0, 0 }, m_neg = { 0, 0, 0, 0 }, m_colperm = { 0, 0, 0, 0 }, m_rowperm = { 0, 0, 0, 0 };
+    int4 b_f2 = { 0, 0, 0, 0 }, b_i2 = { 0, 0, 0, 0 };
+    int b_i1 = 0;
     for (int tile = t0; tile < ntiles; tile += t_step) {
         const int tu_first = tile * S;
         const size_t base = (size_t)tu_first * 16;
@@ -671,7 +683,7 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int c = lane + 64 * half, tu = c >> 1;
-                *reinterpret_cast<v4i *>(lv + ((tu & 7) * 8 + (tu >> 3)) * 16 + (c & 1) * 8) = half ? c_cur1 : c_cur0;
+                *reinterpret_cast<v4i *>(lv + lv_at(tu & 7, tu >> 3) + (c & 1) * 8) = half ? c_cur1 : c_cur0;
             }
         }
 
@@ -690,14 +702,16 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
         const bool dst_lane = ((fl_cur.x & fl_cur.y) & 0x02020202u) == 0x02020202u;
         const bool dct_lane = ((fl_cur.x | fl_cur.y) & 0x02020202u) == 0u;
         const bool all_dst = __all(dst_lane), all_dct = __all(dct_lane);
-        const bool MIXED = !(all_dst || all_dct);
-        for (int pass_i = 0; pass_i < (MIXED ? 2 : 1); pass_i++) {
-            const int type = MIXED ? pass_i : (all_dst ? 1 : 0);
-            const v4i m_nat = s_frag[type][0][lane], m_neg = s_frag[type][1][lane];
-            const v4i m_colperm = s_frag[type][2][lane], m_rowperm = s_frag[type][3][lane];
-            const int4 b_f2 = *reinterpret_cast<const int4 *>(&s_bias[type][0]);
-            const int4 b_i2 = *reinterpret_cast<const int4 *>(&s_bias[type][4]);
-            const int b_i1 = s_bias[type][8 + (r & 3)];
+        auto pass = [&](auto mixed_c, const int type) {
+            constexpr bool MIXED = decltype(mixed_c)::value;
+            if (!KEEP || type != have_type) {
+                m_nat = s_frag[type][0][lane], m_neg = s_frag[type][1][lane];
+                m_colperm = s_frag[type][2][lane], m_rowperm = s_frag[type][3][lane];
+                b_f2 = *reinterpret_cast<const int4 *>(&s_bias[type][0]);
+                b_i2 = *reinterpret_cast<const int4 *>(&s_bias[type][4]);
+                b_i1 = s_bias[type][8 + (r & 3)];
+                have_type = type;
+            }
 
             int t[16];
             v4i hi, lo;
@@ -705,7 +719,7 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
             if (MODE == MODE_IDCT) {
 #pragma unroll
                 for (int g = 0; g < 16; g++)       // coef[k = 8w + 4h + e][i = r] of TU (a = 2w + h, b = r/4)
-                    t[g] = (int)lv[((2 * (g >> 2) + h) * 8 + (r >> 2)) * 16 + (g & 3) * 4 + (r & 3)];
+                    t[g] = (int)lv[lv_at(2 * (g >> 2) + h, r >> 2) + (g & 3) * 4 + (r & 3)];
             } else {
             // ---- F1 ----
             v4i s_frag4, p_frag4;
@@ -743,7 +757,7 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
                     for (int e4 = 0; e4 < 4; e4++) {
                         const int g = 4 * w + e4;
                         const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
-                        if (mine) lv[((2 * w + h) * 8 + (r >> 2)) * 16 + e4 * 4 + (r & 3)] = (int16_t)c;
+                        if (mine) lv[lv_at(2 * w + h, r >> 2) + e4 * 4 + (r & 3)] = (int16_t)c;
                     }
                     continue;
                 }
@@ -759,14 +773,14 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
                     const int c = ((acc_hi[g] << 8) + acc_lo[g]) >> (LG + 6);
                     const int level = (__mul24(c, q) + (c < 0 ? qadd_neg : qadd_pos)) >> qbits;
                     local += abs(level);
-                    if (mine) lv[(a * 8 + b) * 16 + e4 * 4 + (r & 3)] = (int16_t)level;
+                    if (mine) lv[lv_at(a, b) + e4 * 4 + (r & 3)] = (int16_t)level;
                     t[g] = (__mul24(level, dscale) + (1 << (LG - 2))) >> (LG - 1);
                 }
                 local += __builtin_amdgcn_update_dpp(0, local, 0x111, 0xf, 0xf, true);   // row_shr:1
                 local += __builtin_amdgcn_update_dpp(0, local, 0x112, 0xf, 0xf, true);   // row_shr:2
                 if ((r & 3) == 3 && mine) sm[b * 8 + a] = (uint32_t)local;
             }
-            if (MODE == MODE_SUBDCT) continue;
+            if (MODE == MODE_SUBDCT) return;
             }   // MODE != MODE_IDCT
 
             // ---- I1 ----
@@ -814,6 +828,11 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
                 if (MIXED) mine = (int)((p.flags[tu_first + (4 * h + w) * 8 + (r >> 2)] >> 1) & 1) == type;   // p.flags != null when mixed
                 if (mine) *reinterpret_cast<unsigned *>(p.rec + base + pix_off(r, 16 * h + 4 * w)) = o[w];
             }
+        };
+        if (all_dct || all_dst) {
+            pass(std::false_type{}, all_dst ? 1 : 0);
+        } else {
+            for (int type = 0; type < 2; type++) pass(std::true_type{}, type);
         }
         claim();
 
@@ -822,12 +841,31 @@ __global__ void __launch_bounds__(256) tu_mfma4_kernel(const TuParams p)
 #pragma unroll
         for (int c = lane; c < 128; c += 64) {
             const int tu = c >> 1, a = tu & 7, b = tu >> 3;
-            const v4i d = *reinterpret_cast<const v4i *>(lv + (a * 8 + b) * 16 + (c & 1) * 8);
+            const v4i d = *reinterpret_cast<const v4i *>(lv + lv_at(a, b) + (c & 1) * 8);
             *reinterpret_cast<v4i *>(p.out16 + base + c * 8) = d;
         }
         }
         if (MODE == MODE_CHAIN) p.sum[tu_first + lane] = sm[lane];
     }
+}
+
+// Workgroups of a kernel that the device holds at the same time (the wavefronts loop over tiles, so a grid of exactly
+// that size has no second, partly filled wave of workgroups): register use decides it, so it is asked per kernel.
+template <auto Kernel>
+int resident_blocks()
+{
+    static std::atomic<int> cached{ 0 };
+    int v = cached.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, Kernel, 256, 0) != hipSuccess || cus <= 0 || per_cu <= 0)
+            v = 2048;
+        else
+            v = cus * per_cu;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v;
 }
 
 template <int MODE>
@@ -836,7 +874,8 @@ int launch_mfma4(const TuParams &p, hipStream_t st)
     constexpr int S = 64;
     const int tiles = p.count / S;
     if (tiles > 0) {
-        const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;
+        const int cap = resident_blocks<tu_mfma4_kernel<MODE>>();
+        const int blocks = (tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap;
         hipLaunchKernelGGL((tu_mfma4_kernel<MODE>), dim3(blocks), dim3(256), 0, st, p);
         XMI_HIP(hipGetLastError());
     }
@@ -858,7 +897,8 @@ int launch_mfma(const TuParams &p, hipStream_t st)
     constexpr int S = (32 / N) * (32 / N);
     const int tiles = p.count / S;
     if (tiles > 0) {
-        const int blocks = (tiles + 3) / 4 < 2048 ? (tiles + 3) / 4 : 2048;   // 8 workgroups per CU; wavefronts loop over tiles
+        const int cap = resident_blocks<tu_mfma_kernel<N, MODE>>();
+        const int blocks = (tiles + 3) / 4 < cap ? (tiles + 3) / 4 : cap;   // wavefronts loop over tiles
         hipLaunchKernelGGL((tu_mfma_kernel<N, MODE>), dim3(blocks), dim3(256), 0, st, p);
         XMI_HIP(hipGetLastError());
     }
