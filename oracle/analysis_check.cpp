@@ -142,10 +142,17 @@ public:
         words.assign(n, 0);
         uint8_t *b = bytes.data();
         int16_t *w = words.data();
-        for (int i = 0; i < bt.npu; i++) one_intra(*bt.pu[i], b, w);
+        for (int i = 0; i < bt.npu; i++)
+            if (!bt.pu[i]->after_kind) one_intra(*bt.pu[i], b, w);
         for (int i = 0; i < bt.nchroma; i++) one_intra_chroma(*bt.chroma[i], b, w);
-        for (int i = 0; i < bt.nquad; i++) one_quad(*bt.quad[i], b, w);
+        for (int i = 0; i < bt.nquad; i++)
+            if (!bt.quad[i]->after_kind) one_quad(*bt.quad[i], b, w);
         for (int i = 0; i < bt.ncquad; i++) one_chroma_quad(*bt.cquad[i], b, w);
+        // requests that stand after a block of this call: that block's results are there now
+        for (int i = 0; i < bt.npu; i++)
+            if (bt.pu[i]->after_kind) take_left_block(*bt.pu[i]), one_intra(*bt.pu[i], b, w);
+        for (int i = 0; i < bt.nquad; i++)
+            if (bt.quad[i]->after_kind) take_left_block(*bt.quad[i]), one_quad(*bt.quad[i], b, w);
         return 0;
     }
 

@@ -600,7 +600,11 @@ __global__ void __launch_bounds__(256, XMI_ROUND_WAVES) analysis_round_kernel(co
 // ---- I pictures: one workgroup per PU request ----
 struct IntraJob {
     int32_t x0, y0, size;
-    uint8_t valids, strong, mpm[3], parts, reserved[2];      // parts: workgroups that share the PU's mode search
+    uint8_t valids, strong, mpm[3], parts;       // parts: workgroups that share the PU's mode search
+    // An 8x8 PU may leave its right column and mode for requests of the same round that stand for the block to its right
+    // (publish: hand-over slot + 1), or be such a request (after: slot + 1 of the block to its left; top_mode: the mode above,
+    // from which and the left block's mode the most probable modes follow). 0: neither.
+    uint8_t publish, after, top_mode, reserved[3];
     int32_t qp;
     double sqrt_lambda;
     uint8_t ref[136];
@@ -624,7 +628,7 @@ struct IntraChromaHead {
 // four 4x4 PUs of an 8x8 block back to back (luma), and the same for an 8x8 area of the chroma planes
 struct IntraQuadJob {
     int32_t x0, y0;
-    uint8_t valids[4], left_mode[2], top_mode[2], strong, reserved[3];
+    uint8_t valids[4], left_mode[2], top_mode[2], strong, publish, after, reserved;      // publish / after: as in IntraJob
     int32_t qp;
     double sqrt_lambda;
     uint8_t ref[40];
@@ -664,6 +668,10 @@ struct IntraRoundParams {
     const IntraQuadJob *qjobs;
     const IntraChromaQuadJob *cqjobs;
     int npu, nchroma, nquad, ncquad;
+    // Requests that stand after a block of the same round come last - their workgroups start after the ones they wait for -:
+    // PU workgroups npu_first .. npu_first + npu_after - 1 of `groups`, 4x4 groups nquad .. nquad + nquad_after - 1 of `qjobs`.
+    int npu_first, npu_after, nquad_after;
+    unsigned *handoff;            // [slot][4], device memory: the round's number, right column (rows 0..3, 4..7), modes
     const uint8_t *src[3];
     int width;
     uint8_t *out;
@@ -673,6 +681,8 @@ struct IntraRoundParams {
     unsigned seq;
 };
 struct __align__(16) IntraLds {
+    unsigned hand[4];                 // what the block to the left handed over
+    int hand_ok;
     RoundLds r;                       // transform operands; r.win holds the source copies of the search and the prediction
     uint8_t ref[4][272];              // per wavefront: padded samples, then the smoothed set at +136
     double best_cost[4];
@@ -695,6 +705,60 @@ __device__ __forceinline__ uint8_t quad_sample(const uint8_t *outer, const uint8
     if (yy < 0) return outer[16 + 1 + xx];
     if (xx < 0) return outer[15 - yy];
     return xx < 8 && yy < 8 ? area[yy * 8 + xx] : (uint8_t)0x80;
+}
+
+// A decided 8x8 block (area: its reconstruction in LDS, rows 8 apart) leaves its right column and the modes of its right-hand
+// units for the workgroups of the round that evaluate the block to its right. They run on other CUs, maybe of another XCD:
+// everything goes through device-scope atomics, the round's number last.
+__device__ __forceinline__ void publish_block(const IntraRoundParams &p, int slot, const uint8_t *area, int mode_top, int mode_bottom)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned lo = 0, hi = 0;
+        for (int r = 0; r < 4; r++) lo |= (unsigned)area[r * 8 + 7] << (8 * r), hi |= (unsigned)area[(r + 4) * 8 + 7] << (8 * r);
+        unsigned *h = p.handoff + 4 * slot;
+        __hip_atomic_store(h + 1, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h + 2, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(h + 3, (unsigned)mode_top | ((unsigned)mode_bottom << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_store(h, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// The other side: wait for the block to the left (its workgroup was started before this one; the wait is bounded all the same,
+// and a request that could not wait says so in its result instead of answering). All threads return the same value.
+__device__ __forceinline__ bool await_block(const IntraRoundParams &p, IntraLds &L, int slot)
+{
+    if (threadIdx.x == 0) {
+        const unsigned *h = p.handoff + 4 * slot;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();      // 100 MHz
+        int ok = 0;
+        for (;;) {
+            if (__hip_atomic_load(h, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == p.seq) {
+                ok = 1;
+                break;
+            }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000ull) break;      // half a millisecond
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (ok)
+            for (int k = 1; k < 4; k++) L.hand[k] = __hip_atomic_load(h + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.hand_ok = ok;
+    }
+    __syncthreads();
+    return L.hand_ok != 0;
+}
+
+// most probable modes from the modes to the left and above (src/encode.cpp:3980-4003)
+__device__ __forceinline__ void most_probable_modes(int left, int top, uint8_t *mpm)
+{
+    if (left == top) {
+        if (left > 1) mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)(((left + 29) % 32) + 2), mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+        else mpm[0] = 0, mpm[1] = 1, mpm[2] = 26;
+    } else {
+        mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)top;
+        mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+    }
 }
 
 // one luma PU (src/encode.cpp:4005-4115): 35-mode search on the four wavefronts, prediction of the winner, transform chain
@@ -753,11 +817,14 @@ __device__ void intra_pu(const IntraRoundParams &p, IntraLds &L, const IntraJob 
     __syncthreads();
     uint32_t sum, ssd;
     // (the source block is in LDS since the search: wavefront 0's copy, rows N apart - no second trip to memory for it)
-    chain_unit<N, true, N == 4>(L.r, L.r.win, N, pr, N, j.qp, reinterpret_cast<int16_t *>(p.out + j.out_level), p.out + j.out_rec, nullptr, N, sum, ssd);
+    const bool hands_on = N == 8 && j.publish != 0;
+    chain_unit<N, true, N == 4>(L.r, L.r.win, N, pr, N, j.qp, reinterpret_cast<int16_t *>(p.out + j.out_level), p.out + j.out_rec, nullptr, N, sum, ssd,
+                                hands_on ? L.area[0] : nullptr, 8);
     if (tid == 0) {
         IntraHead *h = reinterpret_cast<IntraHead *>(p.out + j.out_head);
         h->best_mode = mode, h->sum = sum, h->ssd = ssd;
     }
+    if (hands_on) publish_block(p, j.publish - 1, L.area[0], mode, mode);
 }
 
 // chroma of one PU (src/encode.cpp:4306-4411): candidate search on one wavefront, then prediction and chain of U and V
@@ -1016,6 +1083,7 @@ __device__ void intra_quad(const IntraRoundParams &p, IntraLds &L, const IntraQu
         }
         // (the other wavefronts wait at the next PU's first barrier until wavefront 0 has its neighbours ready)
     }
+    if (j.publish) publish_block(p, j.publish - 1, L.area[0], L.qmode[1], L.qmode[3]);
 }
 
 // IntraChromaQuadEval on one wavefront
@@ -1100,7 +1168,38 @@ __global__ void __launch_bounds__(256) intra_round_kernel(const IntraRoundParams
     __shared__ __align__(16) uint32_t s_job[(sizeof(IntraJob) > sizeof(IntraChromaJob) ? sizeof(IntraJob) : sizeof(IntraChromaJob)) / 4 + 4];
     static_assert(sizeof(IntraQuadJob) <= sizeof(IntraJob) && sizeof(IntraChromaQuadJob) <= sizeof(IntraChromaJob), "s_job holds every job type");
     const int b = blockIdx.x;
-    if (b < p.npu) {
+    const int first_after = p.npu + p.nchroma + p.nquad + p.ncquad;
+    if (b >= first_after) {
+        // a request for the 8x8 block to the right of a block of this round: that block's right column and modes go into the
+        // record, then it is a request like any other
+        const int k = b - first_after;
+        if (k < p.npu_after) {
+            const IntraGroup g = p.groups[p.npu_first + k];
+            const IntraJob &j = fetch_job(p.jobs + g.job, s_job);
+            XMI_JOB_TYPE(1);
+            IntraJob &jw = *reinterpret_cast<IntraJob *>(s_job);
+            if (j.size == 8 && j.after && await_block(p, L, j.after - 1)) {
+                if (threadIdx.x < 8) jw.ref[15 - threadIdx.x] = (uint8_t)(L.hand[1 + (threadIdx.x >> 2)] >> (8 * (threadIdx.x & 3)));
+                if (threadIdx.x == 8) most_probable_modes((int)(L.hand[3] & 255u), jw.top_mode, jw.mpm);
+                __syncthreads();
+                intra_pu<8>(p, L, j, g.job, g.part);
+            } else if (threadIdx.x == 0) {
+                reinterpret_cast<IntraHead *>(p.out + j.out_head)->best_mode = -1;
+            }
+        } else if (k - p.npu_after < p.nquad_after) {
+            XMI_JOB_TYPE(7);
+            const IntraQuadJob &j = fetch_job(p.qjobs + p.nquad + (k - p.npu_after), s_job);
+            IntraQuadJob &jw = *reinterpret_cast<IntraQuadJob *>(s_job);
+            if (j.after && await_block(p, L, j.after - 1)) {
+                if (threadIdx.x < 8) jw.ref[15 - threadIdx.x] = (uint8_t)(L.hand[1 + (threadIdx.x >> 2)] >> (8 * (threadIdx.x & 3)));
+                if (threadIdx.x == 8) jw.left_mode[0] = (uint8_t)(L.hand[3] & 255u), jw.left_mode[1] = (uint8_t)((L.hand[3] >> 8) & 255u);
+                __syncthreads();
+                intra_quad(p, L, j);
+            } else if (threadIdx.x == 0) {
+                reinterpret_cast<IntraQuadHead *>(p.out + j.out_head)->best_mode[0] = -1;
+            }
+        }
+    } else if (b < p.npu) {
         const IntraGroup g = p.groups[b];
         const IntraJob &j = fetch_job(p.jobs + g.job, s_job);
         XMI_JOB_TYPE(j.size == 4 ? 0 : j.size == 8 ? 1 : j.size == 16 ? 2 : 3);
@@ -1159,7 +1258,8 @@ public:
         unsigned issued_early = 0;                         // P rounds: workgroups whose answers are read first
         bool late_pending = false;                         // the last round may still have workgroups under way
         std::vector<ChromaPlace> place;
-        std::vector<int> order;
+        std::vector<int> order, qorder;
+        std::vector<const void *> slot_owner;      // intra rounds: the blocks that hand their right column on, by slot
         // where a round trip's time goes, nanoseconds (xmi_analysis_counters): table set-up, launch call, wait, result read-back
         uint64_t t_prepare = 0, t_launch = 0, t_wait = 0, t_collect = 0, rounds = 0;
         char err[256] = "";
@@ -1343,7 +1443,7 @@ public:
         max_chroma = lane_rows * 64 * 2;      // per CTU at most 64 CUs of 8x8, two planes
         off_groups = align_up(std::max(sizeof(LumaJob), sizeof(IntraJob)) * max_cu);
         off_cjobs = off_groups + align_up(sizeof(IntraGroup) * max_cu * 8);
-        jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, (sizeof(IntraChromaJob) + sizeof(IntraQuadJob) + sizeof(IntraChromaQuadJob)) * (size_t)lane_rows));
+        jobs_bytes = off_cjobs + align_up(std::max(sizeof(ChromaJob) * max_chroma, (sizeof(IntraChromaJob) + 3 * sizeof(IntraQuadJob) + sizeof(IntraChromaQuadJob)) * (size_t)lane_rows));
         // per CU: head, prediction, two reconstructions, two level blocks; per CTU of chroma: for each of up to 64 CUs the
         // sums and four blocks, each rounded up to the 256-byte grid of the area
         size_t cu_bytes = 0;
@@ -1359,8 +1459,10 @@ public:
             LaneRes &l = lane[i];
             XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_counter), 256));
             intra_scratch = align_up(sizeof(IntraPartial) * kIntraParts * max_cu);
-            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_intra), intra_scratch + align_up(4 * (size_t)max_cu)));
-            XMI_HIP(hipMemsetAsync(l.d_intra, 0, intra_scratch + align_up(4 * (size_t)max_cu), st));
+            // partial winners and arrival counters of the PUs that several workgroups search, then the hand-over slots
+            const size_t intra_bytes = intra_scratch + align_up(4 * (size_t)max_cu) + align_up(16 * 4 * (size_t)lane_rows);
+            XMI_HIP(hipMalloc(reinterpret_cast<void **>(&l.d_intra), intra_bytes));
+            XMI_HIP(hipMemsetAsync(l.d_intra, 0, intra_bytes, st));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_jobs), jobs_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_out), out_bytes, flags));
             XMI_HIP(hipHostMalloc(reinterpret_cast<void **>(&l.h_flag), 256, flags));
@@ -1583,7 +1685,7 @@ private:
         IntraEval *const *pu = bt.pu;
         IntraChromaEval *const *ch = bt.chroma;
         const int npu = bt.npu, nch = bt.nchroma, nq = bt.nquad, ncq = bt.ncquad;
-        XMI_ARG(npu <= max_cu && nch <= lane_rows && nq <= lane_rows && ncq <= lane_rows, "analysis: intra requests (%d, %d, %d, %d) exceed the round capacity", npu, nch, nq,
+        XMI_ARG(npu <= max_cu && nch <= lane_rows && nq <= 3 * lane_rows && ncq <= lane_rows, "analysis: intra requests (%d, %d, %d, %d) exceed the round capacity", npu, nch, nq,
                 ncq);
         const int settled = settle(R);
         if (settled != XMI_OK) return settled;
@@ -1593,18 +1695,65 @@ private:
         int ngroups_pu = 0;
         IntraChromaJob *cjobs = reinterpret_cast<IntraChromaJob *>(R.h_jobs + off_cjobs);
         IntraQuadJob *qjobs = reinterpret_cast<IntraQuadJob *>(cjobs + lane_rows);
-        IntraChromaQuadJob *cqjobs = reinterpret_cast<IntraChromaQuadJob *>(qjobs + lane_rows);
+        IntraChromaQuadJob *cqjobs = reinterpret_cast<IntraChromaQuadJob *>(qjobs + 3 * lane_rows);
+        // job k serves request order[k]: the requests that stand after a block of this round come last, and the block they
+        // stand after gets a hand-over slot
+        std::vector<int> &order = R.order, &qorder = R.qorder;
+        std::vector<const void *> &owner = R.slot_owner;
+        order.clear(), qorder.clear(), owner.clear();
+        for (int i = 0; i < npu; i++)
+            if (!pu[i]->after_kind) order.push_back(i);
+        const int npu_plain = (int)order.size();
+        for (int i = 0; i < npu; i++)
+            if (pu[i]->after_kind) order.push_back(i);
+        for (int i = 0; i < nq; i++)
+            if (!bt.quad[i]->after_kind) qorder.push_back(i);
+        const int nq_plain = (int)qorder.size();
+        for (int i = 0; i < nq; i++)
+            if (bt.quad[i]->after_kind) qorder.push_back(i);
+        auto slot_of = [&](uint8_t kind, const IntraEval *a, const IntraQuadEval *b) -> int {
+            const void *who = kind == 1 ? static_cast<const void *>(a) : static_cast<const void *>(b);
+            for (size_t k = 0; k < owner.size(); k++)
+                if (owner[k] == who) return (int)k;
+            owner.push_back(who);
+            return (int)owner.size() - 1;
+        };
+        auto published = [&](const void *who) -> uint8_t {
+            for (size_t k = 0; k < owner.size(); k++)
+                if (owner[k] == who) return (uint8_t)(k + 1);
+            return 0;
+        };
+        for (int i = npu_plain; i < npu; i++) {
+            const IntraEval &q = *pu[order[i]];
+            XMI_ARG((q.after_kind == 1 && q.after_pu) || (q.after_kind == 2 && q.after_quad), "analysis: intra PU after no block");
+            (void)slot_of(q.after_kind, q.after_pu, q.after_quad);
+        }
+        for (int i = nq_plain; i < nq; i++) {
+            const IntraQuadEval &q = *bt.quad[qorder[i]];
+            XMI_ARG((q.after_kind == 1 && q.after_pu) || (q.after_kind == 2 && q.after_quad), "analysis: intra 4x4 group after no block");
+            (void)slot_of(q.after_kind, q.after_pu, q.after_quad);
+        }
+        XMI_ARG((int)owner.size() <= 4 * lane_rows, "analysis: %zu hand-over slots exceed the round capacity", owner.size());
+        size_t n_publishers = 0;
         size_t out = 0;
+        int npu_first = 0;
         for (int i = 0; i < npu; i++) {
-            const IntraEval &q = *pu[i];
+            const IntraEval &q = *pu[order[i]];
             IntraJob &j = jobs[i];
+            if (i == npu_plain) npu_first = ngroups_pu;
             XMI_ARG(q.size == 4 || q.size == 8 || q.size == 16 || q.size == 32, "analysis: intra PU size %d", q.size);
             XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 4 == 0 && q.y0 % 4 == 0 && q.x0 + q.size <= w && q.y0 + q.size <= h, "analysis: intra PU (%d,%d) size %d outside the picture",
                     q.x0, q.y0, q.size);
-            XMI_ARG(q.qp >= 0 && q.qp <= 51 && q.mpm[0] < 35 && q.mpm[1] < 35 && q.mpm[2] < 35, "analysis: intra PU parameters out of range");
+            XMI_ARG(q.qp >= 0 && q.qp <= 51 && q.mpm[0] < 35 && q.mpm[1] < 35 && q.mpm[2] < 35 && q.top_mode < 35, "analysis: intra PU parameters out of range");
+            XMI_ARG(!q.after_kind || q.size == 8, "analysis: only an 8x8 PU stands after a block");
             j.x0 = q.x0, j.y0 = q.y0, j.size = q.size;
             j.valids = q.valids & 0x1f, j.strong = q.strong;
             j.mpm[0] = q.mpm[0], j.mpm[1] = q.mpm[1], j.mpm[2] = q.mpm[2];
+            j.top_mode = q.top_mode;
+            j.publish = q.after_kind || q.size != 8 ? 0 : published(&q);
+            j.after = q.after_kind ? (uint8_t)(slot_of(q.after_kind, q.after_pu, q.after_quad) + 1) : 0;
+            n_publishers += j.publish != 0;
+            j.reserved[0] = j.reserved[1] = j.reserved[2] = 0;
             j.qp = q.qp, j.sqrt_lambda = q.sqrt_lambda;
             j.parts = q.size >= 16 ? kIntraParts : 1;      // the 35-mode search of a large PU is spread over several workgroups
             for (int g = 0; g < j.parts; g++) groups[ngroups_pu++] = { (uint16_t)i, (uint8_t)g, 0 };
@@ -1614,6 +1763,8 @@ private:
             j.out_rec = (uint32_t)out, out = align_up(out + px);
             j.out_level = (uint32_t)out, out = align_up(out + 2 * px);
         }
+        if (npu_plain == npu) npu_first = ngroups_pu;
+        const int npu_after_groups = ngroups_pu - npu_first;
         for (int i = 0; i < nch; i++) {
             const IntraChromaEval &c = *ch[i];
             IntraChromaJob &j = cjobs[i];
@@ -1630,7 +1781,7 @@ private:
             for (int k = 0; k < 2; k++) j.out_level[k] = (uint32_t)out, out = align_up(out + 2 * px);
         }
         for (int i = 0; i < nq; i++) {
-            const IntraQuadEval &q = *bt.quad[i];
+            const IntraQuadEval &q = *bt.quad[qorder[i]];
             IntraQuadJob &j = qjobs[i];
             XMI_ARG(q.x0 >= 0 && q.y0 >= 0 && q.x0 % 8 == 0 && q.y0 % 8 == 0 && q.x0 + 8 <= w && q.y0 + 8 <= h && q.qp >= 0 && q.qp <= 51,
                     "analysis: intra 4x4 group (%d,%d) outside the picture, or bad parameters", q.x0, q.y0);
@@ -1640,12 +1791,18 @@ private:
                 XMI_ARG(q.left_mode[k] < 35 && q.top_mode[k] < 35, "analysis: intra 4x4 group: neighbour mode out of range");
                 j.left_mode[k] = q.left_mode[k], j.top_mode[k] = q.top_mode[k];
             }
+            j.publish = q.after_kind ? 0 : published(&q);
+            j.after = q.after_kind ? (uint8_t)(slot_of(q.after_kind, q.after_pu, q.after_quad) + 1) : 0;
+            n_publishers += j.publish != 0;
+            j.reserved = 0;
             j.strong = q.strong, j.qp = q.qp, j.sqrt_lambda = q.sqrt_lambda;
             std::memcpy(j.ref, q.ref, 33);
             j.out_head = (uint32_t)out, out = align_up(out + sizeof(IntraQuadHead));
             j.out_rec = (uint32_t)out, out = align_up(out + 64);
             j.out_level = (uint32_t)out, out = align_up(out + 128);
         }
+        // (a block somebody stands after is a request of this round: otherwise its workgroups would wait for nothing)
+        XMI_ARG(n_publishers == owner.size(), "analysis: an intra request stands after a block that is not part of the round");
         for (int i = 0; i < ncq; i++) {
             const IntraChromaQuadEval &c = *bt.cquad[i];
             IntraChromaQuadJob &j = cqjobs[i];
@@ -1669,8 +1826,10 @@ private:
         p.arrived = reinterpret_cast<unsigned *>(R.d_intra + intra_scratch);
         p.cjobs = reinterpret_cast<const IntraChromaJob *>(R.g_jobs + off_cjobs);
         p.qjobs = reinterpret_cast<const IntraQuadJob *>(p.cjobs + lane_rows);
-        p.cqjobs = reinterpret_cast<const IntraChromaQuadJob *>(p.qjobs + lane_rows);
-        p.npu = ngroups_pu, p.nchroma = nch, p.nquad = nq, p.ncquad = ncq;
+        p.cqjobs = reinterpret_cast<const IntraChromaQuadJob *>(p.qjobs + 3 * lane_rows);
+        p.npu = npu_first, p.nchroma = nch, p.nquad = nq_plain, p.ncquad = ncq;
+        p.npu_first = npu_first, p.npu_after = npu_after_groups, p.nquad_after = nq - nq_plain;
+        p.handoff = reinterpret_cast<unsigned *>(R.d_intra + intra_scratch + align_up(4 * (size_t)max_cu));
         for (int k = 0; k < 3; k++) p.src[k] = d_src[k];
         p.width = w;
         p.out = R.g_out;
@@ -1687,7 +1846,7 @@ private:
         if (rc != XMI_OK) return rc;
         const auto t3 = std::chrono::steady_clock::now();
         for (int i = 0; i < npu; i++) {
-            IntraEval &q = *pu[i];
+            IntraEval &q = *pu[order[i]];
             const IntraJob &j = jobs[i];
             const IntraHead &hd = *reinterpret_cast<const IntraHead *>(R.h_out + j.out_head);
             q.best_mode = hd.best_mode, q.sum = hd.sum, q.ssd = hd.ssd;
@@ -1702,12 +1861,15 @@ private:
             c.level_u = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[0]), c.level_v = reinterpret_cast<const int16_t *>(R.h_out + j.out_level[1]);
         }
         for (int i = 0; i < nq; i++) {
-            IntraQuadEval &q = *bt.quad[i];
+            IntraQuadEval &q = *bt.quad[qorder[i]];
             const IntraQuadJob &j = qjobs[i];
             const IntraQuadHead &hd = *reinterpret_cast<const IntraQuadHead *>(R.h_out + j.out_head);
             for (int k = 0; k < 4; k++) q.best_mode[k] = hd.best_mode[k], q.sum[k] = hd.sum[k], q.ssd[k] = hd.ssd[k];
             q.rec = R.h_out + j.out_rec, q.level = reinterpret_cast<const int16_t *>(R.h_out + j.out_level);
         }
+        // the requests that stood after a block say what they were evaluated with, as the kernel put it in place
+        for (int i = npu_plain; i < npu; i++) take_left_block(*pu[order[i]]);
+        for (int i = nq_plain; i < nq; i++) take_left_block(*bt.quad[qorder[i]]);
         for (int i = 0; i < ncq; i++) {
             IntraChromaQuadEval &c = *bt.cquad[i];
             const IntraChromaQuadJob &j = cqjobs[i];

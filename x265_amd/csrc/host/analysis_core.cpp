@@ -15,6 +15,7 @@
 #include <deque>
 #include <functional>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <fstream>
@@ -267,6 +268,17 @@ struct Row {
     uint8_t quad_rec[16];           // the PU of them that is being decided, packed
     int16_t quad_level[16];
     IntraChromaQuadEval cquad;
+    // The 8x8 block to the right of the one a request ends at is asked for in the same call, twice: as it will be when the
+    // block to its left is kept as one 8x8 PU ([0]) and as four 4x4 PUs ([1]); the evaluator takes that block's right column
+    // and modes from the call's own results (IntraEval::after_kind). Which premise holds is this row's cost comparison; the
+    // answers wait until the block comes up, and its round trip is saved.
+    IntraEval pair_in[2];
+    IntraQuadEval pair_quad[2];
+    bool pair_ok = false, req_pair = false;
+    uint64_t pairs_taken = 0;
+    int pair_x = 0, pair_y = 0;
+    void fill_pair(int px, int py);
+    bool take_pair(IntraEval &q, int px, int py);
     // I pictures: the chroma PUs of a decided CTU are a chain of requests of their own - nothing in it depends on a cost, and
     // nothing the luma decisions of the next CTU read depends on it (the estimation contexts pass through luma syntax only) -,
     // so its links travel with the luma requests of the CTU to the right. What the chain reads of its CTU is kept here.
@@ -347,8 +359,8 @@ struct Row {
     void run();
     void evaluate_cus(CuEval *const *list, int n);
     void evaluate_chroma();
-    void evaluate_intra(IntraEval *const *list, int n, bool with_quad);
-    void fill_quad(int px, int py);
+    void evaluate_intra(IntraEval *const *list, int n, bool with_quad, bool with_pair = false);
+    void fill_quad(IntraQuadEval &q, int px, int py);
     void post_and_wait();
     static void fiber_main(unsigned lo, unsigned hi);
     void make_fiber();
@@ -378,6 +390,7 @@ struct Shared {
     int grace_us = 6;               // how long a polling coordinator waits for the rows still busy before it goes without them
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
     bool defer_chroma = true;       // a CTU's chroma requests travel with the next CTU's first luma request
+    bool pairs = true;              // I pictures: an 8x8 block's request takes the block to its right along (Row::fill_pair)
     std::deque<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row (under the mutex)
     std::vector<int> done_luma;     // I pictures: CTUs whose luma is decided (their chroma may still be under way)
@@ -1045,24 +1058,23 @@ void Row::evaluate_chroma()
     req_chroma = false;
 }
 
-void Row::evaluate_intra(IntraEval *const *list, int n, bool with_quad)
+void Row::evaluate_intra(IntraEval *const *list, int n, bool with_quad, bool with_pair)
 {
     for (int i = 0; i < n; i++) req_in[i] = list[i];
     n_req_in = n, n_req_cu = 0;
     req_chroma = req_ichroma = req_cquad = false;
-    req_quad = with_quad;
+    req_quad = with_quad, req_pair = with_pair;
     const bool link = ic_ctu >= 0 && chroma_link_fill();
     post_and_wait();
     n_req_in = 0;
-    req_quad = false;
+    req_quad = req_pair = false;
     if (link) chroma_link_take();
 }
 
 // request for the four 4x4 PUs of the 8x8 block at (px, py) of the CTU, nothing of which is decided yet
-void Row::fill_quad(int px, int py)
+void Row::fill_quad(IntraQuadEval &q, int px, int py)
 {
     const int r4 = py / 4, c4 = px / 4;
-    IntraQuadEval &q = quad;
     q.x0 = ctu_x * 64 + px, q.y0 = y * 64 + py;
     for (int i = 0; i < 16; i++) q.ref[i] = (uint8_t)sample_y(py + 15 - i, px - 1);
     for (int i = 0; i <= 16; i++) q.ref[16 + i] = (uint8_t)sample_y(py - 1, px - 1 + i);
@@ -1077,6 +1089,53 @@ void Row::fill_quad(int px, int py)
     q.strong = (uint8_t)strong;
     q.sqrt_lambda = std::sqrt(lambda);
     q.qp = qp;
+    q.after_kind = 0, q.after_pu = nullptr, q.after_quad = nullptr;
+}
+
+// Requests for the 8x8 block to the right of the block at (px, py), which this call decides: both premises. The block's units
+// count as available; what the premises differ in - the left column and the modes to the left - comes from the evaluator.
+void Row::fill_pair(int px, int py)
+{
+    const int r4 = py / 4, c4 = px / 4;
+    uint8_t keep[4];
+    for (int k = 0; k < 4; k++) keep[k] = M(r4 + (k >> 1), c4 + (k & 1)), M(r4 + (k >> 1), c4 + (k & 1)) = 1;
+    for (int h = 0; h < 2; h++) {
+        fill_intra(pair_in[h], px + 8, py, 8);
+        fill_quad(pair_quad[h], px + 8, py);
+        pair_in[h].after_kind = pair_quad[h].after_kind = (uint8_t)(h + 1);
+        pair_in[h].after_pu = pair_quad[h].after_pu = &in_spec[1];
+        pair_in[h].after_quad = pair_quad[h].after_quad = &quad;
+    }
+    for (int k = 0; k < 4; k++) M(r4 + (k >> 1), c4 + (k & 1)) = keep[k];
+    pair_ok = true;
+    pair_x = ctu_x * 64 + px + 8, pair_y = y * 64 + py;
+}
+
+// The block at (px, py) was asked for with the block to its left: the answers of the premise that came true, if the request
+// they answer is the one the block makes now. q: the block's own request, filled in.
+bool Row::take_pair(IntraEval &q, int px, int py)
+{
+    pair_ok = false;
+    const int r4 = py / 4, c4 = px / 4;
+    const int h = (I1(r4, c4 - 1) >> kOffSize) == 0 ? 1 : 0;      // the block to the left was kept as four 4x4 PUs, or as one PU
+    const IntraEval &a = pair_in[h];
+    const IntraQuadEval &b = pair_quad[h];
+    if (a.best_mode < 0 || b.best_mode[0] < 0) return false;      // the evaluator could not wait for the block to the left
+    fill_intra(q, px, py, 8);
+    IntraQuadEval now;
+    fill_quad(now, px, py);
+    const bool same = q.valids == a.valids && std::memcmp(q.ref, a.ref, 33) == 0 && std::memcmp(q.mpm, a.mpm, 3) == 0 && std::memcmp(now.ref, b.ref, 33) == 0 &&
+                      std::memcmp(now.valids, b.valids, 4) == 0 && std::memcmp(now.left_mode, b.left_mode, 2) == 0 && std::memcmp(now.top_mode, b.top_mode, 2) == 0;
+    if (!same) {      // (cannot happen: the premise is what was decided)
+        sh->error = -3;
+        throw Abort();
+    }
+    q.best_mode = a.best_mode, q.ssd = a.ssd, q.sum = a.sum, q.rec = a.rec, q.level = a.level;
+    pairs_taken++;
+    quad = b;
+    quad.after_kind = 0;
+    quad_ok = true;
+    return true;
 }
 
 inline int interleave4(int v) { return (v & 1) | ((v >> 1) & 2) | ((v >> 2) & 4) | ((v >> 3) & 8); }      // getInterleaveBits (src/encode.cpp:4220)
@@ -1091,13 +1150,9 @@ void Row::fill_intra(IntraEval &q, int px, int py, int size)
     q.valids = (uint8_t)((lb ? 1 : 0) | (l ? 2 : 0) | (lt ? 4 : 0) | (t ? 8 : 0) | (tr ? 16 : 0));
     q.strong = (uint8_t)strong;
     const int left = l ? M(r4, c4 - 1) : 1, top = (t && py) ? M(r4 - 1, c4) : 1;      // DC where there is no neighbour, and above the CTU
-    if (left == top) {
-        if (left > 1) q.mpm[0] = (uint8_t)left, q.mpm[1] = (uint8_t)(((left + 29) % 32) + 2), q.mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
-        else q.mpm[0] = 0, q.mpm[1] = 1, q.mpm[2] = 26;
-    } else {
-        q.mpm[0] = (uint8_t)left, q.mpm[1] = (uint8_t)top;
-        q.mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
-    }
+    q.left_mode = (uint8_t)left, q.top_mode = (uint8_t)top;
+    most_probable_modes(left, top, q.mpm);
+    q.after_kind = 0, q.after_pu = nullptr, q.after_quad = nullptr;
     for (int i = 0; i < 2 * size; i++) q.ref[i] = (uint8_t)sample_y(py + 2 * size - 1 - i, px - 1);
     for (int i = 0; i <= 2 * size; i++) q.ref[2 * size + i] = (uint8_t)sample_y(py - 1, px - 1 + i);
     q.sqrt_lambda = std::sqrt(lambda);
@@ -1129,15 +1184,17 @@ double Row::decide_intra(int px, int py, int size, int depth)
             block_in(quad_level, 8, quad.level + (k >> 1) * 32 + (k & 1) * 4, 16, 4, 8);
             q.rec = quad_rec, q.level = quad_level;
             if (k == 3) quad_ok = false;
+        } else if (size == 8 && pair_ok && pair_x == gx && pair_y == gy && take_pair(q, px, py)) {
+            // (asked for with the block to the left)
         } else if (!(in_ok[li] && q.x0 == gx && q.y0 == gy && q.size == size)) {
             IntraEval *list[4];
             int n = 0;
-            bool with_quad = false;
+            bool with_quad = false, with_pair = false;
             fill_intra(q, px, py, size);
             list[n++] = &q;
             for (int sz = size / 2, l = li - 1; sh->speculate && sz >= 4; sz /= 2, l--) {
                 if (sz == 4) {      // below the 8x8 PU: all four 4x4 PUs
-                    fill_quad(px, py);
+                    fill_quad(quad, px, py);
                     with_quad = quad_ok = true;
                     break;
                 }
@@ -1145,7 +1202,9 @@ double Row::decide_intra(int px, int py, int size, int depth)
                 in_ok[l] = true;
                 list[n++] = &in_spec[l];
             }
-            evaluate_intra(list, n, with_quad);
+            pair_ok = false;
+            if (with_quad && sh->pairs && (px & 8) == 0) fill_pair(px, py), with_pair = true;
+            evaluate_intra(list, n, with_quad, with_pair);
         }
         in_ok[li] = false;
         best_mode = q.best_mode, valids = q.valids;
@@ -1366,7 +1425,7 @@ void Row::run()
             ctu_x = x;
             std::memset(tree_ok, 0, sizeof tree_ok);
             in_ok[0] = in_ok[1] = in_ok[2] = in_ok[3] = false;
-            quad_ok = false;
+            quad_ok = pair_ok = false;
             if (y > 0) wait_row_above(x + 2 < cols ? x + 2 : cols, !S.intra);      // top-right neighbour done (or the whole row above)
 #ifdef XMI_EXP_HOST_TIMING
             const uint64_t tp0 = tick();
@@ -1540,6 +1599,7 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     S.ev = &ev;
     S.speculate = speculate;
     S.defer_chroma = speculate != 0;
+    S.pairs = speculate != 0 && std::getenv("XMI_EXP_NO_PAIRS") == nullptr;
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
     S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {
@@ -1646,6 +1706,8 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
                 for (int i = 0; i < r.n_req_in; i++) pu.push_back(r.req_in[i]);
                 if (r.req_ichroma) ichroma.push_back(&r.ichroma);
                 if (r.req_quad) quads.push_back(&r.quad);
+                if (r.req_pair)
+                    for (int h2 = 0; h2 < 2; h2++) pu.push_back(&r.pair_in[h2]), quads.push_back(&r.pair_quad[h2]);
                 if (r.req_cquad) cquads.push_back(&r.cquad);
             }
             if (served.empty() && !S.error) continue;      // a row is between counting itself out and raising its flag
@@ -1684,6 +1746,12 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     for (std::thread &t : threads) t.join();
     out.row_busy_ns = out.row_requests = 0;
     for (const Row &r : S.rows) out.row_busy_ns += r.busy_ns, out.row_requests += r.requests;
+    if (intra && std::getenv("XMI_EXP_PAIR_STATS")) {
+        uint64_t taken = 0;
+        for (const Row &r : S.rows) taken += r.pairs_taken;
+        std::fprintf(stderr, "I picture: %llu requests of rows, %llu calls, %llu blocks answered with the block to their left\n", (unsigned long long)out.row_requests,
+                     (unsigned long long)out.evaluator_calls, (unsigned long long)taken);
+    }
 #ifdef XMI_EXP_MISS_STATS
     if (!intra) {
         std::fprintf(stderr, "requests that had to be made, by CU size 8/16/32/64 (not asked ahead | guess failed | answers used): ");

@@ -74,14 +74,36 @@ struct ChromaEval {
 // the winner, its transform chain (DST for 4x4, I-slice rounding) and the SSD of the reconstruction. The neighbouring
 // samples are what the reference gathers (:4010-4015: left column from the bottom up, top-left, top row and top-right,
 // 4 size + 1 bytes) with the availability bits of :3965-3974; samples of unavailable segments are arbitrary.
+struct IntraQuadEval;
+
+// most probable modes of a luma PU from the modes to its left and above it (src/encode.cpp:3980-4003)
+inline void most_probable_modes(int left, int top, uint8_t mpm[3])
+{
+    if (left == top) {
+        if (left > 1) mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)(((left + 29) % 32) + 2), mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+        else mpm[0] = 0, mpm[1] = 1, mpm[2] = 26;
+    } else {
+        mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)top;
+        mpm[2] = (left && top) ? 0 : (left + top < 2 ? 26 : 1);
+    }
+}
+
 struct IntraEval {
     int x0, y0, size;                 // luma position in the picture, 4..32
     uint8_t valids;                   // bit 0 below-left, 1 left, 2 top-left, 3 top, 4 top-right
     uint8_t strong;                   // bStrongIntraSmoothing
     uint8_t mpm[3];
+    uint8_t left_mode = 1, top_mode = 1;      // what mpm was made from (DC where there is no neighbour)
     uint8_t ref[132];
     double sqrt_lambda;
     int qp;
+    // A request of size 8 may stand for the 8x8 block to the right of a block that is decided in the same call: its left
+    // column and the mode to its left are then those of `after_pu` (after_kind 1: the block to the left as one 8x8 PU) or of
+    // `after_quad` (2: as four 4x4 PUs), which the evaluator puts in place - ref[8..15], left_mode, mpm - before it evaluates
+    // the request (take_left_block). The caller asks for both and uses the one whose premise came true.
+    uint8_t after_kind = 0;
+    const IntraEval *after_pu = nullptr;
+    const IntraQuadEval *after_quad = nullptr;
     // results; the blocks are size x size, rows `size` apart, valid until the next call of the lane
     int best_mode;
     uint32_t ssd, sum;
@@ -117,12 +139,41 @@ struct IntraQuadEval {
     uint8_t strong;
     double sqrt_lambda;
     int qp;
+    uint8_t after_kind = 0;           // as IntraEval::after_kind: ref[8..15] and left_mode[] come from the block to the left
+    const IntraEval *after_pu = nullptr;
+    const IntraQuadEval *after_quad = nullptr;
     // results; rec and level are the 8x8 block, rows 8 apart
     int best_mode[4];
     uint32_t ssd[4], sum[4];
     const uint8_t *rec;
     const int16_t *level;
 };
+
+// What an evaluator does to a request that stands after a block of the same call, once that block's results are there: the
+// block's right column becomes the request's left column (ref[15 - row], rows 0..7), the modes of the block's right-hand
+// units the modes to the left.
+inline void left_block_of(uint8_t after_kind, const IntraEval *pu, const IntraQuadEval *quad, uint8_t col[8], uint8_t mode[2])
+{
+    const uint8_t *rec = after_kind == 1 ? pu->rec : quad->rec;      // 8x8, rows 8 apart
+    for (int r = 0; r < 8; r++) col[r] = rec[r * 8 + 7];
+    mode[0] = (uint8_t)(after_kind == 1 ? pu->best_mode : quad->best_mode[1]);
+    mode[1] = (uint8_t)(after_kind == 1 ? pu->best_mode : quad->best_mode[3]);
+}
+inline void take_left_block(IntraEval &q)
+{
+    uint8_t col[8], mode[2];
+    left_block_of(q.after_kind, q.after_pu, q.after_quad, col, mode);
+    for (int r = 0; r < 8; r++) q.ref[15 - r] = col[r];
+    q.left_mode = mode[0];
+    most_probable_modes(q.left_mode, q.top_mode, q.mpm);
+}
+inline void take_left_block(IntraQuadEval &q)
+{
+    uint8_t col[8], mode[2];
+    left_block_of(q.after_kind, q.after_pu, q.after_quad, col, mode);
+    for (int r = 0; r < 8; r++) q.ref[15 - r] = col[r];
+    q.left_mode[0] = mode[0], q.left_mode[1] = mode[1];
+}
 
 // The chroma of four neighbouring 8x8 luma blocks (an 8x8 area of the chroma planes): four IntraChromaEval of size 4 back
 // to back; nothing in xEncodeChromaCU depends on a cost comparison. ref_*: the 33 neighbouring samples of the area.
