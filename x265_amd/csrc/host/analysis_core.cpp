@@ -390,6 +390,7 @@ struct Shared {
     int grace_us = 6;               // how long a polling coordinator waits for the rows still busy before it goes without them
     int speculate = 2;              // 1: a CU's request carries those of its chain of first children; 2: of the rest of the CTU
     bool defer_chroma = true;       // a CTU's chroma requests travel with the next CTU's first luma request
+    uint16_t *ctu_requests = nullptr;      // measurement (XMI_EXP_CTU_REQUESTS): requests a row made while it decided each CTU
     bool pairs = true;              // I pictures: an 8x8 block's request takes the block to its right along (Row::fill_pair)
     std::deque<Lane> lanes;
     std::vector<int> done;          // CTUs finished per row (under the mutex)
@@ -1452,6 +1453,7 @@ void Row::run()
                 }
                 for (int r = 0; r < 8; r++) V(r, -1) = out.mv[(size_t)(y * 8 + r) * w8 + x * 8 - 1];
             }
+            const uint64_t requests_before = requests;
             const Ctx &init = (y == 0 || x > 0) ? last : S.saved[y - 1];
             for (int d = 0; d < 5; d++) cab[d] = init;
             std::memcpy(&out.ctx_in[((size_t)y * cols + x) * 256], cab[0].m, 256);
@@ -1485,6 +1487,7 @@ void Row::run()
             const uint64_t te0 = tick();
 #endif
             last = cab[0];
+            if (S.ctu_requests) S.ctu_requests[(size_t)y * cols + x] = (uint16_t)(requests - requests_before);
             std::memcpy(&out.ctx_out[((size_t)y * cols + x) * 256], cab[0].m, 256);
             for (int r = 0; r < 16; r++) {
                 std::memcpy(&out.info0[(size_t)(y * 16 + r) * w4 + x * 16], &I0(r, 0), 32);
@@ -1600,6 +1603,8 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     S.speculate = speculate;
     S.defer_chroma = speculate != 0;
     S.pairs = speculate != 0 && std::getenv("XMI_EXP_NO_PAIRS") == nullptr;
+    std::vector<uint16_t> ctu_requests;
+    if (std::getenv("XMI_EXP_CTU_REQUESTS")) ctu_requests.assign(nctu, 0), S.ctu_requests = ctu_requests.data();
     const int nl = lanes < 1 ? 1 : lanes > rows_ ? rows_ : lanes;
     S.lanes = std::deque<Lane>(nl);
     for (int y = 0; y < rows_; y++) {
@@ -1746,6 +1751,12 @@ int Analyser::picture(int qp, bool intra, int strong, Evaluator &ev, PictureResu
     for (std::thread &t : threads) t.join();
     out.row_busy_ns = out.row_requests = 0;
     for (const Row &r : S.rows) out.row_busy_ns += r.busy_ns, out.row_requests += r.requests;
+    if (S.ctu_requests) {      // one line per picture: type, columns, then the counts row by row
+        std::string line = intra ? "CTU_REQUESTS I " : "CTU_REQUESTS P ";
+        line += std::to_string(cols_);
+        for (size_t i = 0; i < nctu; i++) line += " " + std::to_string(ctu_requests[i]);
+        std::fprintf(stderr, "%s\n", line.c_str());
+    }
     if (intra && std::getenv("XMI_EXP_PAIR_STATS")) {
         uint64_t taken = 0;
         for (const Row &r : S.rows) taken += r.pairs_taken;
