@@ -106,6 +106,7 @@ public:
     // read before that is poison); let the n-th finish call fail
     bool defer = false;
     int fail_at = 0, finish_calls = 0;
+    int refuse_every = 0, refuse_count = 0;      // I pictures: every n-th request that stands after a block gets no result
     std::unordered_map<const CuEval *, CuEval> held;
 
     int finish_merge(CuEval &q) override
@@ -148,11 +149,18 @@ public:
         for (int i = 0; i < bt.nquad; i++)
             if (!bt.quad[i]->after_kind) one_quad(*bt.quad[i], b, w);
         for (int i = 0; i < bt.ncquad; i++) one_chroma_quad(*bt.cquad[i], b, w);
-        // requests that stand after a block of this call: that block's results are there now
+        // requests that stand after a block of this call: that block's results are there now. (Test switch: every n-th of them
+        // is answered as by an evaluator that could not wait for the block - no result -, and the caller has to ask again.)
         for (int i = 0; i < bt.npu; i++)
-            if (bt.pu[i]->after_kind) take_left_block(*bt.pu[i]), one_intra(*bt.pu[i], b, w);
+            if (bt.pu[i]->after_kind) {
+                take_left_block(*bt.pu[i]), one_intra(*bt.pu[i], b, w);
+                if (refuse_every && ++refuse_count % refuse_every == 0) bt.pu[i]->best_mode = -1;
+            }
         for (int i = 0; i < bt.nquad; i++)
-            if (bt.quad[i]->after_kind) take_left_block(*bt.quad[i]), one_quad(*bt.quad[i], b, w);
+            if (bt.quad[i]->after_kind) {
+                take_left_block(*bt.quad[i]), one_quad(*bt.quad[i], b, w);
+                if (refuse_every && ++refuse_count % refuse_every == 0) bt.quad[i]->best_mode[0] = -1;
+            }
         return 0;
     }
 
@@ -560,6 +568,11 @@ int orc_encoder_picture_hash(void *h, int on)
 int orc_encoder_rdoq(void *h, int on)
 {
     static_cast<EncHandle *>(h)->ev.rdoq = on != 0;
+    return 0;
+}
+int orc_encoder_refuse_pairs(void *h, int every)
+{
+    static_cast<EncHandle *>(h)->ev.refuse_every = every;
     return 0;
 }
 int orc_encoder_speculate(void *h, int level)

@@ -31,7 +31,7 @@ def checker():
     return lib
 
 
-def encode(lib, w, h, frames, qp, lanes=1, speculate=1, picture_hash=True):
+def encode(lib, w, h, frames, qp, lanes=1, speculate=1, picture_hash=True, refuse_pairs=0):
     from x265_amd.encoder import align_frame
     W, H = (w + 63) // 64 * 64, (h + 63) // 64 * 64
     enc = lib.orc_encoder_create(W, H, qp, 0)
@@ -41,6 +41,9 @@ def encode(lib, w, h, frames, qp, lanes=1, speculate=1, picture_hash=True):
     if not picture_hash:
         lib.orc_encoder_picture_hash.argtypes = [C.c_void_p, C.c_int]
         assert lib.orc_encoder_picture_hash(enc, 0) == 0
+    if refuse_pairs:
+        lib.orc_encoder_refuse_pairs.argtypes = [C.c_void_p, C.c_int]
+        assert lib.orc_encoder_refuse_pairs(enc, refuse_pairs) == 0
     rng = np.random.default_rng(1234)
     out = np.zeros(W * H * 3 + 4096, np.uint8)
     stream, raw = b"", b""
@@ -53,6 +56,17 @@ def encode(lib, w, h, frames, qp, lanes=1, speculate=1, picture_hash=True):
         stream += bytes(out[:n])
     lib.orc_encoder_destroy(enc)
     return stream, raw
+
+
+@pytest.mark.parametrize("every", [1, 3])
+def test_an_evaluator_that_cannot_wait_for_the_block_to_the_left_makes_the_row_ask_again(every):
+    """I pictures: the 8x8 block to the right of a block goes along with that block's request, evaluated after it; an evaluator
+    may answer such a request with "no result" (best_mode -1). The stream is the recorded one whether every such request or
+    every third is refused."""
+    lib = checker()
+    want = GOLD["416x240_f3_q22"]
+    stream, _ = encode(lib, 416, 240, 3, 22, lanes=2, speculate=2, refuse_pairs=every)
+    assert hashlib.md5(stream).hexdigest() == want["md5"]
 
 
 @pytest.mark.parametrize("key,lanes,speculate", [("416x240_f8_q32", 1, 1), ("416x240_f3_q22", 2, 2), ("416x240_f8_q37", 1, 1)])
