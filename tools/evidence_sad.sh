@@ -2,7 +2,7 @@
 # usage: tools/evidence_sad.sh <tag>   (GPU box, through gpurun) -> gpurun_out/evidence_<tag>/
 # Steady-state evidence for the SAD surface kernel: per-launch durations of a long burst (product library and the
 # store-free / compute-free variants), per-workgroup clocks after bursts of different length, and the microbenchmarks
-# the bounds in DESIGN.md are taken from. Variant libraries are built beforehand with tools/build_variant.sh
+# that give the store and issue bounds quoted for the kernel. Variant libraries are built beforehand with tools/build_variant.sh
 # (timeline: -DXMI_EXP_TIMELINE, nostore: -DXMI_EXP_NOSTORE, nocompute: -DXMI_EXP_NOCOMPUTE).
 tag=$1
 export TMPDIR=/tmp
